@@ -1,0 +1,391 @@
+#!/usr/bin/env python
+"""Generate the golden fixtures in tests/golden/ by RUNNING THE REFERENCE in this container.
+
+Build-container only (needs /root/reference, which does not exist on the GPU box).
+Nothing from the reference is copied: it is imported, executed on seeded inputs, and
+only inputs + outputs (numbers) are written to ``*.npz``.  The fixtures also include the
+PM25 data file and known answers the reference itself stores
+(ExperimentImpute/data/LondonAir_PM25.csv, ExperimentImpute/output/*.json).
+
+The reference needs two third-party modules that are not installed here:
+  * ``autograd`` (pypsmf/psmf/psmf.py:6-8): stubbed below; ``autograd.numpy`` is numpy,
+    ``jacobian`` is a complex-step Jacobian (exact to round-off for sin/cos/@ code) and
+    ``grad`` is a Richardson-extrapolated central difference (h = 1e-6; accurate to ~1e-8 rel).
+    The filter recursion itself (C, V, mu, P, y_pred, eta, N, phi, omega) is plain numpy
+    and is not affected by the stub; only F = df/dx and the theta gradient are.
+  * ``safer`` (ExperimentImpute/common.py:15): only used to write JSON; stubbed.
+
+Usage:  python tests/golden/make_golden.py
+"""
+
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = "/root/reference"
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+# ---------------------------------------------------------------- stubs
+def _install_stubs():
+    ag = types.ModuleType("autograd")
+    ag.numpy = np
+
+    def jacobian(fun, argnum=0):
+        def jac(*args):
+            x = np.asarray(args[argnum], dtype=float)
+            base = np.asarray(fun(*args))
+            out = np.zeros(base.shape + x.shape)
+            h = 1e-30
+            for idx in np.ndindex(x.shape):
+                xp = x.astype(complex)
+                xp[idx] += 1j * h
+                a = list(args)
+                a[argnum] = xp
+                a = [np.asarray(v, dtype=complex) if i == 0 else v for i, v in enumerate(a)]
+                out[(Ellipsis,) + idx] = np.asarray(fun(*a)).imag / h
+            return out
+
+        return jac
+
+    def grad(fun, argnum=0):
+        def g(*args):
+            x = np.asarray(args[argnum], dtype=float)
+            out = np.zeros_like(x)
+
+            def ev(xv):
+                a = list(args)
+                a[argnum] = xv
+                return float(np.asarray(fun(*a)).squeeze())
+
+            for idx in np.ndindex(x.shape):
+                h = 1e-6 * max(1.0, abs(x[idx]))  # f oscillates with 2 pi t in theta: keep h t << 1
+
+                def cd(hh):
+                    xp = x.copy()
+                    xm = x.copy()
+                    xp[idx] += hh
+                    xm[idx] -= hh
+                    return (ev(xp) - ev(xm)) / (2 * hh)
+
+                out[idx] = (4.0 * cd(h / 2) - cd(h)) / 3.0
+            return out
+
+        return g
+
+    ag.grad = grad
+    ag.jacobian = jacobian
+    sys.modules["autograd"] = ag
+    sys.modules["autograd.numpy"] = np
+    sf = types.ModuleType("safer")
+    sf.open = open
+    sys.modules["safer"] = sf
+
+
+_install_stubs()
+import matplotlib  # noqa: E402
+
+matplotlib.use("Agg")
+sys.path.insert(0, os.path.join(REF, "pypsmf"))
+sys.path.insert(0, os.path.join(REF, "ExperimentSynthetic"))
+
+import psmf as refpkg  # noqa: E402
+from psmf.nonlinearities import FourierBasis, RandomWalk  # noqa: E402
+
+
+# ---------------------------------------------------------------- helpers
+def snapshotting(cls, keep):
+    """Subclass ``cls`` so the state after the steps in ``keep`` is recorded before pruning."""
+
+    class Snap(cls):
+        def _compute_dictionary_innovation(self, k, eta_k, mu_bar, P_bar):
+            Nk = super()._compute_dictionary_innovation(k, eta_k, mu_bar, P_bar)
+            self._snap_scal[k] = (float(np.squeeze(eta_k)), float(np.squeeze(Nk)))
+            return Nk
+
+        def _prune(self, k):
+            if k in keep:
+                rec = dict(C=self._C[k].copy(), V=self._V[k].copy(), mu=self._mu[k].copy(),
+                           P=self._P[k].copy(), eta=self._snap_scal[k][0], N=self._snap_scal[k][1])
+                if hasattr(self, "_lambda"):
+                    rec["lam"] = float(self._lambda[k])
+                    rec["Q"] = np.array(self._Q[k])
+                    rec["rho"] = float(np.asarray(self._R[k])[0, 0])
+                self._snaps[self._epoch][k] = rec
+            try:
+                super()._prune(k)
+            except KeyError:
+                pass
+
+        def step(self, *a, **kw):
+            self._epoch = getattr(self, "_epoch", 0) + 1
+            if not hasattr(self, "_snaps"):
+                self._snaps = {}
+            self._snaps[self._epoch] = {}
+            self._snap_scal = {}
+            return super().step(*a, **kw)
+
+    return Snap
+
+
+def flat_snaps(prefix, snaps):
+    out = {}
+    for ep, d in snaps.items():
+        for k, rec in d.items():
+            for name, val in rec.items():
+                out[f"{prefix}_e{ep}_k{k}_{name}"] = np.asarray(val)
+    return out
+
+
+def ydict(Y):
+    """(T, d) -> {k: (d,1)} keyed 1..T"""
+    return {k + 1: Y[k][:, None].copy() for k in range(Y.shape[0])}
+
+
+def ypred_arr(obj, T):
+    return np.array([np.asarray(obj._y_pred[k]).reshape(-1) for k in range(1, T + 1)])
+
+
+# ---------------------------------------------------------------- cases: pypsmf classes
+def case_full(robust, seed, d=20, r=5, T=200, keep=(1, 2, 10, 200)):
+    rng = np.random.default_rng(seed)
+    Ctrue = rng.standard_normal((d, r))
+    x = rng.standard_normal(r)
+    Y = np.empty((T, d))
+    for t in range(T):
+        x = x + 0.1 * rng.standard_normal(r)
+        noise = rng.standard_t(3.0, d) if robust else rng.standard_normal(d)
+        Y[t] = Ctrue @ x + np.sqrt(0.1) * noise
+    C0 = 0.1 * rng.standard_normal((d, r))
+    V0 = 0.1 * np.eye(r)
+    mu0 = np.zeros((r, 1))
+    P0 = np.eye(r)
+    Q = 0.1 * np.eye(r)
+    theta0 = np.zeros((0, 1))
+    nl = RandomWalk()
+    if robust:
+        cls = snapshotting(refpkg.rPSMFIter, set(keep))
+        obj = cls(theta0, C0, V0, mu0, P0, Q, np.eye(d), 1.8, nl)
+    else:
+        cls = snapshotting(refpkg.PSMFIter, set(keep))
+        obj = cls(theta0, C0, V0, mu0, P0, {k: Q for k in range(T + 1)},
+                  {k: np.eye(d) for k in range(T + 1)}, nl)
+    obj.optim_init()
+    obj.step(ydict(Y), 1, T)
+    obj.optim_update(1)  # theta is empty for RandomWalk; creates _theta[1]
+    obj.step(ydict(Y), 2, T)  # second epoch: state carried by step_reset (psmf.py:75-83)
+    out = dict(Y=Y, C0=C0, V0=V0, mu0=mu0.reshape(-1), P0=P0, Q=Q, rho=1.0, lambda0=1.8,
+               y_pred_e2=ypred_arr(obj, T))
+    out.update(flat_snaps("s", obj._snaps))
+    return out
+
+
+def cos_nl(theta, x, t):
+    return np.cos(2 * np.pi * theta * t + x)
+
+
+def case_synthetic(robust, seed, d=20, r=6, T=120, n_pred=40, n_iter=3):
+    """The ExperimentSynthetic subclasses (simplified hooks), reference data generator, fixed seed."""
+    import data as refdata  # ExperimentSynthetic/data.py
+
+    if robust:
+        import synthetic_rpsmf as mod
+
+        base = mod.rPSMFIterSynthetic
+    else:
+        import synthetic_psmf as mod
+
+        base = mod.PSMFIterSynthetic
+    np.random.seed(seed)
+    if robust:
+        dat = refdata.generate_t_data(cos_nl, d=d, T=T, n_pred=n_pred, r=r, var=0.1, dof=3.0)
+    else:
+        dat = refdata.generate_normal_data(cos_nl, d=d, T=T, n_pred=n_pred, r=r, var=0.1)
+    C0 = 0.1 * np.random.randn(d, r)
+    theta0 = 0.1 * np.random.rand(r, 1)
+    V0 = 0.1 * np.eye(r)
+    mu0 = np.zeros((r, 1))
+    P0 = np.zeros((r, r))
+    keep = {1, 2, 10, T}
+    cls = snapshotting(base, keep)
+    if robust:
+        obj = cls(theta0, C0, V0, mu0, P0, 0 * np.eye(r), np.eye(d), 1.8, cos_nl)
+    else:
+        obj = cls(theta0, C0, V0, mu0, P0, {k: 0 * np.eye(r) for k in range(T + 1)},
+                  {k: np.eye(d) for k in range(T + 1)}, cos_nl)
+    # the experiment's own run() minus figures (synthetic_psmf.py:47-74)
+    obj.adam_init(gam=1e-3)
+    obj.errors_init(dat["y_obs"], T, n_iter, n_pred, theta_true=dat["theta_true"])
+    grads = []
+    for i in range(1, n_iter + 1):
+        obj.step(dat["y_train"], i, T)
+        obj.predict(i, T, n_pred)
+        grads.append(obj._gradsum.reshape(-1).copy())
+        obj.adam_update(i)
+        obj.errors_update(i, dat["y_obs"], T, n_pred, theta_true=dat["theta_true"])
+    Yobs = np.array([dat["y_obs"][k].reshape(-1) for k in range(1, T + n_pred + 1)])
+    out = dict(Y_obs=Yobs, C0=C0, theta0=theta0.reshape(-1), V0=V0, mu0=mu0.reshape(-1), P0=P0,
+               theta_true=np.asarray(dat["theta_true"]).reshape(-1), lambda0=1.8,
+               T=T, n_pred=n_pred, n_iter=n_iter,
+               theta=np.array([obj._theta[i].reshape(-1) for i in range(n_iter + 1)]),
+               gradsum=np.array(grads),
+               E_y=np.array([obj._E_y[i] for i in range(n_iter + 1)]),
+               E_train=np.array([obj._E_train[i] for i in range(n_iter + 1)]),
+               E_pred=np.array([obj._E_pred[i] for i in range(n_iter + 1)]),
+               E_theta=np.array([obj._E_theta[i] for i in range(n_iter + 1)]),
+               y_pred_last=ypred_arr(obj, T + n_pred),
+               mu_last=np.array([obj._mu[k].reshape(-1) for k in range(0, T + 1)]))
+    out.update(flat_snaps("s", obj._snaps))
+    return out
+
+
+def case_fourier(seed, d=3, r=1, T=60, n_pred=10, n_iter=2):
+    """Full (un-simplified) PSMFIter with FourierBasis(N=1), Beijing-style (beijing_psmf.py:97-140).
+
+    r = 1 as in the experiment: FourierBasis broadcasts (r,)*(r,1) -> (r,r) for r > 1
+    (nonlinearities.py:143), so it only works at rank 1.
+    """
+    rng = np.random.default_rng(seed)
+    nl = FourierBasis(rank=r, N=1)
+    t = np.arange(1, T + n_pred + 1)
+    Y = np.stack([np.sin(2 * np.pi * t / 23.0 + j) + 0.1 * rng.standard_normal(t.size) for j in range(d)], 1)
+    C0 = 5 * rng.standard_normal((d, r))
+    theta0 = 0.1 * rng.random((nl.n_params, 1))
+    V0 = 5.0 * np.eye(r)
+    mu0 = np.zeros((r, 1))
+    P0 = np.eye(r)
+    Q0 = np.eye(r)
+    cls = snapshotting(refpkg.PSMFIter, {1, 2, 10, T})
+    obj = cls(theta0, C0, V0, mu0, P0, {k: Q0 for k in range(T + 1)},
+              {k: np.eye(d) for k in range(T + 1)}, nl)
+    obj.adam_init(gam=1e-3)
+    grads = []
+    for i in range(1, n_iter + 1):
+        obj.step(ydict(Y[:T]), i, T)
+        obj.predict(i, T, n_pred)
+        grads.append(obj._gradsum.reshape(-1).copy())
+        obj.adam_update(i, project=True)
+    out = dict(Y=Y, C0=C0, theta0=theta0.reshape(-1), V0=V0, mu0=mu0.reshape(-1), P0=P0, Q=Q0, rho=1.0,
+               T=T, n_pred=n_pred, n_iter=n_iter,
+               theta=np.array([obj._theta[i].reshape(-1) for i in range(n_iter + 1)]),
+               gradsum=np.array(grads), y_pred_last=ypred_arr(obj, T + n_pred))
+    out.update(flat_snaps("s", obj._snaps))
+    return out
+
+
+def case_recursive(robust, seed, d=10, r=3, T=60, n_pred=10):
+    """PSMFRecursive / rPSMFRecursive: theta Adam step inside the time loop (psmf.py:287-304)."""
+    rng = np.random.default_rng(seed)
+    Ctrue = rng.standard_normal((d, r))
+    th_true = 1e-3 * np.arange(1, r + 1)[:, None]
+    x = rng.standard_normal((r, 1))
+    Y = np.empty((T, d))
+    for t in range(1, T + 1):
+        x = cos_nl(th_true, x, t)
+        Y[t - 1] = (Ctrue @ x).reshape(-1) + np.sqrt(0.1) * rng.standard_normal(d)
+    C0 = 0.1 * rng.standard_normal((d, r))
+    theta0 = 0.1 * rng.random((r, 1))
+    V0 = 0.1 * np.eye(r)
+    mu0 = np.zeros((r, 1))
+    P0 = 0.5 * np.eye(r)
+    Q = 0.05 * np.eye(r)
+    if robust:
+        obj = refpkg.rPSMFRecursive(theta0, C0, V0, mu0, P0, Q, np.eye(d), 1.8, cos_nl)
+    else:
+        obj = refpkg.PSMFRecursive(theta0, C0, V0, mu0, P0, {k: Q for k in range(T + 1)},
+                                   {k: np.eye(d) for k in range(T + 1)}, cos_nl)
+    obj.run(ydict(Y), T, n_pred, update_every=2)
+    return dict(Y=Y, C0=C0, theta0=theta0.reshape(-1), V0=V0, mu0=mu0.reshape(-1), P0=P0, Q=Q, rho=1.0,
+                lambda0=1.8, T=T, n_pred=n_pred, update_every=2,
+                theta=np.array([obj._theta[k].reshape(-1) for k in range(T + 1)]),
+                C_T=obj._C[T], V_T=obj._V[T], mu_T=obj._mu[T].reshape(-1), P_T=obj._P[T],
+                y_pred=ypred_arr(obj, T + n_pred))
+
+
+# ---------------------------------------------------------------- cases: ExperimentImpute
+def _impute_modules():
+    sys.path.insert(0, os.path.join(REF, "ExperimentImpute"))
+    cwd = os.getcwd()
+    os.chdir("/tmp")  # joblib.Memory("./cache") is created at import (PSMF.py:27)
+    import common as ref_common
+    import PSMF as ref_psmf
+    import rPSMF as ref_rpsmf
+
+    os.chdir(cwd)
+    return ref_common, ref_psmf, ref_rpsmf
+
+
+def case_impute_synth(seed=7, d=19, n=400, r=10):
+    ref_common, ref_psmf, ref_rpsmf = _impute_modules()
+    np.random.seed(seed)
+    base = np.cumsum(0.3 * np.random.randn(d, n), axis=1) + 10.0 * np.random.rand(d, 1)
+    Yorig = base.copy()
+    Yorig[np.random.rand(d, n) < 0.01] = np.nan  # 1 % native missing
+    YorigInt = np.nan_to_num(Yorig, nan=0.0)
+    Ymiss = Yorig.copy()
+    ratio, Mmiss = ref_common.prepare_missing(Ymiss, 0.4)
+    M = np.array(np.invert(np.isnan(Ymiss)), dtype=int)
+    Y = np.nan_to_num(Ymiss, nan=0.0)
+    C = np.random.rand(d, r)
+    X = np.random.rand(r, n)
+    Einit = ref_common.RMSEM(C @ X, YorigInt, Mmiss)
+    out = dict(Yorig=Yorig, Mmiss=Mmiss, M=M, Y=Y, C0=C, X0=X, Einit=Einit, ratio=ratio)
+    V, Q, P = 2 * np.eye(r), 0.1 * np.eye(r), 1.0 * np.eye(r)
+    R = 10 * np.eye(d)
+    Xa = X.copy()
+    ep, ef, _, ib = ref_psmf.ProbabilisticSequentialMatrixFactorizer.func(
+        Y, C.copy(), Xa, d, n, r, M, Mmiss, 10, V, Q, R, P, 2, 2, YorigInt, Einit)
+    out.update(psmf_Epred=ep, psmf_Efull=ef, psmf_inside=ib, psmf_X=Xa)
+    Xb = X.copy()
+    ep, ef, _, ib = ref_rpsmf.robust_PSMF.func(
+        Y, C.copy(), Xb, d, n, r, M, Mmiss, V, Q, R, P, 1.8, 2, 2, YorigInt, Einit)
+    out.update(rpsmf_Epred=ep, rpsmf_Efull=ef, rpsmf_inside=ib, rpsmf_X=Xb)
+    return out
+
+
+def case_impute_kat(dataset="LondonAir_PM25", n_rep=2):
+    """The reference's stored known answers + the data file they were computed on."""
+    Yorig = np.genfromtxt(os.path.join(REF, "ExperimentImpute/data", dataset + ".csv"), delimiter=",")
+    out = dict(Yorig=Yorig)
+    for pct in (20, 30, 40):
+        for method in ("PSMF", "rPSMF"):
+            with open(os.path.join(REF, "ExperimentImpute/output", f"{dataset}_{pct}_{method}.json")) as fp:
+                j = json.load(fp)
+            assert j["seed"] == 123
+            key = f"{method}_{pct}"
+            for name in ("error_full", "error_predict", "inside_sig"):
+                out[f"{key}_{name}"] = np.array(j["results"][name][:n_rep])
+            for name in ("Y", "C", "X"):
+                out[f"{key}_hash_{name}"] = np.array(j["hashes"][name][:n_rep])
+            out[f"{key}_missing_ratio"] = j["missing_ratio"]
+            out[f"{key}_params"] = json.dumps(j["parameters"])
+    return out
+
+
+def main():
+    cases = {
+        "psmf_full_rw": lambda: case_full(False, 11),
+        "rpsmf_full_rw": lambda: case_full(True, 12),
+        "psmf_simplified_cos": lambda: case_synthetic(False, 35853),
+        "rpsmf_simplified_cos": lambda: case_synthetic(True, 35833),
+        "psmf_full_fourier": lambda: case_fourier(13),
+        "psmf_recursive": lambda: case_recursive(False, 14),
+        "rpsmf_recursive": lambda: case_recursive(True, 15),
+        "impute_synth": case_impute_synth,
+        "impute_kat_pm25": case_impute_kat,
+    }
+    only = sys.argv[1:]
+    for name, fn in cases.items():
+        if only and name not in only:
+            continue
+        data = fn()
+        path = os.path.join(OUT, name + ".npz")
+        np.savez_compressed(path, **data)
+        print("wrote", path, os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()
