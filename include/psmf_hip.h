@@ -1,0 +1,174 @@
+/*
+ * psmf_hip.h -- C ABI of the MI355X (gfx950) PSMF / rPSMF filter library  (libpsmf_hip.so)
+ *
+ * The reference (alan-turing-institute/rPSMF) is pure Python and has no FFI layer; the
+ * functions below are what a ctypes binding for its hot path binds instead of executing the
+ * Python/numpy bodies cited next to each entry point (paths relative to the reference root).
+ * Plain pointers and sizes only; no exceptions cross the boundary; every function returns
+ * PSMF_OK (0) or a negative psmf_status, and psmf_last_error() gives the message.
+ *
+ * Conventions
+ *   - the caller owns all host buffers; the library owns all device memory;
+ *   - host matrices are row-major float64 unless a dtype argument says otherwise;
+ *   - one handle = one filter (or one row-shard of a filter on one GPU); a handle is not
+ *     thread-safe, independent handles may be used from different threads;
+ *   - calls are asynchronous on the handle's HIP stream unless they return host data.
+ */
+#ifndef PSMF_HIP_H
+#define PSMF_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PSMF_ABI_VERSION 1
+#define PSMF_RMAX 64 /* largest supported rank r */
+
+typedef enum {
+  PSMF_OK = 0,
+  PSMF_ERR_ARG = -1,         /* bad argument / shape / unsupported configuration           */
+  PSMF_ERR_HIP = -2,         /* HIP runtime error                                          */
+  PSMF_ERR_RCCL = -3,        /* RCCL error                                                 */
+  PSMF_ERR_NUMERIC = -4,     /* singular r x r system (numpy.linalg.LinAlgError upstream)  */
+  PSMF_ERR_STATE = -5,       /* call sequence error (e.g. run before set_state)            */
+  PSMF_ERR_NO_DEVICE = -6    /* no HIP device visible                                      */
+} psmf_status;
+
+typedef enum { PSMF_F32 = 0, PSMF_F64 = 1 } psmf_dtype;
+
+/* State transition f(theta, x, t) evaluated on the device.
+ * PSMF_DYN_RANDOM_WALK  f = x                         pypsmf/psmf/nonlinearities.py:42-56
+ * PSMF_DYN_COS_PHASE    f = cos(2 pi theta t + x)     ExperimentSynthetic/synthetic_psmf.py:105-106 */
+typedef enum { PSMF_DYN_RANDOM_WALK = 0, PSMF_DYN_COS_PHASE = 1 } psmf_dyn_kind;
+
+typedef struct psmf_filter* psmf_handle;
+
+/* Mode table: which hook configuration of PSMFIter / rPSMFIter runs fused. */
+typedef struct {
+  int32_t abi_version;   /* PSMF_ABI_VERSION                                                  */
+  int32_t d;             /* global number of rows of C (= len(y_k))                           */
+  int32_t r;             /* rank, 1..PSMF_RMAX                                                */
+  int32_t row0;          /* first global row held by this handle (row sharding)               */
+  int32_t d_local;       /* rows held by this handle (== d when not sharded)                  */
+  int32_t robust;        /* 0: PSMFIter  psmf.py:90-180;  1: rPSMFIter  rpsmf.py:116-184      */
+  int32_t coef_update;   /* 1: Kalman update of (mu, P) psmf.py:140-165; 0: mu_k = mu_bar,
+                            P_k = P_bar  (synthetic_psmf.py:89-98)                            */
+  int32_t eta_full;      /* 1: eta = tr(R + C Pbar C^T)/d  psmf.py:121-125; 0: tr(R)/d        */
+  int32_t pbar_predict;  /* 1: Pbar = F P F^T + Q  psmf.py:107-115; 0: Pbar = P_{k-1}         */
+  int32_t fixed_lambda;  /* rpsmf.py:36-40                                                    */
+  int32_t dyn_kind;      /* psmf_dyn_kind                                                     */
+  int32_t n_theta;       /* 0 for random walk, r for cos-phase                                */
+  int32_t storage;       /* psmf_dtype of C, y, y_pred in HBM (arithmetic on r x r is f64)    */
+  int32_t store_y_pred;  /* keep y_hat_k = C_{k-1} mu_bar_k for every step (psmf.py:93)       */
+  int32_t recursive;     /* 1: PSMFRecursive -- Adam step on theta inside the time loop every
+                            `update_every` steps (psmf.py:287-304)                            */
+  int32_t update_every;
+  int32_t gram_refresh;  /* recompute G = C^T C exactly every this many steps (0 = only at
+                            set_state); between refreshes G is updated algebraically           */
+  int32_t device;        /* HIP device ordinal                                                */
+  int32_t use_graph;     /* 1: replay the per-step launches from a hipGraph                   */
+  int32_t n_workgroups;  /* row-sweep workgroups, 0 = auto                                    */
+  double alpha, beta;    /* rPSMF scaling factors (rpsmf.py:45-51), 1.0 unless use_scaling     */
+  double adam_lr, adam_lr_end, adam_lr_steps; /* lr (Constant) or lr_start/lr_end/steps
+                            (ExponentialLearningRate, learning_rate.py:20-27; steps = 0 ->
+                            constant), used when recursive = 1                                 */
+  double adam_b1, adam_b2;
+} psmf_config;
+
+/* ---- lifetime -------------------------------------------------------------------------- */
+/* replaces PSMFIter.__init__ / rPSMFIter.__init__  (psmf.py:18-46, rpsmf.py:12-51) */
+int psmf_create(psmf_handle* out, const psmf_config* cfg);
+void psmf_destroy(psmf_handle h);
+const char* psmf_last_error(psmf_handle h); /* h may be NULL: error of the last failed create */
+int psmf_device_count(void);
+
+/* ---- state ----------------------------------------------------------------------------- */
+/* Any pointer may be NULL = leave that part unchanged.  C: d_local x r;  V, P, Q: r x r;
+ * mu: r; theta: n_theta.  rho = diag(R) (uniform), lambda0 = Student-t dof (rPSMF).
+ * Pass a NaN for rho / lambda0 to leave them unchanged.
+ * replaces step_reset (psmf.py:75-83, rpsmf.py:106-114) and the constructors' state. */
+int psmf_set_state(psmf_handle h, const double* C, const double* V, const double* P,
+                   const double* Q, const double* mu, double rho, double lambda0,
+                   const double* theta);
+int psmf_zero_gradsum(psmf_handle h);
+/* scalars[8] = { rho_k, lambda_k, s, eta, N, phi, omega, step_counter } of the last step. */
+int psmf_get_state(psmf_handle h, double* C, double* V, double* P, double* Q, double* mu,
+                   double* theta, double* gradsum, double* scalars);
+/* Adam moments for the recursive mode (psmf.py:190-204): m, v of length n_theta. */
+int psmf_set_adam(psmf_handle h, const double* m, const double* v);
+
+/* ---- series ---------------------------------------------------------------------------- */
+/* Y: nt x d_local time-major block holding y_{t0+1} .. y_{t0+nt}; T_total sizes the device
+ * buffers on first use.  replaces the dict y[k] of (d,1) arrays passed to step (psmf.py:85-88) */
+int psmf_upload_series(psmf_handle h, const void* Y, int dtype, int64_t t0, int64_t nt,
+                       int64_t T_total);
+
+/* ---- the hot loop ---------------------------------------------------------------------- */
+/* for k in k_begin+1 .. k_end: inner(k, y_k)  entirely on the device
+ * replaces PSMFIter.step / inner and its ten hooks (psmf.py:85-180), rPSMFIter overrides
+ * (rpsmf.py:116-184), PSMFRecursive.inner (psmf.py:287-304). Asynchronous. */
+int psmf_run(psmf_handle h, int64_t k_begin, int64_t k_end);
+int psmf_sync(psmf_handle h); /* waits, then reports a device-side numeric failure if any */
+
+/* y_hat for steps t0+1..t0+nt (needs store_y_pred) -> out (nt x d_local), dtype f32/f64 */
+int psmf_download_y_pred(psmf_handle h, void* out, int dtype, int64_t t0, int64_t nt);
+/* psmf.py:182-188: mu rolled forward n_pred steps from the current state, y_hat = C mu_pred;
+ * out: n_pred x d_local float64.  T = index of the last filtered step. */
+int psmf_predict(psmf_handle h, int64_t T, int64_t n_pred, double* out);
+/* sum_t sum_i (y_hat - y)^2 over steps t0+1..t0+nt of the uploaded series (local rows);
+ * tracking.py:63-76 error norms without copying y_pred back. */
+int psmf_sq_error(psmf_handle h, int64_t t0, int64_t nt, double* out);
+
+/* ---- multi-GPU (row shards, one process per GPU, RCCL over xGMI) ------------------------- */
+#define PSMF_UNIQUE_ID_BYTES 128
+int psmf_comm_unique_id(void* id_out /* PSMF_UNIQUE_ID_BYTES */);
+int psmf_comm_init(psmf_handle h, int nranks, int rank, const void* unique_id);
+
+/* ---- measurement ------------------------------------------------------------------------ */
+/* psmf_run bracketed by HIP events on the handle's stream; *ms = elapsed milliseconds. */
+int psmf_run_timed(psmf_handle h, int64_t k_begin, int64_t k_end, float* ms);
+/* average duration (microseconds) of `iters` back-to-back launches of one kernel of the step
+ * on the handle's stream, HIP-event timed: which = 0 row sweep (+ concurrent r x r solve),
+ * 1 = serial r x r stage.  State is saved and restored around the measurement. */
+int psmf_time_kernel(psmf_handle h, int which, int iters, float* avg_us);
+/* geometry actually used: out[0] = sweep workgroups, out[1] = rows per workgroup,
+ * out[2] = padded row length (elements), out[3] = lanes per row, out[4] = graph chunk steps */
+int psmf_geometry(psmf_handle h, int32_t* out5);
+
+/* ================= masked, batched small-d filter (ExperimentImpute) ==================== */
+typedef struct {
+  int32_t abi_version;
+  int32_t d, n, r;       /* Y is d x n, C d x r, X r x n (reference layout)                  */
+  int32_t batch;         /* independent replicas (seeds): own mask, C0, X0                    */
+  int32_t robust;        /* 0: PSMF.py:40-95   1: rPSMF.py:40-148                              */
+  int32_t n_iter;        /* passes over the n columns (Iter)                                  */
+  int32_t device;
+  int32_t want_bands;    /* also return Yrec, YrecL, YrecH                                    */
+  double sig;            /* band half-width in standard deviations                             */
+  double lambda0;
+} psmf_impute_config;
+
+/* All arrays time-major (column t of the reference's d x n matrices is row t here):
+ *   YorgInt  n x d  float64  data with native missing values set to 0        (shared)
+ *   M        batch x n x d  uint8   1 = observed                              (per replica)
+ *   Mmiss    batch x n x d  uint8   1 = artificially removed (evaluation set)
+ *   C        batch x d x r  float64 in: C0   out: final C
+ *   X        batch x n x r  float64 in: X0   out: final X (the reference mutates X in place)
+ *   V, P, Q  r x r float64 (shared initial values);  rho = uniform diag(R)
+ *   Epred, Efull  batch x n_iter  (RMSE after each pass, PSMF.py:88-89)
+ *   inside        batch           (coverage, common.py:87-94)
+ *   Yrec, YrecL, YrecH  batch x n x d float64 or NULL
+ * replaces ProbabilisticSequentialMatrixFactorizer / robust_PSMF and the RMSEM /
+ * compute_number_inside_bars calls made on their outputs. */
+int psmf_impute_run(const psmf_impute_config* cfg, const double* YorgInt, const uint8_t* M,
+                    const uint8_t* Mmiss, double* C, double* X, const double* V,
+                    const double* P, const double* Q, double rho, double* Epred, double* Efull,
+                    double* inside, double* Yrec, double* YrecL, double* YrecH, float* elapsed_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PSMF_HIP_H */

@@ -1,0 +1,261 @@
+"""ctypes binding of include/psmf_hip.h (libpsmf_hip.so).  numpy + ctypes only.
+
+There is no CPU fallback behind this module: if the shared library is missing, or no HIP
+device is visible, the device path raises.
+"""
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libpsmf_hip.so")
+
+ABI_VERSION = 1
+RMAX = 64
+F32, F64 = 0, 1
+DYN_RANDOM_WALK, DYN_COS_PHASE = 0, 1
+UNIQUE_ID_BYTES = 128
+
+OK, ERR_ARG, ERR_HIP, ERR_RCCL, ERR_NUMERIC, ERR_STATE, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5, -6
+
+
+class PsmfError(RuntimeError):
+    pass
+
+
+class PsmfConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "abi_version", "d", "r", "row0", "d_local", "robust", "coef_update", "eta_full", "pbar_predict",
+        "fixed_lambda", "dyn_kind", "n_theta", "storage", "store_y_pred", "recursive", "update_every",
+        "gram_refresh", "device", "use_graph", "n_workgroups")] + [(n, C.c_double) for n in (
+        "alpha", "beta", "adam_lr", "adam_lr_end", "adam_lr_steps", "adam_b1", "adam_b2")]
+
+
+class PsmfImputeConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "abi_version", "d", "n", "r", "batch", "robust", "n_iter", "device", "want_bands")] + [
+        ("sig", C.c_double), ("lambda0", C.c_double)]
+
+
+_dp = C.POINTER(C.c_double)
+_u8p = C.POINTER(C.c_uint8)
+
+# name -> (restype, argtypes); every symbol include/psmf_hip.h declares
+SIGNATURES = {
+    "psmf_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(PsmfConfig)]),
+    "psmf_destroy": (None, [C.c_void_p]),
+    "psmf_last_error": (C.c_char_p, [C.c_void_p]),
+    "psmf_device_count": (C.c_int, []),
+    "psmf_set_state": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_double, _dp]),
+    "psmf_zero_gradsum": (C.c_int, [C.c_void_p]),
+    "psmf_get_state": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
+    "psmf_set_adam": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "psmf_upload_series": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int64]),
+    "psmf_run": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64]),
+    "psmf_sync": (C.c_int, [C.c_void_p]),
+    "psmf_download_y_pred": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64]),
+    "psmf_predict": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, _dp]),
+    "psmf_sq_error": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, _dp]),
+    "psmf_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "psmf_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "psmf_run_timed": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_float)]),
+    "psmf_time_kernel": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    "psmf_geometry": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "psmf_impute_run": (C.c_int, [C.POINTER(PsmfImputeConfig), _dp, _u8p, _u8p, _dp, _dp, _dp, _dp, _dp,
+                                  C.c_double, _dp, _dp, _dp, _dp, _dp, _dp, C.POINTER(C.c_float)]),
+}
+
+_lib = None
+
+
+def load_library():
+    """dlopen libpsmf_hip.so and type every entry point.  Raises if it was not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PsmfError(
+            f"{LIB_PATH} is missing: build it with `python -m rpsmf_amd.build` "
+            "(hipcc --offload-arch=gfx950).  The device path has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(_dp)
+
+
+def _f64(a, shape=None):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+class DeviceFilter:
+    """One device-resident filter (or row shard).  Thin, argument-checking wrapper of the C ABI."""
+
+    def __init__(self, d, r, *, robust=False, coef_update=True, eta_full=True, pbar_predict=True,
+                 fixed_lambda=False, dyn_kind=DYN_RANDOM_WALK, storage="f32", store_y_pred=True,
+                 recursive=False, update_every=1, gram_refresh=0, device=0, use_graph=True,
+                 n_workgroups=0, alpha=1.0, beta=1.0, adam_lr=1e-3, adam_lr_end=0.0, adam_lr_steps=0.0,
+                 adam_b1=0.9, adam_b2=0.999, row0=0, d_local=None):
+        self._lib = load_library()
+        self._h = C.c_void_p()
+        self.d, self.r = int(d), int(r)
+        self.row0 = int(row0)
+        self.d_local = int(d if d_local is None else d_local)
+        self.n_theta = self.r if dyn_kind == DYN_COS_PHASE else 0
+        self.storage = F64 if storage in ("f64", F64, np.float64) else F32
+        self.store_y_pred = bool(store_y_pred)
+        cfg = PsmfConfig(
+            abi_version=ABI_VERSION, d=self.d, r=self.r, row0=self.row0, d_local=self.d_local,
+            robust=int(robust), coef_update=int(coef_update), eta_full=int(eta_full),
+            pbar_predict=int(pbar_predict), fixed_lambda=int(fixed_lambda), dyn_kind=int(dyn_kind),
+            n_theta=self.n_theta, storage=self.storage, store_y_pred=int(store_y_pred),
+            recursive=int(recursive), update_every=int(update_every), gram_refresh=int(gram_refresh),
+            device=int(device), use_graph=int(use_graph), n_workgroups=int(n_workgroups),
+            alpha=float(alpha), beta=float(beta), adam_lr=float(adam_lr), adam_lr_end=float(adam_lr_end),
+            adam_lr_steps=float(adam_lr_steps), adam_b1=float(adam_b1), adam_b2=float(adam_b2))
+        rc = self._lib.psmf_create(C.byref(self._h), C.byref(cfg))
+        if rc != OK:
+            msg = self._lib.psmf_last_error(None).decode()
+            self._h = C.c_void_p()
+            raise (ValueError if rc == ERR_ARG else PsmfError)(f"psmf_create failed ({rc}): {msg}")
+        self.T = 0
+
+    # -- plumbing
+    def _check(self, rc):
+        if rc == OK:
+            return
+        msg = self._lib.psmf_last_error(self._h).decode()
+        if rc == ERR_NUMERIC:
+            raise np.linalg.LinAlgError(msg)
+        if rc == ERR_ARG:
+            raise ValueError(msg)
+        raise PsmfError(f"libpsmf_hip error {rc}: {msg}")
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.psmf_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- state
+    def set_state(self, C_=None, V=None, P=None, Q=None, mu=None, rho=None, lambda0=None, theta=None):
+        r, dl = self.r, self.d_local
+        C_ = _f64(C_, (dl, r))
+        V, P, Q = _f64(V, (r, r)), _f64(P, (r, r)), _f64(Q, (r, r))
+        mu = _f64(mu, (r,))
+        theta = _f64(theta, (self.n_theta,)) if self.n_theta else None
+        nan = float("nan")
+        self._check(self._lib.psmf_set_state(
+            self._h, _ptr(C_), _ptr(V), _ptr(P), _ptr(Q), _ptr(mu),
+            nan if rho is None else float(rho), nan if lambda0 is None else float(lambda0), _ptr(theta)))
+
+    def zero_gradsum(self):
+        self._check(self._lib.psmf_zero_gradsum(self._h))
+
+    def set_adam(self, m, v):
+        m, v = _f64(m, (self.n_theta,)), _f64(v, (self.n_theta,))
+        self._check(self._lib.psmf_set_adam(self._h, _ptr(m), _ptr(v)))
+
+    def get_state(self, want_C=True):
+        r, dl = self.r, self.d_local
+        out = dict(
+            C=np.empty((dl, r)) if want_C else None, V=np.empty((r, r)), P=np.empty((r, r)),
+            Q=np.empty((r, r)), mu=np.empty(r), theta=np.zeros(self.n_theta), gradsum=np.zeros(self.n_theta))
+        sc = np.empty(8)
+        self._check(self._lib.psmf_get_state(
+            self._h, _ptr(out["C"]), _ptr(out["V"]), _ptr(out["P"]), _ptr(out["Q"]), _ptr(out["mu"]),
+            _ptr(out["theta"]) if self.n_theta else None, _ptr(out["gradsum"]) if self.n_theta else None,
+            _ptr(sc)))
+        out.update(rho=sc[0], lam=sc[1], s=sc[2], eta=sc[3], N=sc[4], phi=sc[5], omega=sc[6], k=int(sc[7]))
+        return out
+
+    # -- series / run
+    def upload_series(self, Y, t0=0, T_total=None):
+        Y = np.asarray(Y)
+        if Y.ndim != 2 or Y.shape[1] != self.d_local:
+            raise ValueError(f"series must be (T, {self.d_local}) time-major, got {Y.shape}")
+        if Y.dtype == np.float32:
+            dt = F32
+        else:
+            Y = Y.astype(np.float64, copy=False)
+            dt = F64
+        Y = np.ascontiguousarray(Y)
+        nt = Y.shape[0]
+        T_total = t0 + nt if T_total is None else int(T_total)
+        self._check(self._lib.psmf_upload_series(self._h, Y.ctypes.data_as(C.c_void_p), dt, t0, nt, T_total))
+        self.T = max(self.T, T_total)
+
+    def run(self, k_begin, k_end, sync=True):
+        self._check(self._lib.psmf_run(self._h, int(k_begin), int(k_end)))
+        if sync:
+            self.sync()
+
+    def sync(self):
+        self._check(self._lib.psmf_sync(self._h))
+
+    def run_timed(self, k_begin, k_end):
+        ms = C.c_float()
+        self._check(self._lib.psmf_run_timed(self._h, int(k_begin), int(k_end), C.byref(ms)))
+        return ms.value
+
+    def time_kernel(self, which, iters=200):
+        us = C.c_float()
+        self._check(self._lib.psmf_time_kernel(self._h, int(which), int(iters), C.byref(us)))
+        return us.value
+
+    def geometry(self):
+        g = (C.c_int32 * 5)()
+        self._check(self._lib.psmf_geometry(self._h, g))
+        return dict(n_sweep_wg=g[0], rows_per_wg=g[1], row_stride=g[2], lanes_per_row=g[3], graph_chunk=g[4])
+
+    def y_pred(self, t0, nt, dtype=np.float64):
+        out = np.empty((nt, self.d_local), dtype=dtype)
+        dt = F32 if out.dtype == np.float32 else F64
+        self._check(self._lib.psmf_download_y_pred(self._h, out.ctypes.data_as(C.c_void_p), dt, int(t0), int(nt)))
+        return out
+
+    def predict(self, T, n_pred):
+        out = np.empty((n_pred, self.d_local))
+        self._check(self._lib.psmf_predict(self._h, int(T), int(n_pred), _ptr(out)))
+        return out
+
+    def sq_error(self, t0, nt):
+        v = C.c_double()
+        self._check(self._lib.psmf_sq_error(self._h, int(t0), int(nt), C.byref(v)))
+        return v.value
+
+    # -- multi-GPU
+    @staticmethod
+    def comm_unique_id():
+        lib = load_library()
+        buf = C.create_string_buffer(UNIQUE_ID_BYTES)
+        rc = lib.psmf_comm_unique_id(buf)
+        if rc != OK:
+            raise PsmfError("psmf_comm_unique_id failed: " + lib.psmf_last_error(None).decode())
+        return buf.raw
+
+    def comm_init(self, nranks, rank, unique_id):
+        buf = C.create_string_buffer(bytes(unique_id), UNIQUE_ID_BYTES)
+        self._check(self._lib.psmf_comm_init(self._h, int(nranks), int(rank), buf))
+
+
+def device_count():
+    return load_library().psmf_device_count()

@@ -1,0 +1,694 @@
+// C ABI of libpsmf_hip.so (include/psmf_hip.h): host-side orchestration of the large-d engine.
+// One handle = one HIP stream, one device-resident filter (or row shard), one hipGraph of
+// per-step launches replayed over the series.  No torch, no hipBLAS: plain HIP + RCCL.
+#include "../../include/psmf_hip.h"
+#include "psmf_kernels.hip"
+
+#include <rccl/rccl.h>
+
+#include <cmath>
+#include <cstddef>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using psmf::DevState;
+using psmf::StepParams;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+struct Geometry {
+  int vec, nv, rp, gs, rpp, rpad;
+  int n_sweep_wg, rows_per_wg, ps;
+  size_t sweep_lds;
+};
+
+constexpr int kUnroll = 4;
+constexpr int kGramWG = 128;
+
+}  // namespace
+
+struct psmf_filter {
+  psmf_config cfg;
+  Geometry geo;
+  hipStream_t stream = nullptr;
+  DevState* st = nullptr;
+  void* C = nullptr;
+  void* Y = nullptr;
+  void* YP = nullptr;
+  double* partials = nullptr;
+  double* gpart = nullptr;
+  double* scratch = nullptr;   // sq-error partials / predict staging
+  size_t scratch_bytes = 0;
+  int64_t T_cap = 0;
+  StepParams sp;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t gexec = nullptr;
+  int chunk = 0;
+  bool have_state = false;
+  bool need_prep = true;
+  int64_t k_done = 0;
+  ncclComm_t comm = nullptr;
+  int nranks = 1, rank = 0;
+  bool use_coll = false;   // per-step all-reduce on (nranks > 1, or forced for single-GPU testing)
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::string err;
+  size_t elem() const { return cfg.storage == PSMF_F64 ? 8 : 4; }
+};
+
+namespace {
+
+int fail(psmf_handle h, int code, const std::string& msg) {
+  if (h) h->err = msg; else g_create_error = msg;
+  return code;
+}
+
+#define HIP_TRY(h, expr)                                                                   \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess)                                                                  \
+      return fail(h, PSMF_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));    \
+  } while (0)
+
+#define NCCL_TRY(h, expr)                                                                  \
+  do {                                                                                     \
+    ncclResult_t e_ = (expr);                                                              \
+    if (e_ != ncclSuccess)                                                                 \
+      return fail(h, PSMF_ERR_RCCL, std::string(#expr) + ": " + ncclGetErrorString(e_));  \
+  } while (0)
+
+int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+
+typedef void (*sweep_fn_t)(StepParams);
+typedef void (*serial_fn_t)(StepParams, int);
+
+template <typename T>
+sweep_fn_t sweep_for_gs(int gs) {
+  switch (gs) {
+    case 1: return psmf::psmf_sweep_solve<T, 1, kUnroll>;
+    case 2: return psmf::psmf_sweep_solve<T, 2, kUnroll>;
+    case 4: return psmf::psmf_sweep_solve<T, 4, kUnroll>;
+    case 8: return psmf::psmf_sweep_solve<T, 8, kUnroll>;
+    case 16: return psmf::psmf_sweep_solve<T, 16, kUnroll>;
+    case 32: return psmf::psmf_sweep_solve<T, 32, kUnroll>;
+  }
+  return nullptr;
+}
+
+sweep_fn_t sweep_kernel(const psmf_filter* h) {
+  return h->cfg.storage == PSMF_F64 ? sweep_for_gs<double>(h->geo.gs) : sweep_for_gs<float>(h->geo.gs);
+}
+
+serial_fn_t serial_kernel(const psmf_filter* h) {
+  switch (h->geo.rpad) {
+    case 8: return psmf::psmf_serial<8>;
+    case 16: return psmf::psmf_serial<16>;
+    case 32: return psmf::psmf_serial<32>;
+    default: return psmf::psmf_serial<64>;
+  }
+}
+
+void launch_sweep(psmf_filter* h) {
+  const int grid = h->geo.n_sweep_wg + (h->cfg.coef_update ? 1 : 0);
+  hipLaunchKernelGGL(sweep_kernel(h), dim3(grid), dim3(psmf::WG), h->geo.sweep_lds, h->stream, h->sp);
+}
+
+void launch_serial(psmf_filter* h, int first) {
+  hipLaunchKernelGGL(serial_kernel(h), dim3(1), dim3(psmf::serial_threads(h->geo.rpad)), 0, h->stream, h->sp, first);
+}
+
+// one filter step on the stream (captured into the graph or launched eagerly)
+int enqueue_step(psmf_filter* h) {
+  launch_sweep(h);
+  if (h->use_coll) {
+    hipLaunchKernelGGL(psmf::psmf_reduce_partials, dim3(1), dim3(psmf::WG), 0, h->stream, h->sp);
+    NCCL_TRY(h, ncclAllReduce(h->st->red, h->st->red, h->cfg.r + 1, ncclDouble, ncclSum, h->comm, h->stream));
+  }
+  launch_serial(h, 0);
+  return PSMF_OK;
+}
+
+int enqueue_gram(psmf_filter* h) {
+  const int r = h->cfg.r;
+  const int rows = (h->cfg.d_local + kGramWG - 1) / kGramWG;
+  if (h->cfg.storage == PSMF_F64)
+    hipLaunchKernelGGL(psmf::psmf_gram_partial<double>, dim3(kGramWG), dim3(psmf::WG), 0, h->stream,
+                       (const double*)h->C, h->cfg.d_local, r, h->geo.rp, rows, h->gpart);
+  else
+    hipLaunchKernelGGL(psmf::psmf_gram_partial<float>, dim3(kGramWG), dim3(psmf::WG), 0, h->stream,
+                       (const float*)h->C, h->cfg.d_local, r, h->geo.rp, rows, h->gpart);
+  hipLaunchKernelGGL(psmf::psmf_gram_reduce, dim3((r * r + 255) / 256), dim3(256), 0, h->stream,
+                     (const double*)h->gpart, kGramWG, r * r, h->st->G);
+  if (h->use_coll)
+    NCCL_TRY(h, ncclAllReduce(h->st->G, h->st->G, r * r, ncclDouble, ncclSum, h->comm, h->stream));
+  return PSMF_OK;
+}
+
+void destroy_graph(psmf_filter* h) {
+  if (h->gexec) { hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
+  if (h->graph) { hipGraphDestroy(h->graph); h->graph = nullptr; }
+  h->chunk = 0;
+}
+
+int build_graph(psmf_filter* h, int chunk) {
+  destroy_graph(h);
+  HIP_TRY(h, hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+  int rc = PSMF_OK;
+  for (int i = 0; i < chunk && rc == PSMF_OK; ++i) rc = enqueue_step(h);
+  hipGraph_t g = nullptr;
+  hipError_t e = hipStreamEndCapture(h->stream, &g);
+  if (rc != PSMF_OK) { if (g) hipGraphDestroy(g); return rc; }
+  if (e != hipSuccess) return fail(h, PSMF_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(e));
+  h->graph = g;
+  HIP_TRY(h, hipGraphInstantiate(&h->gexec, h->graph, nullptr, nullptr, 0));
+  h->chunk = chunk;
+  return PSMF_OK;
+}
+
+int ensure_scratch(psmf_filter* h, size_t bytes) {
+  if (h->scratch_bytes >= bytes) return PSMF_OK;
+  if (h->scratch) HIP_TRY(h, hipFree(h->scratch));
+  h->scratch = nullptr;
+  h->scratch_bytes = 0;
+  HIP_TRY(h, hipMalloc((void**)&h->scratch, bytes));
+  h->scratch_bytes = bytes;
+  return PSMF_OK;
+}
+
+void compute_geometry(const psmf_config& c, Geometry& g) {
+  g.vec = c.storage == PSMF_F64 ? 2 : 4;
+  g.nv = (c.r + g.vec - 1) / g.vec;
+  g.rp = g.nv * g.vec;
+  g.gs = next_pow2(g.nv);
+  g.rpp = psmf::WG / g.gs;
+  g.rpad = next_pow2(c.r < 8 ? 8 : c.r);
+  const size_t solve_lds = c.coef_update ? (size_t)(4 * psmf::RM + 2) * 8 : 0;
+  const size_t red_lds = (size_t)4 * (g.gs * g.vec + 1) * 8;
+  g.sweep_lds = ((solve_lds > red_lds ? solve_lds : red_lds) + 15) & ~(size_t)15;
+  int target = c.n_workgroups > 0 ? c.n_workgroups : 512;
+  int rows = (c.d_local + target - 1) / target;
+  rows = ((rows + g.rpp - 1) / g.rpp) * g.rpp;
+  if (rows < g.rpp) rows = g.rpp;
+  g.rows_per_wg = rows;
+  g.n_sweep_wg = (c.d_local + rows - 1) / rows;
+  g.ps = c.r + 1;
+}
+
+int set_device(psmf_handle h) {
+  HIP_TRY(h, hipSetDevice(h->cfg.device));
+  return PSMF_OK;
+}
+
+template <typename T>
+void pack_rows(const double* src, T* dst, int d_local, int r, int rp) {
+  for (int i = 0; i < d_local; ++i) {
+    for (int c = 0; c < r; ++c) dst[(size_t)i * rp + c] = (T)src[(size_t)i * r + c];
+    for (int c = r; c < rp; ++c) dst[(size_t)i * rp + c] = (T)0;
+  }
+}
+
+// start-of-run preparation: step counter, exact Gram, then everything the first sweep needs
+int prepare(psmf_filter* h, int64_t k_begin) {
+  long long k = k_begin;
+  int zero = 0;
+  HIP_TRY(h, hipMemcpyAsync(&h->st->k, &k, sizeof(k), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(&h->st->err, &zero, sizeof(zero), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipStreamSynchronize(h->stream));   // the two sources above are stack variables
+  if (h->sp.track_g) {
+    int rc = enqueue_gram(h);
+    if (rc != PSMF_OK) return rc;
+  }
+  launch_serial(h, 1);
+  HIP_TRY(h, hipGetLastError());
+  h->need_prep = false;
+  h->k_done = k_begin;
+  return PSMF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int psmf_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+const char* psmf_last_error(psmf_handle h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int psmf_create(psmf_handle* out, const psmf_config* cfg) {
+  if (!out || !cfg) return fail(nullptr, PSMF_ERR_ARG, "psmf_create: null argument");
+  *out = nullptr;
+  if (cfg->abi_version != PSMF_ABI_VERSION) return fail(nullptr, PSMF_ERR_ARG, "psmf_create: ABI version mismatch");
+  if (cfg->r < 1 || cfg->r > PSMF_RMAX) return fail(nullptr, PSMF_ERR_ARG, "psmf_create: need 1 <= r <= 64");
+  if (cfg->d < 1 || cfg->d_local < 1 || cfg->row0 < 0 || cfg->row0 + cfg->d_local > cfg->d)
+    return fail(nullptr, PSMF_ERR_ARG, "psmf_create: bad d / row0 / d_local");
+  if (cfg->storage != PSMF_F32 && cfg->storage != PSMF_F64) return fail(nullptr, PSMF_ERR_ARG, "psmf_create: storage must be f32 or f64");
+  if (cfg->dyn_kind == PSMF_DYN_RANDOM_WALK && cfg->n_theta != 0) return fail(nullptr, PSMF_ERR_ARG, "psmf_create: random walk has no theta");
+  if (cfg->dyn_kind == PSMF_DYN_COS_PHASE && cfg->n_theta != cfg->r) return fail(nullptr, PSMF_ERR_ARG, "psmf_create: cos-phase needs n_theta == r");
+  if (cfg->dyn_kind != PSMF_DYN_RANDOM_WALK && cfg->dyn_kind != PSMF_DYN_COS_PHASE) return fail(nullptr, PSMF_ERR_ARG, "psmf_create: unknown dyn_kind");
+  if (cfg->recursive && cfg->update_every < 1) return fail(nullptr, PSMF_ERR_ARG, "psmf_create: update_every must be >= 1");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
+    return fail(nullptr, PSMF_ERR_NO_DEVICE, "psmf_create: no HIP device visible (the MI355X path has no CPU fallback)");
+  if (cfg->device < 0 || cfg->device >= ndev) return fail(nullptr, PSMF_ERR_ARG, "psmf_create: bad device ordinal");
+
+  psmf_filter* h = new psmf_filter();
+  h->cfg = *cfg;
+  compute_geometry(h->cfg, h->geo);
+  auto bail = [&](int code) { g_create_error = h->err; psmf_destroy(h); return code; };
+#define CREATE_TRY(expr)                                                                  \
+  do {                                                                                    \
+    hipError_t e_ = (expr);                                                               \
+    if (e_ != hipSuccess) { h->err = std::string(#expr) + ": " + hipGetErrorString(e_); return bail(PSMF_ERR_HIP); } \
+  } while (0)
+  CREATE_TRY(hipSetDevice(cfg->device));
+  CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+  CREATE_TRY(hipEventCreate(&h->ev0));
+  CREATE_TRY(hipEventCreate(&h->ev1));
+  CREATE_TRY(hipMalloc((void**)&h->st, sizeof(DevState)));
+  CREATE_TRY(hipMemset(h->st, 0, sizeof(DevState)));
+  CREATE_TRY(hipMalloc(&h->C, (size_t)cfg->d_local * h->geo.rp * h->elem()));
+  CREATE_TRY(hipMalloc((void**)&h->partials, (size_t)h->geo.n_sweep_wg * h->geo.ps * sizeof(double)));
+  CREATE_TRY(hipMalloc((void**)&h->gpart, (size_t)kGramWG * cfg->r * cfg->r * sizeof(double)));
+  if (h->geo.sweep_lds > 48 * 1024)
+    CREATE_TRY(hipFuncSetAttribute((const void*)sweep_kernel(h), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->geo.sweep_lds));
+#undef CREATE_TRY
+
+  StepParams& sp = h->sp;
+  memset(&sp, 0, sizeof(sp));
+  sp.st = h->st;
+  sp.C = h->C;
+  sp.partials = h->partials;
+  sp.d = cfg->d; sp.d_local = cfg->d_local; sp.r = cfg->r; sp.rp = h->geo.rp; sp.nv = h->geo.nv;
+  sp.n_sweep_wg = h->geo.n_sweep_wg; sp.rows_per_wg = h->geo.rows_per_wg; sp.ps = h->geo.ps;
+  sp.robust = cfg->robust; sp.coef_update = cfg->coef_update; sp.eta_full = cfg->eta_full;
+  sp.pbar_predict = cfg->pbar_predict; sp.fixed_lambda = cfg->fixed_lambda;
+  sp.dyn_kind = cfg->dyn_kind; sp.n_theta = cfg->n_theta; sp.store_yp = 0;
+  sp.recursive = cfg->recursive; sp.update_every = cfg->update_every > 0 ? cfg->update_every : 1;
+  sp.track_g = (cfg->eta_full || cfg->coef_update) ? 1 : 0;
+  sp.external_reduce = 0;
+  sp.alpha = cfg->alpha; sp.beta = cfg->beta;
+  sp.lr = cfg->adam_lr; sp.lr_end = cfg->adam_lr_end; sp.lr_steps = cfg->adam_lr_steps;
+  sp.b1 = cfg->adam_b1; sp.b2 = cfg->adam_b2;
+  *out = h;
+  return PSMF_OK;
+}
+
+void psmf_destroy(psmf_handle h) {
+  if (!h) return;
+  hipSetDevice(h->cfg.device);
+  if (h->stream) hipStreamSynchronize(h->stream);
+  destroy_graph(h);
+  if (h->comm) ncclCommDestroy(h->comm);
+  if (h->st) hipFree(h->st);
+  if (h->C) hipFree(h->C);
+  if (h->Y) hipFree(h->Y);
+  if (h->YP) hipFree(h->YP);
+  if (h->partials) hipFree(h->partials);
+  if (h->gpart) hipFree(h->gpart);
+  if (h->scratch) hipFree(h->scratch);
+  if (h->ev0) hipEventDestroy(h->ev0);
+  if (h->ev1) hipEventDestroy(h->ev1);
+  if (h->stream) hipStreamDestroy(h->stream);
+  delete h;
+}
+
+int psmf_set_state(psmf_handle h, const double* C, const double* V, const double* P, const double* Q,
+                   const double* mu, double rho, double lambda0, const double* theta) {
+  if (!h) return PSMF_ERR_ARG;
+  int rc = set_device(h);
+  if (rc) return rc;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  const int r = h->cfg.r, dl = h->cfg.d_local, rp = h->geo.rp;
+  if (C) {
+    if (h->cfg.storage == PSMF_F64) {
+      std::vector<double> buf((size_t)dl * rp);
+      pack_rows<double>(C, buf.data(), dl, r, rp);
+      HIP_TRY(h, hipMemcpy(h->C, buf.data(), buf.size() * 8, hipMemcpyHostToDevice));
+    } else {
+      std::vector<float> buf((size_t)dl * rp);
+      pack_rows<float>(C, buf.data(), dl, r, rp);
+      HIP_TRY(h, hipMemcpy(h->C, buf.data(), buf.size() * 4, hipMemcpyHostToDevice));
+    }
+  }
+  const size_t rr = (size_t)r * r * sizeof(double);
+  if (V) HIP_TRY(h, hipMemcpy(h->st->V, V, rr, hipMemcpyHostToDevice));
+  if (P) HIP_TRY(h, hipMemcpy(h->st->P, P, rr, hipMemcpyHostToDevice));
+  if (Q) HIP_TRY(h, hipMemcpy(h->st->Q, Q, rr, hipMemcpyHostToDevice));
+  if (mu) HIP_TRY(h, hipMemcpy(h->st->mu, mu, r * sizeof(double), hipMemcpyHostToDevice));
+  if (theta && h->cfg.n_theta > 0)
+    HIP_TRY(h, hipMemcpy(h->st->theta, theta, h->cfg.n_theta * sizeof(double), hipMemcpyHostToDevice));
+  if (!std::isnan(rho)) HIP_TRY(h, hipMemcpy(&h->st->rho, &rho, sizeof(double), hipMemcpyHostToDevice));
+  if (!std::isnan(lambda0)) HIP_TRY(h, hipMemcpy(&h->st->lam, &lambda0, sizeof(double), hipMemcpyHostToDevice));
+  if (C && V && P && mu) h->have_state = true;
+  h->need_prep = true;
+  return PSMF_OK;
+}
+
+int psmf_zero_gradsum(psmf_handle h) {
+  if (!h) return PSMF_ERR_ARG;
+  int rc = set_device(h);
+  if (rc) return rc;
+  HIP_TRY(h, hipMemsetAsync(h->st->gradsum, 0, sizeof(double) * psmf::RM, h->stream));
+  return PSMF_OK;
+}
+
+int psmf_set_adam(psmf_handle h, const double* m, const double* v) {
+  if (!h) return PSMF_ERR_ARG;
+  int rc = set_device(h);
+  if (rc) return rc;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  const size_t nb = (size_t)h->cfg.n_theta * sizeof(double);
+  if (m && nb) HIP_TRY(h, hipMemcpy(h->st->adam_m, m, nb, hipMemcpyHostToDevice));
+  if (v && nb) HIP_TRY(h, hipMemcpy(h->st->adam_v, v, nb, hipMemcpyHostToDevice));
+  return PSMF_OK;
+}
+
+int psmf_get_state(psmf_handle h, double* C, double* V, double* P, double* Q, double* mu, double* theta,
+                   double* gradsum, double* scalars) {
+  if (!h) return PSMF_ERR_ARG;
+  int rc = psmf_sync(h);
+  if (rc) return rc;
+  const int r = h->cfg.r, dl = h->cfg.d_local, rp = h->geo.rp;
+  if (C) {
+    if (h->cfg.storage == PSMF_F64) {
+      std::vector<double> buf((size_t)dl * rp);
+      HIP_TRY(h, hipMemcpy(buf.data(), h->C, buf.size() * 8, hipMemcpyDeviceToHost));
+      for (int i = 0; i < dl; ++i) for (int c = 0; c < r; ++c) C[(size_t)i * r + c] = buf[(size_t)i * rp + c];
+    } else {
+      std::vector<float> buf((size_t)dl * rp);
+      HIP_TRY(h, hipMemcpy(buf.data(), h->C, buf.size() * 4, hipMemcpyDeviceToHost));
+      for (int i = 0; i < dl; ++i) for (int c = 0; c < r; ++c) C[(size_t)i * r + c] = (double)buf[(size_t)i * rp + c];
+    }
+  }
+  const size_t rr = (size_t)r * r * sizeof(double);
+  if (V) HIP_TRY(h, hipMemcpy(V, h->st->V, rr, hipMemcpyDeviceToHost));
+  if (P) HIP_TRY(h, hipMemcpy(P, h->st->P, rr, hipMemcpyDeviceToHost));
+  if (Q) HIP_TRY(h, hipMemcpy(Q, h->st->Q, rr, hipMemcpyDeviceToHost));
+  if (mu) HIP_TRY(h, hipMemcpy(mu, h->st->mu, r * sizeof(double), hipMemcpyDeviceToHost));
+  if (theta && h->cfg.n_theta) HIP_TRY(h, hipMemcpy(theta, h->st->theta, h->cfg.n_theta * sizeof(double), hipMemcpyDeviceToHost));
+  if (gradsum && h->cfg.n_theta) HIP_TRY(h, hipMemcpy(gradsum, h->st->gradsum, h->cfg.n_theta * sizeof(double), hipMemcpyDeviceToHost));
+  if (scalars) {
+    DevState* s = h->st;
+    double tmp[12];  // rho lam s eta N kappa phi omega ee s_done eta_done N_done
+    HIP_TRY(h, hipMemcpy(tmp, &s->rho, sizeof(double) * 12, hipMemcpyDeviceToHost));
+    long long k;
+    HIP_TRY(h, hipMemcpy(&k, &s->k, sizeof(k), hipMemcpyDeviceToHost));
+    scalars[0] = tmp[0]; scalars[1] = tmp[1]; scalars[2] = tmp[9]; scalars[3] = tmp[10];
+    scalars[4] = tmp[11]; scalars[5] = tmp[6]; scalars[6] = tmp[7]; scalars[7] = (double)k;
+  }
+  return PSMF_OK;
+}
+
+int psmf_upload_series(psmf_handle h, const void* Y, int dtype, int64_t t0, int64_t nt, int64_t T_total) {
+  if (!h || !Y || nt < 0 || t0 < 0) return fail(h, PSMF_ERR_ARG, "psmf_upload_series: bad argument");
+  if (dtype != PSMF_F32 && dtype != PSMF_F64) return fail(h, PSMF_ERR_ARG, "psmf_upload_series: dtype");
+  int rc = set_device(h);
+  if (rc) return rc;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  const size_t dl = h->cfg.d_local, es = h->elem();
+  if (T_total < t0 + nt) T_total = t0 + nt;
+  if (!h->Y || T_total > h->T_cap) {
+    if (h->Y && t0 != 0) return fail(h, PSMF_ERR_STATE, "psmf_upload_series: buffer would grow mid-series; pass T_total on the first block");
+    destroy_graph(h);   // graph nodes hold the old buffer addresses
+    if (h->Y) HIP_TRY(h, hipFree(h->Y));
+    if (h->YP) HIP_TRY(h, hipFree(h->YP));
+    h->Y = h->YP = nullptr;
+    HIP_TRY(h, hipMalloc(&h->Y, (size_t)T_total * dl * es));
+    if (h->cfg.store_y_pred) HIP_TRY(h, hipMalloc(&h->YP, (size_t)T_total * dl * es));
+    h->T_cap = T_total;
+    h->sp.Y = h->Y;
+    h->sp.YP = h->YP;
+    h->sp.store_yp = h->cfg.store_y_pred ? 1 : 0;
+    h->sp.series_t0 = 0;
+  }
+  char* dst = (char*)h->Y + (size_t)t0 * dl * es;
+  const size_t n = (size_t)nt * dl;
+  if ((dtype == PSMF_F64) == (h->cfg.storage == PSMF_F64)) {
+    HIP_TRY(h, hipMemcpy(dst, Y, n * es, hipMemcpyHostToDevice));
+  } else {
+    const size_t blk = (size_t)1 << 24;
+    if (h->cfg.storage == PSMF_F32) {
+      std::vector<float> buf(n < blk ? n : blk);
+      const double* src = (const double*)Y;
+      for (size_t a = 0; a < n; a += blk) {
+        const size_t m = n - a < blk ? n - a : blk;
+        for (size_t i = 0; i < m; ++i) buf[i] = (float)src[a + i];
+        HIP_TRY(h, hipMemcpy(dst + a * 4, buf.data(), m * 4, hipMemcpyHostToDevice));
+      }
+    } else {
+      std::vector<double> buf(n < blk ? n : blk);
+      const float* src = (const float*)Y;
+      for (size_t a = 0; a < n; a += blk) {
+        const size_t m = n - a < blk ? n - a : blk;
+        for (size_t i = 0; i < m; ++i) buf[i] = (double)src[a + i];
+        HIP_TRY(h, hipMemcpy(dst + a * 8, buf.data(), m * 8, hipMemcpyHostToDevice));
+      }
+    }
+  }
+  return PSMF_OK;
+}
+
+int psmf_run(psmf_handle h, int64_t k_begin, int64_t k_end) {
+  if (!h) return PSMF_ERR_ARG;
+  if (!h->have_state) return fail(h, PSMF_ERR_STATE, "psmf_run: set_state (C, V, P, mu) first");
+  if (!h->Y) return fail(h, PSMF_ERR_STATE, "psmf_run: upload_series first");
+  if (k_begin < 0 || k_end < k_begin || k_end > h->T_cap) return fail(h, PSMF_ERR_ARG, "psmf_run: step range outside the uploaded series");
+  int rc = set_device(h);
+  if (rc) return rc;
+  if (h->need_prep || h->k_done != k_begin) {
+    rc = prepare(h, k_begin);
+    if (rc) return rc;
+  }
+  int64_t n = k_end - k_begin;
+  const int64_t refresh = h->cfg.gram_refresh > 0 && h->sp.track_g ? h->cfg.gram_refresh : 0;
+  while (n > 0) {
+    int64_t seg = n;
+    if (refresh) {
+      const int64_t to_next = refresh - (h->k_done % refresh);
+      if (to_next < seg) seg = to_next;
+    }
+    int64_t left = seg;
+    if (h->cfg.use_graph) {
+      const int want = 256;
+      if (left >= want && h->chunk != want) {
+        rc = build_graph(h, want);
+        if (rc) return rc;
+      }
+      while (h->chunk > 0 && left >= h->chunk) {
+        HIP_TRY(h, hipGraphLaunch(h->gexec, h->stream));
+        left -= h->chunk;
+      }
+    }
+    for (; left > 0; --left) {
+      rc = enqueue_step(h);
+      if (rc) return rc;
+    }
+    HIP_TRY(h, hipGetLastError());
+    h->k_done += seg;
+    n -= seg;
+    if (refresh && n > 0 && h->k_done % refresh == 0) {
+      rc = enqueue_gram(h);
+      if (rc) return rc;
+      launch_serial(h, 1);   // recompute eta / N / kappa of the next step with the exact Gram
+    }
+  }
+  return PSMF_OK;
+}
+
+int psmf_sync(psmf_handle h) {
+  if (!h) return PSMF_ERR_ARG;
+  int rc = set_device(h);
+  if (rc) return rc;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  int err = 0;
+  HIP_TRY(h, hipMemcpy(&err, &h->st->err, sizeof(int), hipMemcpyDeviceToHost));
+  if (err != 0) {
+    char msg[128];
+    snprintf(msg, sizeof(msg), "singular r x r system (I + kappa Pbar G) at step %d", err);
+    return fail(h, PSMF_ERR_NUMERIC, msg);
+  }
+  return PSMF_OK;
+}
+
+int psmf_run_timed(psmf_handle h, int64_t k_begin, int64_t k_end, float* ms) {
+  if (!h || !ms) return PSMF_ERR_ARG;
+  int rc = set_device(h);
+  if (rc) return rc;
+  if (h->have_state && h->Y && (h->need_prep || h->k_done != k_begin)) {
+    rc = prepare(h, k_begin);   // keep the one-off preparation outside the timed region
+    if (rc) return rc;
+  }
+  HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+  rc = psmf_run(h, k_begin, k_end);
+  if (rc) return rc;
+  HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+  HIP_TRY(h, hipEventSynchronize(h->ev1));
+  HIP_TRY(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
+  return psmf_sync(h);
+}
+
+int psmf_time_kernel(psmf_handle h, int which, int iters, float* avg_us) {
+  if (!h || !avg_us || iters < 1 || (which != 0 && which != 1)) return PSMF_ERR_ARG;
+  if (!h->have_state || !h->Y) return fail(h, PSMF_ERR_STATE, "psmf_time_kernel: needs state and series");
+  int rc = set_device(h);
+  if (rc) return rc;
+  if (h->need_prep) { rc = prepare(h, h->k_done); if (rc) return rc; }
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  // save everything the kernels mutate
+  const size_t cbytes = (size_t)h->cfg.d_local * h->geo.rp * h->elem();
+  void* Csave = nullptr; DevState* ssave = nullptr;
+  HIP_TRY(h, hipMalloc(&Csave, cbytes));
+  HIP_TRY(h, hipMalloc((void**)&ssave, sizeof(DevState)));
+  HIP_TRY(h, hipMemcpy(Csave, h->C, cbytes, hipMemcpyDeviceToDevice));
+  HIP_TRY(h, hipMemcpy(ssave, h->st, sizeof(DevState), hipMemcpyDeviceToDevice));
+  {  // the sweep reads y_k / writes y_hat_k at the step counter: point it at a valid row of the series
+    long long k0 = h->sp.series_t0;
+    HIP_TRY(h, hipMemcpy(&h->st->k, &k0, sizeof(k0), hipMemcpyHostToDevice));
+  }
+  // which = 1 times the full serial stage (first = 0: reduction of the partials left by the last
+  // sweep, updates, next-step preparation); the step counter it increments is reset with the state
+  for (int i = 0; i < 3; ++i) { if (which == 0) launch_sweep(h); else launch_serial(h, 0); }
+  HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+  for (int i = 0; i < iters; ++i) { if (which == 0) launch_sweep(h); else launch_serial(h, 0); }
+  HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+  HIP_TRY(h, hipEventSynchronize(h->ev1));
+  float ms = 0.f;
+  HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+  *avg_us = ms * 1000.f / iters;
+  HIP_TRY(h, hipMemcpy(h->C, Csave, cbytes, hipMemcpyDeviceToDevice));
+  HIP_TRY(h, hipMemcpy(h->st, ssave, sizeof(DevState), hipMemcpyDeviceToDevice));
+  HIP_TRY(h, hipFree(Csave));
+  HIP_TRY(h, hipFree(ssave));
+  return PSMF_OK;
+}
+
+int psmf_geometry(psmf_handle h, int32_t* out5) {
+  if (!h || !out5) return PSMF_ERR_ARG;
+  out5[0] = h->geo.n_sweep_wg; out5[1] = h->geo.rows_per_wg; out5[2] = h->geo.rp; out5[3] = h->geo.gs;
+  out5[4] = h->chunk;
+  return PSMF_OK;
+}
+
+int psmf_download_y_pred(psmf_handle h, void* out, int dtype, int64_t t0, int64_t nt) {
+  if (!h || !out) return PSMF_ERR_ARG;
+  if (!h->YP) return fail(h, PSMF_ERR_STATE, "psmf_download_y_pred: handle was created with store_y_pred = 0");
+  if (t0 < 0 || nt < 0 || t0 + nt > h->T_cap) return fail(h, PSMF_ERR_ARG, "psmf_download_y_pred: range");
+  int rc = psmf_sync(h);
+  if (rc) return rc;
+  const size_t dl = h->cfg.d_local, es = h->elem(), n = (size_t)nt * dl;
+  const char* src = (const char*)h->YP + (size_t)t0 * dl * es;
+  if ((dtype == PSMF_F64) == (h->cfg.storage == PSMF_F64)) {
+    HIP_TRY(h, hipMemcpy(out, src, n * es, hipMemcpyDeviceToHost));
+  } else if (h->cfg.storage == PSMF_F32) {
+    std::vector<float> buf(n);
+    HIP_TRY(h, hipMemcpy(buf.data(), src, n * 4, hipMemcpyDeviceToHost));
+    double* o = (double*)out;
+    for (size_t i = 0; i < n; ++i) o[i] = (double)buf[i];
+  } else {
+    std::vector<double> buf(n);
+    HIP_TRY(h, hipMemcpy(buf.data(), src, n * 8, hipMemcpyDeviceToHost));
+    float* o = (float*)out;
+    for (size_t i = 0; i < n; ++i) o[i] = (float)buf[i];
+  }
+  return PSMF_OK;
+}
+
+int psmf_predict(psmf_handle h, int64_t T, int64_t n_pred, double* out) {
+  if (!h || !out || n_pred < 0) return PSMF_ERR_ARG;
+  if (n_pred == 0) return PSMF_OK;
+  int rc = psmf_sync(h);
+  if (rc) return rc;
+  const int r = h->cfg.r, dl = h->cfg.d_local;
+  std::vector<double> mu(r), theta(psmf::RM, 0.0), mup((size_t)n_pred * r);
+  HIP_TRY(h, hipMemcpy(mu.data(), h->st->mu, r * sizeof(double), hipMemcpyDeviceToHost));
+  if (h->cfg.n_theta) HIP_TRY(h, hipMemcpy(theta.data(), h->st->theta, h->cfg.n_theta * sizeof(double), hipMemcpyDeviceToHost));
+  for (int64_t q = 0; q < n_pred; ++q) {   // psmf.py:183-187, r-sized: done on the host
+    const double k = (double)(T + q + 1);
+    for (int i = 0; i < r; ++i) {
+      if (h->cfg.dyn_kind == PSMF_DYN_COS_PHASE) mu[i] = cos(2.0 * M_PI * theta[i] * k + mu[i]);
+      mup[(size_t)q * r + i] = mu[i];
+    }
+  }
+  const size_t mbytes = mup.size() * sizeof(double), obytes = (size_t)n_pred * dl * sizeof(double);
+  rc = ensure_scratch(h, mbytes + obytes);
+  if (rc) return rc;
+  double* dmu = h->scratch;
+  double* dout = h->scratch + mup.size();
+  HIP_TRY(h, hipMemcpy(dmu, mup.data(), mbytes, hipMemcpyHostToDevice));
+  const int grid = (dl + psmf::WG - 1) / psmf::WG;
+  const size_t lds = (size_t)64 * r * sizeof(double);
+  if (h->cfg.storage == PSMF_F64)
+    hipLaunchKernelGGL(psmf::psmf_predict_rows<double>, dim3(grid), dim3(psmf::WG), lds, h->stream,
+                       (const double*)h->C, dl, r, h->geo.rp, (const double*)dmu, (int)n_pred, dout);
+  else
+    hipLaunchKernelGGL(psmf::psmf_predict_rows<float>, dim3(grid), dim3(psmf::WG), lds, h->stream,
+                       (const float*)h->C, dl, r, h->geo.rp, (const double*)dmu, (int)n_pred, dout);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, hipMemcpy(out, dout, obytes, hipMemcpyDeviceToHost));
+  return PSMF_OK;
+}
+
+int psmf_sq_error(psmf_handle h, int64_t t0, int64_t nt, double* out) {
+  if (!h || !out) return PSMF_ERR_ARG;
+  if (!h->YP || !h->Y) return fail(h, PSMF_ERR_STATE, "psmf_sq_error: needs store_y_pred and an uploaded series");
+  if (t0 < 0 || nt < 0 || t0 + nt > h->T_cap) return fail(h, PSMF_ERR_ARG, "psmf_sq_error: range");
+  int rc = set_device(h);
+  if (rc) return rc;
+  const int grid = 1024;
+  rc = ensure_scratch(h, grid * sizeof(double));
+  if (rc) return rc;
+  const size_t dl = h->cfg.d_local, n = (size_t)nt * dl, off = (size_t)t0 * dl;
+  if (h->cfg.storage == PSMF_F64)
+    hipLaunchKernelGGL(psmf::psmf_sq_error_k<double>, dim3(grid), dim3(psmf::WG), 0, h->stream,
+                       (const double*)h->YP + off, (const double*)h->Y + off, n, h->scratch);
+  else
+    hipLaunchKernelGGL(psmf::psmf_sq_error_k<float>, dim3(grid), dim3(psmf::WG), 0, h->stream,
+                       (const float*)h->YP + off, (const float*)h->Y + off, n, h->scratch);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  std::vector<double> part(grid);
+  HIP_TRY(h, hipMemcpy(part.data(), h->scratch, grid * sizeof(double), hipMemcpyDeviceToHost));
+  double a = 0.0;
+  for (int i = 0; i < grid; ++i) a += part[i];
+  *out = a;
+  return PSMF_OK;
+}
+
+int psmf_comm_unique_id(void* id_out) {
+  if (!id_out) return PSMF_ERR_ARG;
+  static_assert(sizeof(ncclUniqueId) <= PSMF_UNIQUE_ID_BYTES, "unique id size");
+  ncclUniqueId id;
+  if (ncclGetUniqueId(&id) != ncclSuccess) return fail(nullptr, PSMF_ERR_RCCL, "ncclGetUniqueId failed");
+  memset(id_out, 0, PSMF_UNIQUE_ID_BYTES);
+  memcpy(id_out, &id, sizeof(id));
+  return PSMF_OK;
+}
+
+int psmf_comm_init(psmf_handle h, int nranks, int rank, const void* unique_id) {
+  if (!h || !unique_id || nranks < 1 || rank < 0 || rank >= nranks) return fail(h, PSMF_ERR_ARG, "psmf_comm_init: bad argument");
+  int rc = set_device(h);
+  if (rc) return rc;
+  ncclUniqueId id;
+  memcpy(&id, unique_id, sizeof(id));
+  NCCL_TRY(h, ncclCommInitRank(&h->comm, nranks, id, rank));
+  h->nranks = nranks;
+  h->rank = rank;
+  h->use_coll = nranks > 1 || getenv("PSMF_FORCE_COLLECTIVE") != nullptr;
+  h->sp.external_reduce = h->use_coll ? 1 : 0;
+  destroy_graph(h);
+  h->need_prep = true;
+  return PSMF_OK;
+}
+
+
+}  // extern "C"
+
+#include "psmf_impute.hip"

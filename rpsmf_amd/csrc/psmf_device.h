@@ -1,0 +1,51 @@
+// Device-side data structures shared by the kernels and the C-ABI host code.
+// gfx950 only: wave = 64 lanes, workgroups of 256 threads (4 waves, one per SIMD).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace psmf {
+
+constexpr int RM = 64;    // PSMF_RMAX
+constexpr int WG = 256;   // threads per workgroup everywhere
+
+// All O(r^2) state lives here, in float64, replicated on every GPU of a sharded filter.
+// r x r matrices are stored compactly (row stride r); all are symmetric.
+struct DevState {
+  double V[RM * RM];      // dictionary column covariance V_{k-1}
+  double P[RM * RM];      // coefficient covariance P_{k-1}
+  double Pplus[RM * RM];  // (I + kappa Pbar G)^-1 Pbar for the CURRENT step (written by the solve block)
+  double Pbar[RM * RM];   // predictive covariance of the current step
+  double Q[RM * RM];      // running Q (scaled by omega in rPSMF)
+  double G[RM * RM];      // Gram matrix C^T C of the current C (tracked algebraically)
+  double mu[RM];          // posterior mean mu_{k-1}
+  double mu_bar[RM];      // predictive mean of the current step
+  double w[RM];           // V mu_bar
+  double wN[RM];          // w / N   (rank-1 update direction used by the row sweep)
+  double theta[RM], gradsum[RM], adam_m[RM], adam_v[RM];
+  double red[RM + 8];     // h[0..r), ee at [r]: all-reduced partial sums (multi-GPU path)
+  double rho, lam;        // running diag(R) (uniform) and Student-t dof
+  double s, eta, N, kappa;  // scalars of the current step
+  double phi, omega, ee;  // scalars of the last finished step
+  double s_done, eta_done, N_done;  // s, eta, N of the last finished step
+  long long k;            // number of finished steps = 0-based series index of the current step
+  int err;                // != 0: numeric failure (singular system) at step err
+  int pad;
+};
+
+struct StepParams {
+  DevState* st;
+  void* C;            // d_local x rp, storage type
+  const void* Y;      // series buffer, time-major, storage type
+  void* YP;           // y_pred buffer or nullptr
+  double* partials;   // n_sweep_wg x ps
+  long long series_t0;  // global index of the first step held in Y
+  int d, d_local, r, rp, nv;
+  int n_sweep_wg, rows_per_wg, ps;
+  int robust, coef_update, eta_full, pbar_predict, fixed_lambda;
+  int dyn_kind, n_theta, store_yp, recursive, update_every, track_g;
+  int external_reduce;  // 1: partial sums were reduced into st->red (multi-GPU)
+  double alpha, beta, lr, lr_end, lr_steps, b1, b2;
+};
+
+}  // namespace psmf

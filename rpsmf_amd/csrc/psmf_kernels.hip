@@ -1,0 +1,683 @@
+// CDNA4 (gfx950) kernels of the per-timestep PSMF / rPSMF filter, large-d engine.
+//
+// One filter step = two launches (captured back to back in a hipGraph by the host):
+//
+//   psmf_sweep_solve   n_sweep_wg row blocks: ONE pass over the rows of C.  With the Gram
+//                      matrix G = C^T C tracked algebraically in r x r space, N_k and
+//                      w_k = V mu_bar are known before the pass, so the rank-1 update
+//                      C <- C + e w^T / N is applied in the same pass that forms
+//                      y_hat = C mu_bar and e = y - y_hat: C is read once and
+//                      written once per step, y read once, y_hat written once
+//                      = 8 d (r+1) algorithmic bytes in fp32.  d->r contractions
+//                      (h = C^T e, ee = e^T e) are accumulated in float64 per lane, reduced
+//                      with wavefront shuffles, then through LDS, one partial per workgroup.
+//                      block 0 (only if coef_update; sweep blocks then start at 1): the r x r solve
+//                      P+ = (I + kappa Pbar G)^-1 Pbar of the SAME step, concurrently with the
+//                      sweep (it needs G_{k-1}, not the sweep's output) -- two symmetric SWEEP
+//                      inversions in float64, matrix in registers, one barrier per pivot.
+//   psmf_serial        one workgroup: deterministic reduction of the partials, Kalman mean
+//                      update, V / P / G / Q / rho / lambda updates, theta gradient (+ Adam in
+//                      recursive mode), then everything O(r^2) the NEXT sweep needs
+//                      (mu_bar, Pbar, w, s, eta, N, kappa).
+//
+// Reference equations: pypsmf/psmf/psmf.py:104-177, rpsmf.py:116-184 (see SURVEY App. A for
+// the d x d -> r x r reduction).  fp32 (or fp64) storage for C, y, y_hat; everything r-sized
+// is float64.
+#pragma once
+#include "psmf_device.h"
+
+namespace psmf {
+
+template <typename T> struct VecOf;
+template <> struct VecOf<float> { typedef float __attribute__((ext_vector_type(4))) type; };
+template <> struct VecOf<double> { typedef double __attribute__((ext_vector_type(2))) type; };
+
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
+  return x;
+}
+
+
+// fixed-order sum of base[w * ps] for w = first, first + step, ... < n, with 16 independent loads in
+// flight (a serial dependent-load loop would cost one L2 round trip per term)
+__device__ __forceinline__ double strided_sum(const double* base, int first, int step, int n, int ps) {
+  double a[16];
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int w = first + q * step;
+    a[q] = w < n ? base[(size_t)w * ps] : 0.0;
+  }
+  for (int w0 = first + 16 * step; w0 < n; w0 += 16 * step) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int w = w0 + q * step;
+      a[q] += w < n ? base[(size_t)w * ps] : 0.0;
+    }
+  }
+  return (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) +
+         (((a[8] + a[9]) + (a[10] + a[11])) + ((a[12] + a[13]) + (a[14] + a[15])));
+}
+
+// ------------------------------------------------------------------------------------------
+// r x r solve block:  Pplus = (Pbar^-1 + kappa G)^-1  -- the reference's own formulation
+// (inv(P_bar), then inv(Pi + C^T Ri C): pypsmf/psmf/psmf.py:147-149, ExperimentImpute/PSMF.py:34-36)
+// as two symmetric SWEEP passes in float64.  Sweeping pivot k of a symmetric matrix A,
+//     a_ij <- a_ij - a_ik a_kj / a_kk   (i, j != k),   a_ik = a_ki <- a_ik / a_kk,   a_kk <- -1 / a_kk,
+// for all k turns A into -A^-1; for SPD A every pivot is positive, no pivot search is needed and
+// the matrix stays (bitwise) symmetric, so one pivot ROW per step is all the waves exchange:
+// matrix in registers (thread = column c, rows rg + m * RG), pivot row through a ping-pong LDS
+// line, one barrier per pivot.  A non-positive pivot raises the numeric-error flag (the
+// reference raises LinAlgError from np.linalg.inv in the same situation).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double fast_rcp(double d) {
+  double x = __builtin_amdgcn_rcp(d);   // v_rcp_f64, ~1e-8 relative
+  x = x * (2.0 - d * x);
+  x = x * (2.0 - d * x);
+  return x;
+}
+
+template <int RPAD>
+__device__ __forceinline__ void sweep_all(double (&A)[(RPAD * RPAD) / WG > 0 ? (RPAD * RPAD) / WG : 1], const int r2,
+                                          const int c, const int rg, double* rowbuf, int* errflag) {
+  constexpr int RG = WG / RPAD;                 // row groups; wave w holds row groups [w*RGW, (w+1)*RGW)
+  constexpr int RGW = RG / 4 > 0 ? RG / 4 : 1;  // (RPAD = 64: one row group per wave)
+  constexpr int M = (RPAD * RPAD) / WG > 0 ? (RPAD * RPAD) / WG : 1;
+  // Measured on MI355X (tools/solve_prof.hip): one LDS publish -> barrier -> LDS read exchange costs
+  // ~450 cycles whatever is exchanged, the arithmetic of a pivot ~250.  So pivots are taken as 2 x 2
+  // SPD blocks: two pivot rows per exchange, the 2 x 2 inverse recomputed by every thread.
+  //   K = [[a, b], [b, e]] = rows/cols (k, k+1);  Ki = K^-1 = [[p, q], [q, s]]
+  //   a_ic <- a_ic - [u_i w_i] Ki [u_c w_c]^T            (i, c outside the block; u = row k, w = row k+1)
+  //   rows k, k+1 <- Ki [u_c; w_c]    columns k, k+1 <- the same by symmetry    block <- -Ki
+  // r2 = r rounded up to even (the caller pads with an identity row/column).
+  const int wv = threadIdx.x >> 6;
+  const bool con = c < r2;
+  const int cc = con ? c : r2 - 1;
+  int ic[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) ic[m] = min(rg + m * RG, r2 - 1);
+  // rows 0 and 1 live in slot m = 0 of row groups 0 and 1 (RG >= 4)
+  if (rg < 2 && con) rowbuf[rg * RM + c] = A[0];
+  __syncthreads();
+  bool bad = false;
+  for (int k = 0; k < r2; k += 2) {
+    const double* rb0 = rowbuf + ((k >> 1) & 1) * 2 * RM;
+    const double* rb1 = rb0 + RM;
+    double* rn0 = rowbuf + (((k >> 1) + 1) & 1) * 2 * RM;
+    double* rn1 = rn0 + RM;
+    const double ka = rb0[k], kb = rb0[k + 1], ke = rb1[k + 1];
+    const double uc = rb0[cc], wc = rb1[cc];
+    double ui[M], wi[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      ui[m] = rb0[ic[m]];
+      wi[m] = rb1[ic[m]];
+    }
+    const double det = ka * ke - kb * kb;
+    bad |= !(ka > 0.0) | !(det > 0.0);
+    const double dinv = fast_rcp(det);
+    const double kp = ke * dinv, kq = -kb * dinv, ks = ka * dinv;
+    const bool c0 = (c == k), c1 = (c == k + 1);
+    // coefficients of this thread's column: generic  t = Ki [u_c; w_c];  pivot columns: -row of Ki, no a_ic term
+    double t1 = kp * uc + kq * wc;
+    double t2 = kq * uc + ks * wc;
+    const double keep = (c0 | c1) ? 0.0 : 1.0;
+    const double g1 = c0 ? -kp : (c1 ? -kq : t1);
+    const double g2 = c0 ? -kq : (c1 ? -ks : t2);
+#pragma unroll
+    for (int m = 0; m < M; ++m) A[m] = fma(-wi[m], g2, fma(-ui[m], g1, keep * A[m]));
+    // pivot rows: a_kc <- t1, a_(k+1)c <- t2; inside the block <- -Ki   (only in the waves that hold them)
+    if (((k % RG) / RGW) == wv || (((k + 1) % RG) / RGW) == wv) {
+      const double r0v = c0 ? -kp : (c1 ? -kq : t1);
+      const double r1v = c0 ? -kq : (c1 ? -ks : t2);
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        const int i = rg + m * RG;
+        A[m] = (i == k) ? r0v : ((i == k + 1) ? r1v : A[m]);
+      }
+    }
+    // next two pivot rows -> LDS
+    if (k + 2 < r2) {
+      if ((((k + 2) % RG) / RGW) == wv || (((k + 3) % RG) / RGW) == wv) {
+        double nx = 0.0;
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+          const int i = rg + m * RG;
+          nx = (i == k + 2 || i == k + 3) ? A[m] : nx;
+        }
+        if (con && ((k + 2) % RG) == rg) rn0[c] = nx;
+        if (con && ((k + 3) % RG) == rg) rn1[c] = nx;
+      }
+    }
+    __syncthreads();
+  }
+  if (bad && threadIdx.x == 0) *errflag = 1;
+}
+
+template <int RPAD>
+__device__ __forceinline__ void solve_block_t(const StepParams& p, double* sm) {
+  constexpr int RG = WG / RPAD;
+  constexpr int M = (RPAD * RPAD) / WG > 0 ? (RPAD * RPAD) / WG : 1;
+  DevState* st = p.st;
+  const int r = p.r, tid = threadIdx.x, c = tid % RPAD, rg = tid / RPAD;
+  const int r2 = r + (r & 1);                            // identity padding to an even size
+  double* rowbuf = sm;                                   // [2][2][RM]
+  int* errflag = reinterpret_cast<int*>(sm + 4 * RM);
+  if (tid == 0) *errflag = 0;
+  double A[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const int i = rg + m * RG;
+    const bool in = (i < r && c < r);
+    const double pv = in ? 0.5 * (st->Pbar[i * r + c] + st->Pbar[c * r + i]) : 0.0;
+    A[m] = in ? pv : ((i == c && i < r2) ? 1.0 : 0.0);
+  }
+  sweep_all<RPAD>(A, r2, c, rg, rowbuf, errflag);       // A = -Pbar^-1
+  const double kappa = st->kappa;
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const int i = rg + m * RG;
+    const double gv = (i < r && c < r) ? kappa * st->G[i * r + c] : 0.0;
+    A[m] = gv - A[m];
+  }
+  sweep_all<RPAD>(A, r2, c, rg, rowbuf, errflag);       // A = -(Pbar^-1 + kappa G)^-1
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const int i = rg + m * RG;
+    if (i < r && c < r) st->Pplus[i * r + c] = -A[m];   // symmetrised by the consumer (serial stage)
+  }
+  if (tid == 0 && *errflag && st->err == 0) st->err = (int)(st->k + 1);
+}
+
+__device__ __forceinline__ void solve_block(const StepParams& p, double* sm) {
+  const int r = p.r;
+  if (r <= 8) solve_block_t<8>(p, sm);
+  else if (r <= 16) solve_block_t<16>(p, sm);
+  else if (r <= 32) solve_block_t<32>(p, sm);
+  else solve_block_t<64>(p, sm);
+}
+
+// ------------------------------------------------------------------------------------------
+// Row sweep.  GS = lanes cooperating on one row (power of two >= nv = ceil(r / VEC)); each lane
+// owns one 16-byte vector of the row; a 256-thread workgroup covers 256/GS rows per pass and
+// keeps U passes of loads in flight.
+// ------------------------------------------------------------------------------------------
+template <typename T, int GS, int U>
+__global__ __launch_bounds__(WG) void psmf_sweep_solve(StepParams p) {
+  constexpr int VEC = 16 / sizeof(T);
+  constexpr int RPP = WG / GS;
+  typedef typename VecOf<T>::type VT;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* sm = reinterpret_cast<double*>(smem_raw);
+
+  // block 0 runs the r x r solve (dispatched first: it is the longest block)
+  const int has_solve = p.coef_update;
+  if (has_solve && blockIdx.x == 0) {
+    solve_block(p, sm);
+    return;
+  }
+  const int wgid = (int)blockIdx.x - has_solve;
+  DevState* st = p.st;
+  const int tid = threadIdx.x, j = tid % GS, g = tid / GS;
+  const int r = p.r, rp = p.rp;
+  const long long t = st->k - p.series_t0;  // row of the series buffer holding y_k
+  const T* __restrict__ y = reinterpret_cast<const T*>(p.Y) + (size_t)t * p.d_local;
+  T* __restrict__ yp = p.store_yp ? reinterpret_cast<T*>(p.YP) + (size_t)t * p.d_local : nullptr;
+  T* __restrict__ C = reinterpret_cast<T*>(p.C);
+
+  // r-sized operands and all row arithmetic in float64; only the storage of C, y, y_hat is T
+  double mub[VEC], wn[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    const int e = j * VEC + v;
+    mub[v] = e < r ? st->mu_bar[e] : 0.0;
+    wn[v] = e < r ? st->wN[e] : 0.0;
+  }
+  double hacc[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) hacc[v] = 0.0;
+  double eacc = 0.0;
+
+  const int row_begin = wgid * p.rows_per_wg;
+  const int row_end = min(row_begin + p.rows_per_wg, p.d_local);
+  const bool lane_on = j < p.nv;
+
+  for (int base = row_begin; base < row_end; base += RPP * U) {
+    VT cv[U];
+    T yv[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int row = base + u * RPP + g;
+      const bool ok = row < row_end;
+      if (ok && lane_on) {
+        cv[u] = *reinterpret_cast<const VT*>(C + (size_t)row * rp + j * VEC);
+      } else {
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) cv[u][v] = (T)0;
+      }
+      yv[u] = ok ? y[row] : (T)0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int row = base + u * RPP + g;
+      const bool ok = row < row_end;
+      double cd[VEC];
+      double dot = 0.0;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        cd[v] = (double)cv[u][v];
+        dot += cd[v] * mub[v];
+      }
+#pragma unroll
+      for (int m = GS / 2; m >= 1; m >>= 1) dot += __shfl_xor(dot, m, 64);
+      const double e = ok ? (double)yv[u] - dot : 0.0;
+      VT cn;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        cn[v] = (T)(cd[v] + e * wn[v]);      // one rounding to the storage type per step
+        hacc[v] += cd[v] * e;
+      }
+      if (ok && lane_on) *reinterpret_cast<VT*>(C + (size_t)row * rp + j * VEC) = cn;
+      if (ok && j == 0) {
+        if (yp) yp[row] = (T)dot;
+        eacc += e * e;
+      }
+    }
+  }
+
+  // lanes with equal j inside a wave, then the 4 waves through LDS
+#pragma unroll
+  for (int m = 32; m >= GS; m >>= 1) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) hacc[v] += __shfl_xor(hacc[v], m, 64);
+    eacc += __shfl_xor(eacc, m, 64);
+  }
+  constexpr int NE = GS * VEC;  // >= rp
+  const int lane = tid & 63, wv = tid >> 6;
+  if (lane < GS) {
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) sm[wv * (NE + 1) + lane * VEC + v] = hacc[v];
+    if (lane == 0) sm[wv * (NE + 1) + NE] = eacc;
+  }
+  __syncthreads();
+  double* out = p.partials + (size_t)wgid * p.ps;
+  if (tid <= NE) {
+    const double s4 = (sm[tid] + sm[(NE + 1) + tid]) + (sm[2 * (NE + 1) + tid] + sm[3 * (NE + 1) + tid]);
+    if (tid < r) out[tid] = s4;
+    if (tid == NE) out[r] = s4;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Serial stage: one workgroup of SWG = 1024 threads.  All 16 waves take part in the
+// deterministic (fixed-order) reduction of the sweep partials -- each thread sums <= 16 terms with
+// every load in flight at once, i.e. ONE memory round trip -- then waves 4..15 retire and the four
+// "worker" waves do the r x r work.  RPAD = power of two >= max(r, 8).  Worker thread tid owns
+// column j = tid % RPAD and rows i_m = tid / RPAD + m * (256 / RPAD) of every r x r matrix, in
+// registers.  All matrices are symmetric, so a matrix-vector product is a per-thread partial
+// plus one LDS column reduce.  Every global load of the stage is issued before the first
+// barrier (the stage is latency-bound: what matters is the number of dependent round trips).
+// ------------------------------------------------------------------------------------------
+constexpr int SWG = 1024;
+// r > 32 keeps 4 x 16 matrix elements per worker thread in registers: 8 waves (256 VGPRs each) instead of 16
+__host__ __device__ constexpr int serial_threads(int rpad) { return rpad >= 64 ? 512 : SWG; }
+
+template <int RPAD>
+__device__ __forceinline__ void col_reduce(double partial, double* s_red, double* s_out) {
+  constexpr int RG = WG / RPAD;
+  const int tid = threadIdx.x;
+  s_red[tid] = partial;  // index = (tid / RPAD) * RPAD + tid % RPAD
+  __syncthreads();
+  if (tid < RPAD) {
+    double a = 0.0;
+#pragma unroll
+    for (int gI = 0; gI < RG; ++gI) a += s_red[gI * RPAD + tid];
+    s_out[tid] = a;
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ double block_sum(double x, double* s4) {   // worker waves only
+  x = wave_sum(x);
+  if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = x;
+  __syncthreads();
+  return (s4[0] + s4[1]) + (s4[2] + s4[3]);
+}
+
+template <int RPAD>
+__global__ __launch_bounds__(serial_threads(RPAD)) void psmf_serial(StepParams p, int first) {
+  constexpr int RG = WG / RPAD;
+  constexpr int M = (RPAD * RPAD) / WG > 0 ? (RPAD * RPAD) / WG : 1;
+  constexpr int NSEG = 32;
+  DevState* st = p.st;
+  const int r = p.r, tid = threadIdx.x;
+  const bool worker = tid < WG;
+  const int j = tid % RPAD, ig = (tid % WG) / RPAD;
+  const double dd = (double)p.d;
+
+  __shared__ double s_red[WG];
+  __shared__ double s_he[RM + 1];   // h[0..r), ee at [r]
+  __shared__ double s_w[RM], s_mub[RM], s_f[RM], s_vec[RM];
+  __shared__ double s_part[NSEG][RM + 1];
+  __shared__ double s4[4];
+
+  // ---------------- every global load of the stage, issued up front ----------------
+  const int ne = r + 1;
+  int nseg = serial_threads(RPAD) / ne;
+  if (nseg > NSEG) nseg = NSEG;
+  const int pe = tid % ne, psg = tid / ne;
+  double psum = 0.0;
+  if (!first) {
+    if (p.external_reduce) {
+      if (tid < ne) psum = st->red[tid];
+    } else if (tid < ne * nseg) {
+      psum = strided_sum(p.partials + pe, psg, nseg, p.n_sweep_wg, p.ps);
+    }
+  }
+  double Vv[M], Pv[M], Gv[M], Qv[M];
+  bool val[M];
+  int ii[M];
+  const double* psrc = first ? st->P : (p.coef_update ? st->Pplus : st->Pbar);
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    ii[m] = ig + m * RG;
+    val[m] = worker && (j < r) && (ii[m] < r);
+    const int idx = val[m] ? ii[m] * r + j : 0;
+    const int idt = val[m] ? j * r + ii[m] : 0;
+    Vv[m] = val[m] ? st->V[idx] : 0.0;
+    Gv[m] = val[m] ? st->G[idx] : 0.0;
+    Qv[m] = val[m] ? st->Q[idx] : 0.0;
+    Pv[m] = val[m] ? 0.5 * (psrc[idx] + psrc[idt]) : 0.0;
+  }
+  double rho = st->rho, lam = st->lam;
+  const double N0 = st->N, kappa0 = st->kappa, s0 = st->s, eta0 = st->eta;
+  const long long k0 = st->k;       // read once (thread 0 rewrites it below)
+  long long knext = k0;             // index (0-based) of the step to prepare
+  const bool vl = tid < r;
+  const bool tl = tid < p.n_theta;
+  double mu_new = vl ? st->mu[tid] : 0.0;
+  const double mu_old = mu_new;
+  const double w_t = vl ? st->w[tid] : 0.0;
+  const double mub_t = vl ? st->mu_bar[tid] : 0.0;
+  double theta = tl ? st->theta[tid] : 0.0;
+  double gsum = tl ? st->gradsum[tid] : 0.0;
+  double am = (tl && p.recursive) ? st->adam_m[tid] : 0.0;
+  double av = (tl && p.recursive) ? st->adam_v[tid] : 0.0;
+
+  if (!first) {
+    // ---- fixed-order reduction of the per-workgroup partials ----
+    if (!p.external_reduce) {
+      if (tid < ne * nseg) s_part[psg][pe] = psum;
+      __syncthreads();
+      if (!worker) return;          // helper waves retire; later barriers count the 4 worker waves only
+      if (tid < ne) {
+        double a = 0.0;
+        for (int sg = 0; sg < nseg; ++sg) a += s_part[sg][tid];
+        s_he[tid] = a;
+      }
+    } else {
+      if (!worker) return;
+      if (tid < ne) s_he[tid] = psum;
+    }
+    if (vl) {
+      s_w[tid] = w_t;
+      s_mub[tid] = mub_t;
+    }
+    __syncthreads();
+    const double N = N0, kappa = kappa0;
+    const double ee = s_he[r];
+    const double wj = j < r ? s_w[j] : 0.0;
+
+    // ---- coefficient mean / covariance   psmf.py:155-165 ----
+    double quad = kappa * ee;
+    if (p.coef_update) {
+      double part = 0.0;
+#pragma unroll
+      for (int m = 0; m < M; ++m) part += val[m] ? Pv[m] * (kappa * s_he[min(ii[m], r)]) : 0.0;
+      col_reduce<RPAD>(part, s_red, s_vec);   // s_vec = Pplus b
+      double bPb = 0.0;
+      for (int l = 0; l < r; ++l) bPb += kappa * s_he[l] * s_vec[l];
+      quad -= bPb;
+      if (vl) mu_new = mub_t + s_vec[tid];
+    } else {
+      if (vl) mu_new = mub_t;
+    }
+
+    // ---- theta gradient at the pre-update state   psmf.py:48-66,167-177; rpsmf.py:53-73 ----
+    if (tl && p.dyn_kind == 1) {
+      const double tk = (double)(k0 + 1);
+      const double arg = 2.0 * M_PI * theta * tk + mu_old;
+      const double jt = -sin(arg) * (2.0 * M_PI * tk);
+      const double wi = w_t, hi = s_he[tid];
+      double gf;
+      if (p.robust) {
+        const double D = lam * N;
+        gf = dd * wi / N + 0.5 * (dd + lam) * (-2.0 * hi / D - 2.0 * lam * ee * wi / (D * D)) / (1.0 + ee / D);
+      } else {
+        gf = dd * wi / N - hi / N - ee * wi / (N * N);
+      }
+      gsum += jt * gf;
+    }
+
+    // ---- robust scalars   rpsmf.py:133-171 ----
+    double vscale = 1.0, pscale = 1.0, qscale = 1.0, phi = 1.0, omega = 1.0;
+    if (p.robust) {
+      phi = (lam + ee / N) / (lam + dd);
+      omega = (lam + quad) / (lam + dd);
+      vscale = p.alpha * phi;
+      if (p.coef_update) { pscale = p.beta * omega; qscale = omega; }
+      rho *= omega;
+      if (!p.fixed_lambda) lam += dd;
+    }
+
+    // ---- r x r elementwise updates (V, P, Q, tracked Gram) ----
+    const double invN = 1.0 / N;
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      if (val[m]) {
+        const int idx = ii[m] * r + j;
+        const double wi = s_w[ii[m]], hi = s_he[ii[m]], hj = s_he[j];
+        Vv[m] = vscale * (Vv[m] - wi * wj * invN);
+        Pv[m] *= pscale;
+        st->V[idx] = Vv[m];
+        st->P[idx] = Pv[m];
+        if (p.track_g) {
+          Gv[m] += (hi * wj + wi * hj) * invN + ee * (wi * wj) * (invN * invN);
+          st->G[idx] = Gv[m];
+        }
+        if (qscale != 1.0) { Qv[m] *= qscale; st->Q[idx] = Qv[m]; }
+      }
+    }
+    knext = k0 + 1;
+
+    // ---- Adam on theta inside the time loop (PSMFRecursive, psmf.py:299-304,224-242) ----
+    if (tl) {
+      if (p.recursive && (knext % p.update_every) == 0) {
+        const double kk = (double)knext;
+        const double lr = p.lr_steps > 0.0 ? p.lr * pow(p.lr_end / p.lr, kk / p.lr_steps) : p.lr;
+        am = p.b1 * am + (1.0 - p.b1) * gsum;
+        av = p.b2 * av + (1.0 - p.b2) * gsum * gsum;
+        st->adam_m[tid] = am;
+        st->adam_v[tid] = av;
+        const double mh = am / (1.0 - pow(p.b1, kk));
+        const double vh = av / (1.0 - pow(p.b2, kk));
+        theta = fmax(theta - lr * mh / (sqrt(vh) + 1e-8), 0.0);
+        st->theta[tid] = theta;
+        gsum = 0.0;
+      }
+      st->gradsum[tid] = gsum;
+    }
+    if (vl) st->mu[tid] = mu_new;
+    if (tid == 0) {
+      st->k = knext;
+      st->rho = rho;
+      st->lam = lam;
+      st->phi = phi;
+      st->omega = omega;
+      st->ee = ee;
+      st->s_done = s0;
+      st->eta_done = eta0;
+      st->N_done = N;
+    }
+  } else {
+    if (!worker) return;
+  }
+
+  // =============== everything the NEXT sweep / solve needs (step index knext + 1) ===========
+  if (vl) {
+    double mb = mu_new, f = 1.0;
+    if (p.dyn_kind == 1) {   // cos(2 pi theta t + x)
+      const double arg = 2.0 * M_PI * theta * (double)(knext + 1) + mu_new;
+      mb = cos(arg);
+      f = -sin(arg);
+    }
+    s_mub[tid] = mb;         // (the current step's mu_bar was consumed from registers above)
+    s_f[tid] = f;
+    st->mu_bar[tid] = mb;
+  }
+  __syncthreads();
+  double part = 0.0, gp = 0.0;
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    if (val[m]) {
+      const double pb = p.pbar_predict ? s_f[ii[m]] * Pv[m] * s_f[j] + Qv[m] : Pv[m];
+      st->Pbar[ii[m] * r + j] = pb;
+      part += Vv[m] * s_mub[ii[m]];
+      gp += Gv[m] * pb;
+    }
+  }
+  col_reduce<RPAD>(part, s_red, s_vec);   // s_vec = V mu_bar
+  double s = 0.0;
+  for (int l = 0; l < r; ++l) s += s_mub[l] * s_vec[l];
+  double eta = rho;
+  if (p.eta_full) eta += block_sum(gp, s4) / dd;   // (d rho + <G, Pbar>) / d   psmf.py:121-125
+  const double N = s + eta;
+  if (vl) {
+    st->w[tid] = s_vec[tid];
+    st->wN[tid] = s_vec[tid] / N;
+  }
+  if (tid == 0) {
+    st->s = s;
+    st->eta = eta;
+    st->N = N;
+    st->kappa = 1.0 / (rho + s);
+  }
+}
+
+// local reduction of the per-workgroup partials into st->red (multi-GPU: input of the all-reduce)
+__global__ __launch_bounds__(WG) void psmf_reduce_partials(StepParams p) {
+  __shared__ double s_part[8][RM + 1];
+  const int tid = threadIdx.x, ne = p.r + 1;
+  int nseg = WG / ne;
+  if (nseg > 8) nseg = 8;
+  if (tid < ne * nseg) {
+    const int e = tid % ne, sg = tid / ne;
+    s_part[sg][e] = strided_sum(p.partials + e, sg, nseg, p.n_sweep_wg, p.ps);
+  }
+  __syncthreads();
+  if (tid < ne) {
+    double a = 0.0;
+    for (int sg = 0; sg < nseg; ++sg) a += s_part[sg][tid];
+    p.st->red[tid] = a;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Exact Gram matrix G = C^T C of the local rows (float64 accumulation), used at set_state and
+// at the optional periodic refresh.  gpart: n_wg x r*r partials, reduced in fixed order.
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(WG) void psmf_gram_partial(const T* __restrict__ C, int d_local, int r, int rp,
+                                                        int rows_per_wg, double* __restrict__ gpart) {
+  constexpr int TR = 32;   // rows per LDS tile
+  __shared__ double tile[TR][RM + 1];
+  const int tid = threadIdx.x;
+  constexpr int MU = (RM * RM) / WG;   // 16
+  double acc[MU];
+  int qa[MU], qb[MU];
+#pragma unroll
+  for (int u = 0; u < MU; ++u) {
+    const int q = tid + u * WG;
+    acc[u] = 0.0;
+    qa[u] = q < r * r ? q / r : -1;
+    qb[u] = q < r * r ? q - (q / r) * r : 0;
+  }
+  const int row_begin = blockIdx.x * rows_per_wg;
+  const int row_end = min(row_begin + rows_per_wg, d_local);
+  for (int base = row_begin; base < row_end; base += TR) {
+    __syncthreads();
+    for (int idx = tid; idx < TR * r; idx += WG) {
+      const int rr = idx / r, c = idx - rr * r;
+      const int row = base + rr;
+      tile[rr][c] = row < row_end ? (double)C[(size_t)row * rp + c] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < MU; ++u) {
+      if (qa[u] >= 0) {
+        double a = acc[u];
+        for (int rr = 0; rr < TR; ++rr) a += tile[rr][qa[u]] * tile[rr][qb[u]];
+        acc[u] = a;
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < MU; ++u)
+    if (qa[u] >= 0) gpart[(size_t)blockIdx.x * r * r + tid + u * WG] = acc[u];
+}
+
+__global__ void psmf_gram_reduce(const double* __restrict__ gpart, int n_wg, int rr, double* __restrict__ G) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < rr) {
+    double a = 0.0;
+    for (int w = 0; w < n_wg; ++w) a += gpart[(size_t)w * rr + q];
+    G[q] = a;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// predict roll-out: out[t][row] = C[row] . mu_pred[t]          psmf.py:182-188
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(WG) void psmf_predict_rows(const T* __restrict__ C, int d_local, int r, int rp,
+                                                        const double* __restrict__ mu_pred, int n_pred,
+                                                        double* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* s_mu = reinterpret_cast<double*>(smem_raw);   // chunk of mu_pred rows
+  const int row = blockIdx.x * WG + threadIdx.x;
+  double c[RM];
+  if (row < d_local)
+    for (int l = 0; l < r; ++l) c[l] = (double)C[(size_t)row * rp + l];
+  constexpr int TC = 64;
+  for (int t0 = 0; t0 < n_pred; t0 += TC) {
+    const int nt = min(TC, n_pred - t0);
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < nt * r; idx += WG) s_mu[idx] = mu_pred[(size_t)t0 * r + idx];
+    __syncthreads();
+    if (row < d_local) {
+      for (int t = 0; t < nt; ++t) {
+        double a = 0.0;
+        for (int l = 0; l < r; ++l) a += c[l] * s_mu[t * r + l];
+        out[(size_t)(t0 + t) * d_local + row] = a;
+      }
+    }
+  }
+}
+
+// sum of squared prediction errors over a block of steps (tracking.py:63-76 norms)
+template <typename T>
+__global__ __launch_bounds__(WG) void psmf_sq_error_k(const T* __restrict__ YP, const T* __restrict__ Y, size_t n,
+                                                      double* __restrict__ part) {
+  __shared__ double s4[4];
+  double a = 0.0;
+  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n; i += (size_t)gridDim.x * WG) {
+    const double dlt = (double)YP[i] - (double)Y[i];
+    a += dlt * dlt;
+  }
+  a = wave_sum(a);
+  if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = a;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+}
+
+}  // namespace psmf

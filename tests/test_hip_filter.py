@@ -1,0 +1,259 @@
+"""Parity of the HIP large-d engine (through the C ABI) with the CPU oracle and the golden
+fixtures.  GPU only: `pytest -m gpu`.
+
+Tolerances: storage f64 -> 1e-9 relative (pure float64 arithmetic on both sides, different
+summation order + algebraically tracked Gram); storage f32 -> 1e-5 relative, the bar
+BASELINE.json's north_star states.
+"""
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, relerr
+from oracle import psmf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = {"f64": 1e-9, "f32": 1e-5}
+
+
+def _capi():
+    from rpsmf_amd import _capi
+
+    return _capi
+
+
+def _mode_kwargs(mode):
+    return dict(robust=mode.robust, coef_update=mode.coef_update, eta_full=mode.eta_full,
+                pbar_predict=mode.pbar_predict, fixed_lambda=mode.fixed_lambda, alpha=mode.alpha, beta=mode.beta)
+
+
+def _compare(dev_state, st, tol, what=("C", "V", "mu", "P")):
+    for name in what:
+        ref = getattr(st, name)
+        if np.max(np.abs(ref)) == 0.0:
+            assert np.max(np.abs(dev_state[name])) == 0.0, name
+        else:
+            assert relerr(dev_state[name], ref) < tol, (name, relerr(dev_state[name], ref))
+
+
+@pytest.mark.parametrize("storage", ["f64", "f32"])
+@pytest.mark.parametrize("name,robust", [("psmf_full_rw", False), ("rpsmf_full_rw", True)])
+def test_golden_full_filter(name, robust, storage):
+    """PSMFIter / rPSMFIter as shipped (d=20, r=5, T=200, two epochs) against the reference's outputs."""
+    c = _capi()
+    g = load_golden(name)
+    Y = g["Y"]
+    T, d = Y.shape
+    r = g["C0"].shape[1]
+    f = c.DeviceFilter(d, r, robust=robust, storage=storage)
+    f.upload_series(Y)
+    f.set_state(g["C0"], g["V0"], g["P0"], g["Q"], g["mu0"], rho=float(g["rho"]), lambda0=float(g["lambda0"]))
+    tol = TOL[storage]
+    for ep in (1, 2):
+        if ep == 2 and robust:
+            f.set_state(Q=g["Q"], rho=float(g["rho"]), lambda0=float(g["lambda0"]))
+        k_prev = 0
+        for k in (1, 2, 10, 200):
+            f.run(k_prev, k)
+            k_prev = k
+            s = f.get_state()
+            p = f"s_e{ep}_k{k}_"
+            assert relerr(s["C"], g[p + "C"]) < tol
+            assert relerr(s["V"], g[p + "V"]) < tol
+            assert relerr(s["mu"], g[p + "mu"].reshape(-1)) < tol
+            assert relerr(s["P"], g[p + "P"]) < tol
+            assert relerr(s["eta"], g[p + "eta"]) < tol
+            assert relerr(s["N"], g[p + "N"]) < tol
+            if robust:
+                assert relerr(s["lam"], g[p + "lam"]) < tol
+                assert relerr(s["rho"], g[p + "rho"]) < tol
+                assert relerr(s["Q"], g[p + "Q"]) < tol
+    assert relerr(f.y_pred(0, T), g["y_pred_e2"]) < tol
+    f.close()
+
+
+def _problem(d, r, T, seed, noise="normal"):
+    Y = O.synthetic_series(d, r, T, seed, noise=noise, dtype=np.float64)
+    rng = np.random.default_rng(seed + 1)
+    return Y, 0.1 * rng.standard_normal((d, r))
+
+
+@pytest.mark.parametrize("storage", ["f64", "f32"])
+@pytest.mark.parametrize("robust", [False, True])
+@pytest.mark.parametrize("d,r,T", [(3000, 20, 150), (777, 7, 60), (4096, 32, 80), (260, 64, 40), (50, 1, 30)])
+def test_full_filter_vs_oracle(d, r, T, robust, storage):
+    """Full filter, random walk, ragged shapes (rows not a multiple of the tile, r not a multiple of 4)."""
+    c = _capi()
+    Y, C0 = _problem(d, r, T, 100 + d + r, "t" if robust else "normal")
+    if storage == "f32":
+        Y = Y.astype(np.float32).astype(np.float64)
+        C0 = C0.astype(np.float32).astype(np.float64)
+    V0, P0, Q = 0.1 * np.eye(r), np.eye(r), 0.1 * np.eye(r)
+    st = O.State(C=C0, V=V0, mu=np.zeros(r), P=P0, Q=Q, rho=1.0, lam=1.8)
+    mode = O.Mode(robust=robust)
+    st, Yp, _ = O.run_epoch(st, Y, mode, O.RandomWalkDyn())
+    f = c.DeviceFilter(d, r, storage=storage, **_mode_kwargs(mode))
+    f.upload_series(Y)
+    f.set_state(C0, V0, P0, Q, np.zeros(r), rho=1.0, lambda0=1.8)
+    f.run(0, T)
+    s = f.get_state()
+    tol = TOL[storage]
+    _compare(s, st, tol)
+    assert relerr(f.y_pred(0, T), Yp) < tol
+    if robust:
+        assert relerr(s["rho"], st.rho) < tol and relerr(s["lam"], st.lam) < 1e-12
+    # squared-error reduction on the device == host value
+    assert relerr(f.sq_error(0, T), np.sum((Yp - Y) ** 2)) < 10 * tol
+    # predict roll-out (random walk: y_hat = C_T mu_T)
+    assert relerr(f.predict(T, 3), O.predict_rollout(st.C, st.mu, None, O.RandomWalkDyn(), T, 3)) < tol
+    f.close()
+
+
+@pytest.mark.parametrize("storage", ["f64", "f32"])
+@pytest.mark.parametrize("robust", [False, True])
+def test_simplified_cos_mode(robust, storage):
+    """ExperimentSynthetic configuration on the device: P = 0, eta = tr(R)/d, no coefficient update,
+    cos dynamics with theta, closed-form theta gradient (synthetic_psmf.py:78-100)."""
+    c = _capi()
+    g = load_golden("rpsmf_simplified_cos" if robust else "psmf_simplified_cos")
+    T, n_pred = int(g["T"]), int(g["n_pred"])
+    Y = g["Y_obs"][:T]
+    d, r = g["C0"].shape
+    mode = O.Mode(robust=robust, coef_update=False, eta_full=False, pbar_predict=False)
+    f = c.DeviceFilter(d, r, storage=storage, dyn_kind=c.DYN_COS_PHASE, **_mode_kwargs(mode))
+    f.upload_series(Y)
+    f.set_state(g["C0"], g["V0"], g["P0"], np.zeros((r, r)), g["mu0"], rho=1.0, lambda0=1.8, theta=g["theta0"])
+    f.zero_gradsum()
+    f.run(0, T)
+    s = f.get_state()
+    tol = TOL[storage]
+    p = f"s_e1_k{T}_"
+    assert relerr(s["C"], g[p + "C"]) < tol
+    assert relerr(s["V"], g[p + "V"]) < tol
+    assert relerr(s["mu"], g[p + "mu"].reshape(-1)) < tol
+    # the fixture's gradient is a finite-difference derivative of the reference's likelihood
+    assert relerr(s["gradsum"], g["gradsum"][0]) < max(tol, 1e-6) * 10
+    # epoch-1 predictions incl. the roll-out: theta is still theta0 at this point
+    yp = np.vstack([f.y_pred(0, T), f.predict(T, n_pred)])
+    st = O.State(C=g["C0"], V=g["V0"], mu=g["mu0"], P=g["P0"], Q=np.zeros((r, r)), rho=1.0, lam=1.8,
+                 theta=g["theta0"].copy(), gradsum=np.zeros(r))
+    st, Yp, _ = O.run_epoch(st, Y, mode, O.CosPhaseDyn(r))
+    ref = np.vstack([Yp, O.predict_rollout(st.C, st.mu, st.theta, O.CosPhaseDyn(r), T, n_pred)])
+    assert relerr(yp, ref) < tol
+    assert relerr(s["gradsum"], st.gradsum) < tol * 10
+    f.close()
+
+
+@pytest.mark.parametrize("robust", [False, True])
+def test_recursive_adam_on_device(robust):
+    """PSMFRecursive / rPSMFRecursive: theta updated by Adam inside the device time loop."""
+    c = _capi()
+    g = load_golden("rpsmf_recursive" if robust else "psmf_recursive")
+    T, n_pred, ue = int(g["T"]), int(g["n_pred"]), int(g["update_every"])
+    d, r = g["C0"].shape
+    f = c.DeviceFilter(d, r, storage="f64", robust=robust, dyn_kind=c.DYN_COS_PHASE, recursive=True,
+                       update_every=ue, adam_lr=1e-3)
+    f.upload_series(g["Y"])
+    f.set_state(g["C0"], g["V0"], g["P0"], g["Q"], g["mu0"], rho=float(g["rho"]), lambda0=float(g["lambda0"]),
+                theta=g["theta0"])
+    f.zero_gradsum()
+    f.set_adam(np.zeros(r), np.zeros(r))
+    f.run(0, T)
+    s = f.get_state()
+    assert relerr(s["theta"], g["theta"][-1]) < 1e-6
+    assert relerr(s["C"], g["C_T"]) < 1e-6
+    assert relerr(s["mu"], g["mu_T"]) < 1e-6
+    assert relerr(s["P"], g["P_T"]) < 1e-6
+    yp = np.vstack([f.y_pred(0, T), f.predict(T, n_pred)])
+    assert relerr(yp, g["y_pred"]) < 1e-6
+    f.close()
+
+
+def test_graph_and_eager_agree_bitwise():
+    """The hipGraph replay and plain launches run the same kernels: identical bits."""
+    c = _capi()
+    d, r, T = 2000, 20, 600   # > one graph chunk of 256 steps
+    Y, C0 = _problem(d, r, T, 5)
+    outs = []
+    for use_graph in (True, False):
+        f = c.DeviceFilter(d, r, storage="f32", use_graph=use_graph)
+        f.upload_series(Y.astype(np.float32))
+        f.set_state(C0, 0.1 * np.eye(r), np.eye(r), 0.1 * np.eye(r), np.zeros(r), rho=1.0, lambda0=0.0)
+        f.run(0, T)
+        outs.append(f.get_state())
+        f.close()
+    for k in ("C", "V", "mu", "P"):
+        assert np.array_equal(outs[0][k], outs[1][k]), k
+
+
+def test_gram_refresh_changes_nothing_material():
+    c = _capi()
+    d, r, T = 3000, 16, 300
+    Y, C0 = _problem(d, r, T, 9)
+    res = []
+    for refresh in (0, 64):
+        f = c.DeviceFilter(d, r, storage="f32", gram_refresh=refresh)
+        f.upload_series(Y.astype(np.float32))
+        f.set_state(C0, 0.1 * np.eye(r), np.eye(r), 0.1 * np.eye(r), np.zeros(r), rho=1.0, lambda0=0.0)
+        f.run(0, T)
+        res.append(f.get_state())
+        f.close()
+    for k in ("C", "V", "mu", "P"):
+        assert relerr(res[0][k], res[1][k]) < 1e-5  # fp32 storage: different rounding path, same bar
+
+
+def test_collective_path_single_rank_matches_plain():
+    """The multi-GPU code path (local reduce kernel -> RCCL all-reduce of h, ee -> serial stage, all
+    captured in the hipGraph) run with a one-rank communicator must equal the plain path."""
+    c = _capi()
+    d, r, T = 1500, 12, 40
+    Y, C0 = _problem(d, r, T, 21)
+    full = c.DeviceFilter(d, r, storage="f64")
+    full.upload_series(Y)
+    full.set_state(C0, 0.1 * np.eye(r), np.eye(r), 0.1 * np.eye(r), np.zeros(r), rho=1.0, lambda0=0.0)
+    full.run(0, T)
+    s_full = full.get_state()
+    full.close()
+    # RCCL with a single rank exercises the collective code path (reduce kernel + all-reduce + graph capture)
+    import os
+
+    os.environ["PSMF_FORCE_COLLECTIVE"] = "1"
+    try:
+        one = c.DeviceFilter(d, r, storage="f64")
+        one.comm_init(1, 0, c.DeviceFilter.comm_unique_id())
+        one.upload_series(Y)
+        one.set_state(C0, 0.1 * np.eye(r), np.eye(r), 0.1 * np.eye(r), np.zeros(r), rho=1.0, lambda0=0.0)
+        one.run(0, T)
+        s_one = one.get_state()
+        one.close()
+    finally:
+        del os.environ["PSMF_FORCE_COLLECTIVE"]
+    for k in ("C", "V", "mu", "P"):
+        assert relerr(s_one[k], s_full[k]) < 1e-12, k
+
+
+def test_singular_system_raises_linalgerror():
+    """Non-finite state -> the r x r solve has no usable pivot -> LinAlgError, as numpy.linalg.inv would raise."""
+    c = _capi()
+    d, r, T = 64, 4, 3
+    Y = np.zeros((T, d))
+    f = c.DeviceFilter(d, r, storage="f64")
+    f.upload_series(Y)
+    P0 = np.full((r, r), np.nan)
+    f.set_state(np.ones((d, r)), np.eye(r), P0, np.eye(r), np.zeros(r), rho=1.0, lambda0=0.0)
+    with pytest.raises(np.linalg.LinAlgError):
+        f.run(0, T)
+    f.close()
+
+
+def test_argument_errors():
+    c = _capi()
+    with pytest.raises(ValueError):
+        c.DeviceFilter(10, 65)
+    f = c.DeviceFilter(10, 3)
+    with pytest.raises(c.PsmfError):
+        f.run(0, 1)   # no state / series yet
+    with pytest.raises(ValueError):
+        f.upload_series(np.zeros((4, 11)))
+    f.close()
