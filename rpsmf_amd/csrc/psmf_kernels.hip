@@ -154,6 +154,21 @@ __device__ __forceinline__ void sweep_all(double (&A)[(RPAD * RPAD) / WG > 0 ? (
   if (bad && threadIdx.x == 0) *errflag = 1;
 }
 
+// A (in): symmetric Pbar elements of this thread, identity-padded to r2;  Gk (in): kappa * G elements
+// (0 in the padding).  A (out): elements of (Pbar^-1 + kappa G)^-1.  rowbuf: 4 * RM doubles of LDS.
+template <int RPAD>
+__device__ __forceinline__ void spd_update_solve(double (&A)[(RPAD * RPAD) / WG > 0 ? (RPAD * RPAD) / WG : 1],
+                                                 const double (&Gk)[(RPAD * RPAD) / WG > 0 ? (RPAD * RPAD) / WG : 1],
+                                                 const int r2, const int c, const int rg, double* rowbuf, int* errflag) {
+  constexpr int M = (RPAD * RPAD) / WG > 0 ? (RPAD * RPAD) / WG : 1;
+  sweep_all<RPAD>(A, r2, c, rg, rowbuf, errflag);       // A = -Pbar^-1
+#pragma unroll
+  for (int m = 0; m < M; ++m) A[m] = Gk[m] - A[m];
+  sweep_all<RPAD>(A, r2, c, rg, rowbuf, errflag);       // A = -(Pbar^-1 + kappa G)^-1
+#pragma unroll
+  for (int m = 0; m < M; ++m) A[m] = -A[m];
+}
+
 template <int RPAD>
 __device__ __forceinline__ void solve_block_t(const StepParams& p, double* sm) {
   constexpr int RG = WG / RPAD;
@@ -164,27 +179,21 @@ __device__ __forceinline__ void solve_block_t(const StepParams& p, double* sm) {
   double* rowbuf = sm;                                   // [2][2][RM]
   int* errflag = reinterpret_cast<int*>(sm + 4 * RM);
   if (tid == 0) *errflag = 0;
-  double A[M];
+  const double kappa = st->kappa;
+  double A[M], Gk[M];
 #pragma unroll
   for (int m = 0; m < M; ++m) {
     const int i = rg + m * RG;
     const bool in = (i < r && c < r);
     const double pv = in ? 0.5 * (st->Pbar[i * r + c] + st->Pbar[c * r + i]) : 0.0;
     A[m] = in ? pv : ((i == c && i < r2) ? 1.0 : 0.0);
+    Gk[m] = in ? kappa * st->G[i * r + c] : 0.0;
   }
-  sweep_all<RPAD>(A, r2, c, rg, rowbuf, errflag);       // A = -Pbar^-1
-  const double kappa = st->kappa;
+  spd_update_solve<RPAD>(A, Gk, r2, c, rg, rowbuf, errflag);
 #pragma unroll
   for (int m = 0; m < M; ++m) {
     const int i = rg + m * RG;
-    const double gv = (i < r && c < r) ? kappa * st->G[i * r + c] : 0.0;
-    A[m] = gv - A[m];
-  }
-  sweep_all<RPAD>(A, r2, c, rg, rowbuf, errflag);       // A = -(Pbar^-1 + kappa G)^-1
-#pragma unroll
-  for (int m = 0; m < M; ++m) {
-    const int i = rg + m * RG;
-    if (i < r && c < r) st->Pplus[i * r + c] = -A[m];   // symmetrised by the consumer (serial stage)
+    if (i < r && c < r) st->Pplus[i * r + c] = A[m];    // symmetrised by the consumer (serial stage)
   }
   if (tid == 0 && *errflag && st->err == 0) st->err = (int)(st->k + 1);
 }

@@ -1,0 +1,538 @@
+"""PSMF filter classes with the call surface of pypsmf (`PSMFIter`, `PSMFRecursive`).
+
+Same constructor, `run / step / inner / predict / optim_* / adam_* / sgd_*` methods, the same
+overridable hook names and the same state attributes (`_C, _V, _mu, _P, _theta, _y_pred, _Q, _R,
+_gradsum`, `C0, theta0, V0, _d, _r`) as pypsmf/psmf/psmf.py, so experiment subclasses written
+against the reference (and its TrackingMixin) run unchanged.  Two execution back ends:
+
+backend="hip"    (default) the whole `for k in 1..T: inner(...)` loop runs on the MI355X through
+                 libpsmf_hip.so (include/psmf_hip.h).  Only *recognised* hook configurations can
+                 be fused: the class attribute `hip_mode` names one ("full" = the hooks as
+                 shipped; "simplified" = the ExperimentSynthetic overrides: P_bar = P_{k-1},
+                 eta = tr(R)/d, no coefficient update).  A subclass that overrides compute hooks
+                 must declare its `hip_mode`; otherwise the constructor raises.  There is no
+                 silent CPU fallback: if the library or the GPU is missing, it raises.
+backend="numpy"  the hooks below are executed one by one on the host, exactly as the
+                 reference does, but in O(d r^2): no d x d matrix is ever formed (diagonal R,
+                 Woodbury in r x r form, S^-1 as an implicit operator).  This is the plumbing
+                 path for arbitrary hook overrides and arbitrary `nonlinearity` callables.
+
+Deviations from the reference, all deliberate: `Rs[k]` / `Qs[k]` may be scalars or (d,) vectors
+in addition to dense matrices (dense d x d is unusable at d >= 10^4); derivatives of the
+nonlinearity are analytic / complex-step instead of autograd.
+"""
+
+import numpy as np
+
+from . import _capi
+from .learning_rate import BaseLearningRate, ConstantLearningRate
+from .linop import InverseInnovation
+from .nonlinearities import BaseNonLinearity, wrap_nonlinearity
+
+__all__ = ["PSMFIter", "PSMFIterMissing", "PSMFRecursive"]
+
+COMPUTE_HOOKS = (
+    "_predictive_mean", "_predictive_covariance", "_predict_measurement", "_compute_eta_k",
+    "_compute_dictionary_innovation", "_update_dictionary_mean", "_update_dictionary_covariance",
+    "_compute_inverse_coefficient_innovation", "_update_coefficient_mean",
+    "_update_coefficient_covariance", "_store_gradient",
+)
+
+HIP_MODES = {
+    # name: (coef_update, eta_full, pbar_predict)
+    "full": (True, True, True),
+    "simplified": (False, False, False),
+}
+
+
+class _Lazy:
+    """A value that lives on the device until somebody asks for it."""
+
+    def __init__(self, owner, name, epoch):
+        self.owner, self.name, self.epoch = owner, name, epoch
+
+    def fetch(self):
+        return self.owner._fetch_device(self.name, self.epoch)
+
+
+class _StateDict(dict):
+    """dict k -> array whose values may be device-resident (_Lazy) until first read."""
+
+    def __getitem__(self, k):
+        v = dict.__getitem__(self, k)
+        if isinstance(v, _Lazy):
+            v = v.fetch()
+            dict.__setitem__(self, k, v)
+        return v
+
+    def raw(self, k):
+        return dict.__getitem__(self, k)
+
+
+class _YPred(dict):
+    """`_y_pred[k]` -> (d, 1).  Steps 1..T are served from the device buffer (fetched once, whole)."""
+
+    def __init__(self, owner=None, T=0):
+        super().__init__()
+        self._owner, self._T, self._host = owner, T, None
+
+    def _block(self):
+        if self._host is None:
+            self._host = self._owner._dev.y_pred(0, self._T)
+        return self._host
+
+    def __missing__(self, k):
+        if self._owner is not None and 1 <= k <= self._T:
+            return self._block()[k - 1].reshape(-1, 1)
+        raise KeyError(k)
+
+    def __contains__(self, k):
+        return dict.__contains__(self, k) or (self._owner is not None and 1 <= k <= self._T)
+
+
+def _diag_of(R, d):
+    """diag(R) as scalar or (d,) vector, or None if R is a non-diagonal matrix."""
+    if np.ndim(R) == 0:
+        return float(R)
+    R = np.asarray(R)
+    if R.ndim == 1:
+        return R.astype(float)
+    if R.shape == (1, 1):
+        return float(R[0, 0])
+    dg = np.diagonal(R)
+    if np.count_nonzero(R) != np.count_nonzero(dg):
+        return None
+    return dg.astype(float)
+
+
+def _as_scalar_if_uniform(rho):
+    if np.ndim(rho) == 0:
+        return float(rho)
+    rho = np.asarray(rho)
+    return float(rho[0]) if np.all(rho == rho[0]) else None
+
+
+class PSMFIter:
+    """Iterative (epochs over a fixed series) PSMF.  See the module docstring."""
+
+    hip_mode = "full"
+    robust = False
+
+    def __init__(self, theta0, C0, V0, mu0, P0, Qs, Rs, nonlinearity, optim="adam", backend="hip",
+                 device=0, storage="f32", gram_refresh=0):
+        assert optim in ["adam", "sgd"]
+        if backend not in ("hip", "numpy"):
+            raise ValueError("backend must be 'hip' or 'numpy'")
+        self.optim = optim
+        self.backend = backend
+        self.theta0 = theta0
+        self.C0 = C0
+        self.V0 = V0
+        self.mu0 = mu0
+        self.P0 = P0
+        self._d, self._r = C0.shape
+        self.nonlinearity = nonlinearity
+        self._nl = wrap_nonlinearity(nonlinearity, np.asarray(theta0).size)
+        self._C = _StateDict()
+        self._P = _StateDict()
+        self._V = _StateDict()
+        self._mu = _StateDict()
+        self._Q = Qs
+        self._R = Rs
+        self._theta = {0: theta0}
+        self._y_pred = {}
+        self._gradsum = np.zeros(np.asarray(theta0).shape)
+        self._dev = None
+        self._dev_opts = dict(device=device, storage=storage, gram_refresh=gram_refresh)
+        self._dev_epoch = 0
+        self._series_key = None
+        if backend == "hip":
+            self._check_hip_configuration()
+
+    # ------------------------------------------------------------------ drive methods
+    def run(self, y, T, n_iter, n_pred):
+        self.optim_init()
+        for i in range(1, n_iter + 1):
+            self.step(y, i, T)
+            self.predict(i, T, n_pred)
+            self.optim_update(i)
+
+    def step_reset(self):
+        """Epoch start: carry the last C, mu, P, V (or the initial values); zero the gradient."""
+        def latest(D, init):
+            if not D:
+                return init
+            k = max(D.keys())
+            return D.raw(k) if isinstance(D, _StateDict) else D[k]
+
+        self._C = _StateDict({0: latest(self._C, self.C0)})
+        self._mu = _StateDict({0: latest(self._mu, self.mu0)})
+        self._P = _StateDict({0: latest(self._P, self.P0)})
+        self._V = _StateDict({0: latest(self._V, self.V0)})
+        self._gradsum = np.zeros(np.asarray(self.theta0).shape)
+
+    def step(self, y, i, T):
+        if self.backend == "hip":
+            return self._step_hip(y, i, T)
+        self.step_reset()
+        for k in range(1, T + 1):
+            self.inner(i, k, y[k])
+
+    def inner(self, i, k, yk):
+        mu_bar = self._predictive_mean(i, k)
+        P_bar = self._predictive_covariance(i, k)
+        self._y_pred[k] = self._predict_measurement(k, mu_bar)
+        eta_k = self._compute_eta_k(k, P_bar)
+        Nk = self._compute_dictionary_innovation(k, eta_k, mu_bar, P_bar)
+        self._update_dictionary_mean(k, yk, Nk, mu_bar)
+        self._update_dictionary_covariance(k, Nk, mu_bar, yk)
+        Skinv = self._compute_inverse_coefficient_innovation(k, mu_bar, P_bar)
+        self._update_coefficient_mean(k, yk, Skinv, mu_bar, P_bar)
+        self._update_coefficient_covariance(k, Skinv, P_bar, yk)
+        self._store_gradient(i, k, yk, eta_k)
+        self._prune(k)
+
+    # ------------------------------------------------------------------ hooks (numpy backend)
+    def _q_at(self, k):
+        return self._Q[k]
+
+    def _r_index(self, k):
+        return k
+
+    def _rho_at(self, k):
+        """diag(R_k) as (d,) vector; raises for a non-diagonal R (use the dense route)."""
+        dg = _diag_of(self._R[self._r_index(k)], self._d)
+        if dg is None:
+            return None
+        return np.full(self._d, dg) if np.ndim(dg) == 0 else dg
+
+    def _predictive_mean(self, i, k):
+        return self._nl(self._theta[i - 1], self._mu[k - 1], k)
+
+    def _predictive_covariance(self, i, k):
+        F = self._nl.jac_x(self._theta[i - 1], self._mu[k - 1], k)
+        return F @ self._P[k - 1] @ F.T + self._q_at(k)
+
+    def _predict_measurement(self, k, mu_bar):
+        return self._C[k - 1] @ mu_bar
+
+    def _compute_eta_k(self, k, P_bar):
+        C = self._C[k - 1]
+        rho = self._rho_at(k)
+        tr_R = np.trace(self._R[self._r_index(k)]) if rho is None else rho.sum()
+        return (tr_R + np.sum((C.T @ C) * P_bar)) / self._d
+
+    def _compute_dictionary_innovation(self, k, eta_k, mu_bar, P_bar):
+        return mu_bar.T @ self._V[k - 1] @ mu_bar + eta_k
+
+    def _update_dictionary_mean(self, k, yk, Nk, mu_bar):
+        w = self._V[k - 1] @ mu_bar
+        self._C[k] = self._C[k - 1] + (yk - self._y_pred[k]) @ w.T / Nk
+
+    def _update_dictionary_covariance(self, k, Nk, mu_bar, yk):
+        w = self._V[k - 1] @ mu_bar
+        self._V[k] = self._V[k - 1] - (w @ w.T) / Nk
+
+    def _compute_inverse_coefficient_innovation(self, k, mu_bar, P_bar):
+        C = self._C[k - 1]
+        s = float(np.squeeze(mu_bar.T @ self._V[k - 1] @ mu_bar))
+        rho = self._rho_at(k)
+        if rho is not None and (rho + s).sum() > 0:
+            w = 1.0 / (rho + s)
+            U = w[:, None] * C
+            K = np.linalg.inv(np.linalg.inv(P_bar) + C.T @ U)
+            return InverseInnovation(w, U, K)
+        Rbar = np.asarray(self._R[self._r_index(k)], dtype=float) + s * np.eye(self._d)
+        return np.linalg.inv(C @ P_bar @ C.T + Rbar)
+
+    def _update_coefficient_mean(self, k, yk, Skinv, mu_bar, P_bar):
+        self._mu[k] = mu_bar + P_bar @ (self._C[k - 1].T @ (Skinv @ (yk - self._y_pred[k])))
+
+    def _update_coefficient_covariance(self, k, Skinv, P_bar, yk):
+        C = self._C[k - 1]
+        self._P[k] = P_bar - P_bar @ (C.T @ (Skinv @ C)) @ P_bar
+
+    def _grad_f(self, k, yk, eta_k, mu_prev, theta):
+        """d(incremental likelihood)/d f at the pre-update state (closed form of psmf.py:57-64)."""
+        f = self._nl(theta, mu_prev, k)
+        C, V = self._C[k - 1], self._V[k - 1]
+        u = V @ f
+        N = float(np.squeeze(f.T @ u)) + float(np.squeeze(eta_k))
+        e = yk - C @ f
+        ee = float(np.squeeze(e.T @ e))
+        return self._d * u / N - (C.T @ e) / N - ee * u / N**2
+
+    def _store_gradient(self, i, k, yk, eta_k):
+        theta = self._theta[i - 1]
+        if np.asarray(theta).size == 0:
+            return
+        Jt = self._nl.jac_theta(theta, self._mu[k - 1], k)
+        g = Jt.T @ self._grad_f(k, yk, eta_k, self._mu[k - 1], theta)
+        self._gradsum = self._gradsum + g.reshape(self._gradsum.shape)
+
+    def _prune(self, k):
+        del self._C[k - 1], self._V[k - 1], self._mu[k - 1], self._P[k - 1]
+
+    def predict(self, i, T, n_pred):
+        if self.backend == "hip" and self._dev is not None and isinstance(self._y_pred, _YPred):
+            return self._predict_hip(i, T, n_pred)
+        self._mu_pred = {T: self._mu[T]}
+        for k in range(T + 1, T + n_pred + 1):
+            self._mu_pred[k] = self._nl(self._theta[i - 1], self._mu_pred[k - 1], k)
+            self._y_pred[k] = self._C[T] @ self._mu_pred[k]
+
+    # ------------------------------------------------------------------ optimiser (host, p-sized)
+    def adam_init(self, gam=1e-3, b1=0.9, b2=0.999):
+        self.adam_gam = gam if isinstance(gam, BaseLearningRate) else ConstantLearningRate(gam)
+        self.adam_b1, self.adam_b2 = b1, b2
+        shape = np.asarray(self.theta0).shape
+        self.adam_m, self.adam_v = np.zeros(shape), np.zeros(shape)
+        self.adam_m_hat, self.adam_v_hat = np.zeros(shape), np.zeros(shape)
+
+    def sgd_init(self, gam=1e-3):
+        self.sgd_gam = gam if isinstance(gam, BaseLearningRate) else ConstantLearningRate(gam)
+
+    def optim_init(self, gam=1e-3):
+        if self.optim == "adam":
+            self.adam_init(gam=gam)
+        else:
+            self.sgd_init(gam=gam)
+
+    def optim_update(self, i, project=True):
+        if self.optim == "adam":
+            return self.adam_update(i, project=project)
+        return self.sgd_update(i, project=project)
+
+    def adam_update(self, i, project=True):
+        g = self._gradsum
+        self.adam_m = self.adam_b1 * self.adam_m + (1 - self.adam_b1) * g
+        self.adam_v = self.adam_b2 * self.adam_v + (1 - self.adam_b2) * g * g
+        self.adam_m_hat = self.adam_m / (1 - self.adam_b1**i)
+        self.adam_v_hat = self.adam_v / (1 - self.adam_b2**i)
+        step = self.adam_gam.get(i) * self.adam_m_hat / (np.sqrt(self.adam_v_hat) + 1e-8)
+        self._theta[i] = self._theta[i - 1] - step
+        if project:
+            self._theta[i] = np.maximum(self._theta[i], 0)
+
+    def sgd_update(self, i, project=True):
+        self._theta[i] = self._theta[i - 1] - self.sgd_gam.get(i) * self._gradsum
+        if project:
+            self._theta[i] = np.maximum(self._theta[i], 0)
+
+    # ------------------------------------------------------------------ device back end
+    def _overridden_hooks(self):
+        base = rPSMF_BASE if self.robust else PSMFIter
+        return [h for h in COMPUTE_HOOKS if getattr(type(self), h) is not getattr(base, h)]
+
+    def _check_hip_configuration(self):
+        over = self._overridden_hooks()
+        declared = any("hip_mode" in vars(c) for c in type(self).__mro__ if c not in _BASE_CLASSES)
+        if over and not declared:
+            raise TypeError(
+                f"{type(self).__name__} overrides {over}: the device back end can only fuse recognised hook "
+                f"configurations.  Declare the class attribute hip_mode (one of {sorted(HIP_MODES)}) if the overrides "
+                "match one, or construct with backend='numpy'.")
+        if self.hip_mode not in HIP_MODES:
+            raise ValueError(f"unknown hip_mode {self.hip_mode!r}")
+        if self._nl.device_kind is None:
+            raise TypeError(
+                "the nonlinearity is not one the device evaluates (RandomWalk, CosPhase); wrap it in one of those "
+                "or construct with backend='numpy'")
+        if self._r > _capi.RMAX:
+            raise ValueError(f"r = {self._r} > {_capi.RMAX}")
+
+    def _uniform_scalar(self, D, what):
+        """The device path takes a constant, uniform-diagonal R and a constant Q."""
+        keys = sorted(D.keys()) if isinstance(D, dict) else None
+        vals = [D[k] for k in keys] if keys is not None else [D]
+        first = vals[0]
+        for v in vals[1:]:
+            if v is not first and not np.array_equal(np.asarray(v), np.asarray(first)):
+                raise NotImplementedError(f"time-varying {what} is only supported by backend='numpy'")
+        return first
+
+    def _device_rho_q(self):
+        R0 = self._uniform_scalar(self._R, "R")
+        dg = _diag_of(R0, self._d)
+        rho = None if dg is None else _as_scalar_if_uniform(dg)
+        if rho is None:
+            raise NotImplementedError("the device path needs R = rho * I (uniform diagonal); use backend='numpy'")
+        Q = np.asarray(self._uniform_scalar(self._Q, "Q"), dtype=float)
+        if Q.ndim == 0:
+            Q = float(Q) * np.eye(self._r)
+        return rho, Q
+
+    def _device_kwargs(self):
+        coef, eta_full, pbar = HIP_MODES[self.hip_mode]
+        return dict(robust=self.robust, coef_update=coef, eta_full=eta_full, pbar_predict=pbar,
+                    dyn_kind=self._nl.device_kind, **self._dev_opts)
+
+    def _ensure_device(self):
+        if self._dev is None:
+            self._dev = _capi.DeviceFilter(self._d, self._r, **self._device_kwargs())
+        return self._dev
+
+    def _fetch_device(self, name, epoch):
+        if epoch != self._dev_epoch:
+            raise RuntimeError(f"stale device reference to {name} (the device state has moved on)")
+        if name == "C":
+            return self._dev.get_state(want_C=True)["C"]
+        raise KeyError(name)
+
+    def _upload_series(self, y, T):
+        key = (id(y), T)
+        if self._series_key == key:
+            return
+        if isinstance(y, dict):
+            Y = np.concatenate([np.asarray(y[k]).reshape(1, -1) for k in range(1, T + 1)], axis=0)
+        else:
+            Y = np.asarray(y)[:T]
+        self._dev.upload_series(Y, t0=0, T_total=T)
+        self._series_key = key
+
+    def _push_state(self, i):
+        dev = self._dev
+        C0 = self._C.raw(0)
+        same_C = isinstance(C0, _Lazy) and C0.owner is self and C0.epoch == self._dev_epoch
+        rho, Q = self._device_rho_q()
+        theta = np.asarray(self._theta[i - 1], dtype=float).reshape(-1)
+        dev.set_state(None if same_C else np.asarray(C0, dtype=float), self._V[0], self._P[0], Q,
+                      np.asarray(self._mu[0]).reshape(-1), rho=rho, lambda0=self._device_lambda0(),
+                      theta=theta if theta.size else None)
+
+    def _device_lambda0(self):
+        return 0.0
+
+    def _pull_state(self, T):
+        s = self._dev.get_state(want_C=False)
+        self._dev_epoch += 1
+        ep = self._dev_epoch
+        self._C = _StateDict({T: _Lazy(self, "C", ep)})
+        self._V = _StateDict({T: s["V"]})
+        self._P = _StateDict({T: s["P"]})
+        self._mu = _StateDict({T: s["mu"].reshape(-1, 1)})
+        if s["gradsum"].size:
+            self._gradsum = s["gradsum"].reshape(np.asarray(self.theta0).shape)
+        self._y_pred = _YPred(self, T)
+        return s
+
+    def _step_hip(self, y, i, T):
+        self.step_reset()
+        self._ensure_device()
+        self._upload_series(y, T)
+        self._push_state(i)
+        self._dev.zero_gradsum()
+        self._dev.run(0, T)
+        self._after_device_epoch(self._pull_state(T), T)
+
+    def _after_device_epoch(self, s, T):
+        pass
+
+    def _predict_hip(self, i, T, n_pred):
+        out = self._dev.predict(T, n_pred)
+        for q in range(n_pred):
+            dict.__setitem__(self._y_pred, T + q + 1, out[q].reshape(-1, 1))
+
+    def sq_errors(self, T):
+        """sum_k ||y_hat_k - y_k||^2 over the filtered steps, reduced on the device
+        (what TrackingMixin.errors_update computes from `_y_pred` on the host)."""
+        return self._dev.sq_error(0, T)
+
+
+def _recursive_kwargs(obj, kw):
+    """Adds the in-loop Adam configuration (psmf.py:224-242,299-304) to the device options."""
+    if obj.optim != "adam":
+        raise NotImplementedError("the recursive device path implements Adam; use backend='numpy' for SGD")
+    gam = getattr(obj, "adam_gam", ConstantLearningRate(1e-3))
+    if isinstance(gam, ConstantLearningRate):
+        lr = dict(adam_lr=gam.lr)
+    elif hasattr(gam, "lr_start"):
+        lr = dict(adam_lr=gam.lr_start, adam_lr_end=gam.lr_end, adam_lr_steps=gam.steps)
+    else:
+        raise NotImplementedError("custom learning-rate schedules need backend='numpy'")
+    kw.update(recursive=True, update_every=getattr(obj, "_update_every", 1),
+              adam_b1=getattr(obj, "adam_b1", 0.9), adam_b2=getattr(obj, "adam_b2", 0.999), **lr)
+    return kw
+
+
+class PSMFIterMissing(PSMFIter):
+    def __init__(*args, **kwargs):
+        # unfinished in the reference as well (pypsmf/psmf/psmf.py:251-254); the working masked
+        # filter is rpsmf_amd.impute (ExperimentImpute semantics)
+        raise NotImplementedError
+
+
+class PSMFRecursive(PSMFIter):
+    """Online variant: theta takes an optimiser step inside the time loop every `update_every`
+    observations (pypsmf/psmf/psmf.py:275-331)."""
+
+    def run(self, y, T, n_pred, update_every=1):
+        self._update_every = update_every
+        self.optim_init()
+        self.step(y, T)
+        self.predict(T, n_pred)
+
+    def step(self, y, T):
+        if self.backend == "hip":
+            return self._step_hip_recursive(y, T)
+        self.step_reset()
+        for k in range(1, T + 1):
+            self.inner(k, y[k])
+
+    def inner(self, k, yk):
+        mu_bar = self._predictive_mean(k, k)
+        P_bar = self._predictive_covariance(k, k)
+        self._y_pred[k] = self._predict_measurement(k, mu_bar)
+        eta_k = self._compute_eta_k(k, P_bar)
+        Nk = self._compute_dictionary_innovation(k, eta_k, mu_bar, P_bar)
+        self._update_dictionary_mean(k, yk, Nk, mu_bar)
+        self._update_dictionary_covariance(k, Nk, mu_bar, yk)
+        Skinv = self._compute_inverse_coefficient_innovation(k, mu_bar, P_bar)
+        self._update_coefficient_mean(k, yk, Skinv, mu_bar, P_bar)
+        self._update_coefficient_covariance(k, Skinv, P_bar, yk)
+        self._store_gradient(k, k, yk, eta_k)
+        if k % self._update_every == 0:
+            self.optim_update(k)
+            self._reset_gradient()
+        else:
+            self._carry_theta(k)
+
+    def _reset_gradient(self):
+        self._gradsum = np.zeros(np.asarray(self.theta0).shape)
+
+    def _carry_theta(self, i):
+        self._theta[i] = self._theta[i - 1]
+
+    def _set_gradient(self, k, yk, eta_k):
+        self._reset_gradient()
+        self._store_gradient(k, k, yk, eta_k)
+
+    def predict(self, T, n_pred):
+        if self.backend == "hip" and self._dev is not None and isinstance(self._y_pred, _YPred):
+            return self._predict_hip(T, T, n_pred)
+        last_theta = self._theta[T]
+        self._mu_pred = {T: self._mu[T]}
+        for k in range(T + 1, T + n_pred + 1):
+            self._mu_pred[k] = self._nl(last_theta, self._mu_pred[k - 1], k)
+            self._y_pred[k] = self._C[T] @ self._mu_pred[k]
+
+    # device: Adam runs inside the serial stage of every step
+    def _device_kwargs(self):
+        return _recursive_kwargs(self, super()._device_kwargs())
+
+    def _step_hip_recursive(self, y, T):
+        self.step_reset()
+        self._ensure_device()
+        self._upload_series(y, T)
+        self._theta = {0: self._theta[0]}
+        self._push_state(1)
+        self._dev.zero_gradsum()
+        self._dev.set_adam(self.adam_m.reshape(-1), self.adam_v.reshape(-1))
+        self._dev.run(0, T)
+        s = self._pull_state(T)
+        self._theta[T] = s["theta"].reshape(np.asarray(self.theta0).shape)
+        self._after_device_epoch(s, T)
+
+
+rPSMF_BASE = PSMFIter          # rebound by rpsmf.py once rPSMFIter exists
+_BASE_CLASSES = [PSMFIter, PSMFRecursive, PSMFIterMissing, object]
