@@ -22,7 +22,7 @@ namespace {
 thread_local std::string g_create_error;
 
 struct Geometry {
-  int vec, nv, rp, gs, rpp, rpad;
+  int vec, nv, rp, gs, rpp, rpad, nt;
   int n_sweep_wg, rows_per_wg, ps;
   size_t sweep_lds;
 };
@@ -86,21 +86,31 @@ int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 typedef void (*sweep_fn_t)(StepParams);
 typedef void (*serial_fn_t)(StepParams, int);
 
-template <typename T>
+template <typename T, int NT>
 sweep_fn_t sweep_for_gs(int gs) {
   switch (gs) {
-    case 1: return psmf::psmf_sweep_solve<T, 1, kUnroll>;
-    case 2: return psmf::psmf_sweep_solve<T, 2, kUnroll>;
-    case 4: return psmf::psmf_sweep_solve<T, 4, kUnroll>;
-    case 8: return psmf::psmf_sweep_solve<T, 8, kUnroll>;
-    case 16: return psmf::psmf_sweep_solve<T, 16, kUnroll>;
-    case 32: return psmf::psmf_sweep_solve<T, 32, kUnroll>;
+    case 1: return psmf::psmf_sweep_solve<T, 1, kUnroll, NT>;
+    case 2: return psmf::psmf_sweep_solve<T, 2, kUnroll, NT>;
+    case 4: return psmf::psmf_sweep_solve<T, 4, kUnroll, NT>;
+    case 8: return psmf::psmf_sweep_solve<T, 8, kUnroll, NT>;
+    case 16: return psmf::psmf_sweep_solve<T, 16, kUnroll, NT>;
+    case 32: return psmf::psmf_sweep_solve<T, 32, kUnroll, NT>;
   }
   return nullptr;
 }
 
+// threads per sweep workgroup (tuning knob PSMF_SWEEP_THREADS=256|512): 512 halves the number of
+// per-workgroup partial rows the serial stage has to read at the same number of waves per CU
+int sweep_threads() {
+  static const int nt = [] { const char* e = getenv("PSMF_SWEEP_THREADS"); return (e && atoi(e) == 256) ? 256 : 512; }();
+  return nt;
+}
+
 sweep_fn_t sweep_kernel(const psmf_filter* h) {
-  return h->cfg.storage == PSMF_F64 ? sweep_for_gs<double>(h->geo.gs) : sweep_for_gs<float>(h->geo.gs);
+  const int gs = h->geo.gs;
+  if (h->geo.nt == 512)
+    return h->cfg.storage == PSMF_F64 ? sweep_for_gs<double, 512>(gs) : sweep_for_gs<float, 512>(gs);
+  return h->cfg.storage == PSMF_F64 ? sweep_for_gs<double, 256>(gs) : sweep_for_gs<float, 256>(gs);
 }
 
 serial_fn_t serial_kernel(const psmf_filter* h) {
@@ -114,7 +124,7 @@ serial_fn_t serial_kernel(const psmf_filter* h) {
 
 void launch_sweep(psmf_filter* h) {
   const int grid = h->geo.n_sweep_wg + (h->cfg.coef_update ? 1 : 0);
-  hipLaunchKernelGGL(sweep_kernel(h), dim3(grid), dim3(psmf::WG), h->geo.sweep_lds, h->stream, h->sp);
+  hipLaunchKernelGGL(sweep_kernel(h), dim3(grid), dim3(h->geo.nt), h->geo.sweep_lds, h->stream, h->sp);
 }
 
 void launch_serial(psmf_filter* h, int first) {
@@ -184,12 +194,13 @@ void compute_geometry(const psmf_config& c, Geometry& g) {
   g.nv = (c.r + g.vec - 1) / g.vec;
   g.rp = g.nv * g.vec;
   g.gs = next_pow2(g.nv);
-  g.rpp = psmf::WG / g.gs;
+  g.nt = sweep_threads();
+  g.rpp = g.nt / g.gs;
   g.rpad = next_pow2(c.r < 8 ? 8 : c.r);
   const size_t solve_lds = c.coef_update ? (size_t)(4 * psmf::RM + 2) * 8 : 0;
-  const size_t red_lds = (size_t)4 * (g.gs * g.vec + 1) * 8;
+  const size_t red_lds = (size_t)(g.nt / 64) * (g.gs * g.vec + 1) * 8;
   g.sweep_lds = ((solve_lds > red_lds ? solve_lds : red_lds) + 15) & ~(size_t)15;
-  int target = c.n_workgroups > 0 ? c.n_workgroups : 512;
+  int target = c.n_workgroups > 0 ? c.n_workgroups : (g.nt == 512 ? 256 : 512);
   int rows = (c.d_local + target - 1) / target;
   rows = ((rows + g.rpp - 1) / g.rpp) * g.rpp;
   if (rows < g.rpp) rows = g.rpp;

@@ -28,6 +28,13 @@
 
 namespace psmf {
 
+// In-kernel stamps for tools/serial_prof.hip (diagnostic builds define PSMF_SERIAL_STAMPS); no-ops in the product.
+#ifdef PSMF_SERIAL_STAMPS
+#define PSMF_STAMP(n) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(p.partials)[4096 + (n)] = t_; } while (0)
+#else
+#define PSMF_STAMP(n) do { } while (0)
+#endif
+
 template <typename T> struct VecOf;
 template <> struct VecOf<float> { typedef float __attribute__((ext_vector_type(4))) type; };
 template <> struct VecOf<double> { typedef double __attribute__((ext_vector_type(2))) type; };
@@ -39,24 +46,21 @@ __device__ __forceinline__ double wave_sum(double x) {
 }
 
 
-// fixed-order sum of base[w * ps] for w = first, first + step, ... < n, with 16 independent loads in
-// flight (a serial dependent-load loop would cost one L2 round trip per term)
+// fixed-order sum of base[w * ps] for w = first, first + step, ... < n, 16 independent loads in flight.
+// The loads are UNCONDITIONAL (index clamped, value masked afterwards): a load under a runtime
+// predicate makes hipcc branch around it and wait for it alone -- 16 dependent L2 round trips.
 __device__ __forceinline__ double strided_sum(const double* base, int first, int step, int n, int ps) {
-  double a[16];
+  double acc = 0.0;
+  for (int w0 = first; w0 < n; w0 += 16 * step) {
+    double v[16];
 #pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const int w = first + q * step;
-    a[q] = w < n ? base[(size_t)w * ps] : 0.0;
-  }
-  for (int w0 = first + 16 * step; w0 < n; w0 += 16 * step) {
+    for (int q = 0; q < 16; ++q) v[q] = base[(size_t)min(w0 + q * step, n - 1) * ps];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int w = w0 + q * step;
-      a[q] += w < n ? base[(size_t)w * ps] : 0.0;
-    }
+    for (int q = 0; q < 16; ++q) v[q] = (w0 + q * step < n) ? v[q] : 0.0;
+    acc += (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) +
+           (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
   }
-  return (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) +
-         (((a[8] + a[9]) + (a[10] + a[11])) + ((a[12] + a[13]) + (a[14] + a[15])));
+  return acc;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -211,10 +215,11 @@ __device__ __forceinline__ void solve_block(const StepParams& p, double* sm) {
 // owns one 16-byte vector of the row; a 256-thread workgroup covers 256/GS rows per pass and
 // keeps U passes of loads in flight.
 // ------------------------------------------------------------------------------------------
-template <typename T, int GS, int U>
-__global__ __launch_bounds__(WG) void psmf_sweep_solve(StepParams p) {
+template <typename T, int GS, int U, int NT>
+__global__ __launch_bounds__(NT) void psmf_sweep_solve(StepParams p) {
   constexpr int VEC = 16 / sizeof(T);
-  constexpr int RPP = WG / GS;
+  constexpr int RPP = NT / GS;
+  constexpr int NW = NT / 64;
   typedef typename VecOf<T>::type VT;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* sm = reinterpret_cast<double*>(smem_raw);
@@ -222,6 +227,7 @@ __global__ __launch_bounds__(WG) void psmf_sweep_solve(StepParams p) {
   // block 0 runs the r x r solve (dispatched first: it is the longest block)
   const int has_solve = p.coef_update;
   if (has_solve && blockIdx.x == 0) {
+    if (NT > WG && threadIdx.x >= WG) return;   // the solve uses 4 waves; surplus waves retire (barriers count live waves)
     solve_block(p, sm);
     return;
   }
@@ -250,21 +256,18 @@ __global__ __launch_bounds__(WG) void psmf_sweep_solve(StepParams p) {
   const int row_begin = wgid * p.rows_per_wg;
   const int row_end = min(row_begin + p.rows_per_wg, p.d_local);
   const bool lane_on = j < p.nv;
+  const int jl = lane_on ? j : 0;
 
   for (int base = row_begin; base < row_end; base += RPP * U) {
     VT cv[U];
     T yv[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const int row = base + u * RPP + g;
-      const bool ok = row < row_end;
-      if (ok && lane_on) {
-        cv[u] = *reinterpret_cast<const VT*>(C + (size_t)row * rp + j * VEC);
-      } else {
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) cv[u][v] = (T)0;
-      }
-      yv[u] = ok ? y[row] : (T)0;
+      // unconditional loads from a clamped (valid) row / lane: a load under a runtime predicate is
+      // branched around and waited for on its own; the value is masked below instead
+      const int row = min(base + u * RPP + g, row_end - 1);
+      cv[u] = *reinterpret_cast<const VT*>(C + (size_t)row * rp + jl * VEC);
+      yv[u] = y[row];
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -274,7 +277,7 @@ __global__ __launch_bounds__(WG) void psmf_sweep_solve(StepParams p) {
       double dot = 0.0;
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {
-        cd[v] = (double)cv[u][v];
+        cd[v] = (ok && lane_on) ? (double)cv[u][v] : 0.0;
         dot += cd[v] * mub[v];
       }
 #pragma unroll
@@ -311,7 +314,9 @@ __global__ __launch_bounds__(WG) void psmf_sweep_solve(StepParams p) {
   __syncthreads();
   double* out = p.partials + (size_t)wgid * p.ps;
   if (tid <= NE) {
-    const double s4 = (sm[tid] + sm[(NE + 1) + tid]) + (sm[2 * (NE + 1) + tid] + sm[3 * (NE + 1) + tid]);
+    double s4 = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s4 += sm[w * (NE + 1) + tid];   // fixed order
     if (tid < r) out[tid] = s4;
     if (tid == NE) out[r] = s4;
   }
@@ -328,8 +333,8 @@ __global__ __launch_bounds__(WG) void psmf_sweep_solve(StepParams p) {
 // barrier (the stage is latency-bound: what matters is the number of dependent round trips).
 // ------------------------------------------------------------------------------------------
 constexpr int SWG = 1024;
-// r > 32 keeps 4 x 16 matrix elements per worker thread in registers: 8 waves (256 VGPRs each) instead of 16
-__host__ __device__ constexpr int serial_threads(int rpad) { return rpad >= 64 ? 512 : SWG; }
+// r > 16: the worker threads keep 4 matrices x (4..16) elements in registers -- 8 waves (256 VGPRs each) instead of 16 (128: spills)
+__host__ __device__ constexpr int serial_threads(int rpad) { return rpad >= 32 ? 512 : SWG; }
 
 template <int RPAD>
 __device__ __forceinline__ void col_reduce(double partial, double* s_red, double* s_out) {
@@ -354,7 +359,7 @@ __device__ __forceinline__ double block_sum(double x, double* s4) {   // worker 
 }
 
 template <int RPAD>
-__global__ __launch_bounds__(serial_threads(RPAD)) void psmf_serial(StepParams p, int first) {
+__device__ __forceinline__ void serial_body(const StepParams& p, const int first) {
   constexpr int RG = WG / RPAD;
   constexpr int M = (RPAD * RPAD) / WG > 0 ? (RPAD * RPAD) / WG : 1;
   constexpr int NSEG = 32;
@@ -370,17 +375,18 @@ __global__ __launch_bounds__(serial_threads(RPAD)) void psmf_serial(StepParams p
   __shared__ double s_part[NSEG][RM + 1];
   __shared__ double s4[4];
 
+  PSMF_STAMP(0);
   // ---------------- every global load of the stage, issued up front ----------------
   const int ne = r + 1;
-  int nseg = serial_threads(RPAD) / ne;
+  int nseg = (int)blockDim.x / ne;
   if (nseg > NSEG) nseg = NSEG;
   const int pe = tid % ne, psg = tid / ne;
   double psum = 0.0;
   if (!first) {
     if (p.external_reduce) {
-      if (tid < ne) psum = st->red[tid];
-    } else if (tid < ne * nseg) {
-      psum = strided_sum(p.partials + pe, psg, nseg, p.n_sweep_wg, p.ps);
+      psum = st->red[min(tid, ne - 1)];
+    } else {
+      psum = strided_sum(p.partials + pe, min(psg, nseg - 1), nseg, p.n_sweep_wg, p.ps);
     }
   }
   double Vv[M], Pv[M], Gv[M], Qv[M];
@@ -393,10 +399,11 @@ __global__ __launch_bounds__(serial_threads(RPAD)) void psmf_serial(StepParams p
     val[m] = worker && (j < r) && (ii[m] < r);
     const int idx = val[m] ? ii[m] * r + j : 0;
     const int idt = val[m] ? j * r + ii[m] : 0;
-    Vv[m] = val[m] ? st->V[idx] : 0.0;
-    Gv[m] = val[m] ? st->G[idx] : 0.0;
-    Qv[m] = val[m] ? st->Q[idx] : 0.0;
-    Pv[m] = val[m] ? 0.5 * (psrc[idx] + psrc[idt]) : 0.0;
+    const double lv = st->V[idx], lg = st->G[idx], lq = st->Q[idx], lp = psrc[idx], lt = psrc[idt];   // unconditional
+    Vv[m] = val[m] ? lv : 0.0;
+    Gv[m] = val[m] ? lg : 0.0;
+    Qv[m] = val[m] ? lq : 0.0;
+    Pv[m] = val[m] ? 0.5 * (lp + lt) : 0.0;
   }
   double rho = st->rho, lam = st->lam;
   const double N0 = st->N, kappa0 = st->kappa, s0 = st->s, eta0 = st->eta;
@@ -404,15 +411,22 @@ __global__ __launch_bounds__(serial_threads(RPAD)) void psmf_serial(StepParams p
   long long knext = k0;             // index (0-based) of the step to prepare
   const bool vl = tid < r;
   const bool tl = tid < p.n_theta;
-  double mu_new = vl ? st->mu[tid] : 0.0;
+  const int tc = tid & (RM - 1);   // every r-sized array has RM entries: load unconditionally, mask afterwards
+  const double l_mu = st->mu[tc], l_w = st->w[tc], l_mub = st->mu_bar[tc], l_th = st->theta[tc], l_gs = st->gradsum[tc],
+               l_am = st->adam_m[tc], l_av = st->adam_v[tc];
+  double mu_new = vl ? l_mu : 0.0;
   const double mu_old = mu_new;
-  const double w_t = vl ? st->w[tid] : 0.0;
-  const double mub_t = vl ? st->mu_bar[tid] : 0.0;
-  double theta = tl ? st->theta[tid] : 0.0;
-  double gsum = tl ? st->gradsum[tid] : 0.0;
-  double am = (tl && p.recursive) ? st->adam_m[tid] : 0.0;
-  double av = (tl && p.recursive) ? st->adam_v[tid] : 0.0;
+  const double w_t = vl ? l_w : 0.0;
+  const double mub_t = vl ? l_mub : 0.0;
+  double theta = tl ? l_th : 0.0;
+  double gsum = tl ? l_gs : 0.0;
+  double am = tl ? l_am : 0.0;
+  double av = tl ? l_av : 0.0;
 
+  asm volatile("" :: "v"(psum), "v"(Vv[0]), "v"(Pv[0]));
+  PSMF_STAMP(1);
+  if (tid <= RM) s_he[tid] = 0.0;
+  if (tid < RM) { s_mub[tid] = 0.0; s_w[tid] = 0.0; }
   if (!first) {
     // ---- fixed-order reduction of the per-workgroup partials ----
     if (!p.external_reduce) {
@@ -420,8 +434,15 @@ __global__ __launch_bounds__(serial_threads(RPAD)) void psmf_serial(StepParams p
       __syncthreads();
       if (!worker) return;          // helper waves retire; later barriers count the 4 worker waves only
       if (tid < ne) {
-        double a = 0.0;
-        for (int sg = 0; sg < nseg; ++sg) a += s_part[sg][tid];
+        double a = 0.0;      // fixed order; 8 LDS reads in flight per batch, clamped rows, masked afterwards
+#pragma unroll
+        for (int b8 = 0; b8 < NSEG; b8 += 8) {
+          double v[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) v[q] = s_part[min(b8 + q, nseg - 1)][tid];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) a += (b8 + q < nseg) ? v[q] : 0.0;
+        }
         s_he[tid] = a;
       }
     } else {
@@ -433,6 +454,7 @@ __global__ __launch_bounds__(serial_threads(RPAD)) void psmf_serial(StepParams p
       s_mub[tid] = mub_t;
     }
     __syncthreads();
+    PSMF_STAMP(2);
     const double N = N0, kappa = kappa0;
     const double ee = s_he[r];
     const double wj = j < r ? s_w[j] : 0.0;
@@ -442,16 +464,18 @@ __global__ __launch_bounds__(serial_threads(RPAD)) void psmf_serial(StepParams p
     if (p.coef_update) {
       double part = 0.0;
 #pragma unroll
-      for (int m = 0; m < M; ++m) part += val[m] ? Pv[m] * (kappa * s_he[min(ii[m], r)]) : 0.0;
-      col_reduce<RPAD>(part, s_red, s_vec);   // s_vec = Pplus b
+      for (int m = 0; m < M; ++m) part += val[m] ? Pv[m] * s_he[min(ii[m], r)] : 0.0;
+      col_reduce<RPAD>(part, s_red, s_vec);   // s_vec = Pplus h
       double bPb = 0.0;
-      for (int l = 0; l < r; ++l) bPb += kappa * s_he[l] * s_vec[l];
-      quad -= bPb;
-      if (vl) mu_new = mub_t + s_vec[tid];
+#pragma unroll
+      for (int l = 0; l < RPAD; ++l) bPb += s_he[l] * s_vec[l];   // s_vec[l >= r] = 0
+      quad -= kappa * kappa * bPb;
+      if (vl) mu_new = mub_t + kappa * s_vec[tid];
     } else {
       if (vl) mu_new = mub_t;
     }
 
+    PSMF_STAMP(3);
     // ---- theta gradient at the pre-update state   psmf.py:48-66,167-177; rpsmf.py:53-73 ----
     if (tl && p.dyn_kind == 1) {
       const double tk = (double)(k0 + 1);
@@ -470,17 +494,19 @@ __global__ __launch_bounds__(serial_threads(RPAD)) void psmf_serial(StepParams p
 
     // ---- robust scalars   rpsmf.py:133-171 ----
     double vscale = 1.0, pscale = 1.0, qscale = 1.0, phi = 1.0, omega = 1.0;
+    const double invN = fast_rcp(N);
     if (p.robust) {
-      phi = (lam + ee / N) / (lam + dd);
-      omega = (lam + quad) / (lam + dd);
+      const double ild = fast_rcp(lam + dd);
+      phi = (lam + ee * invN) * ild;
+      omega = (lam + quad) * ild;
       vscale = p.alpha * phi;
       if (p.coef_update) { pscale = p.beta * omega; qscale = omega; }
       rho *= omega;
       if (!p.fixed_lambda) lam += dd;
     }
 
+    PSMF_STAMP(4);
     // ---- r x r elementwise updates (V, P, Q, tracked Gram) ----
-    const double invN = 1.0 / N;
 #pragma unroll
     for (int m = 0; m < M; ++m) {
       if (val[m]) {
@@ -532,6 +558,7 @@ __global__ __launch_bounds__(serial_threads(RPAD)) void psmf_serial(StepParams p
     if (!worker) return;
   }
 
+  PSMF_STAMP(5);
   // =============== everything the NEXT sweep / solve needs (step index knext + 1) ===========
   if (vl) {
     double mb = mu_new, f = 1.0;
@@ -555,22 +582,31 @@ __global__ __launch_bounds__(serial_threads(RPAD)) void psmf_serial(StepParams p
       gp += Gv[m] * pb;
     }
   }
+  PSMF_STAMP(6);
   col_reduce<RPAD>(part, s_red, s_vec);   // s_vec = V mu_bar
+  PSMF_STAMP(7);
   double s = 0.0;
-  for (int l = 0; l < r; ++l) s += s_mub[l] * s_vec[l];
+#pragma unroll
+  for (int l = 0; l < RPAD; ++l) s += s_mub[l] * s_vec[l];       // both are 0 beyond r
   double eta = rho;
   if (p.eta_full) eta += block_sum(gp, s4) / dd;   // (d rho + <G, Pbar>) / d   psmf.py:121-125
   const double N = s + eta;
   if (vl) {
     st->w[tid] = s_vec[tid];
-    st->wN[tid] = s_vec[tid] / N;
+    st->wN[tid] = s_vec[tid] * fast_rcp(N);
   }
   if (tid == 0) {
     st->s = s;
     st->eta = eta;
     st->N = N;
-    st->kappa = 1.0 / (rho + s);
+    st->kappa = fast_rcp(rho + s);
   }
+  PSMF_STAMP(8);
+}
+
+template <int RPAD>
+__global__ __launch_bounds__(serial_threads(RPAD)) void psmf_serial(StepParams p, int first) {
+  serial_body<RPAD>(p, first);
 }
 
 // local reduction of the per-workgroup partials into st->red (multi-GPU: input of the all-reduce)
