@@ -71,6 +71,9 @@ typedef struct {
   int32_t device;        /* HIP device ordinal                                                */
   int32_t use_graph;     /* 1: replay the per-step launches from a hipGraph                   */
   int32_t n_workgroups;  /* row-sweep workgroups, 0 = auto                                    */
+  int32_t engine;        /* 0 = auto, 1 = per-step engine (one row sweep per timestep),
+                            2 = exact time-blocked engine (one Gram Z^T Z per block of 64 - r steps,
+                            the steps in coefficient space; needs r <= 32, recursive = 0)       */
   double alpha, beta;    /* rPSMF scaling factors (rpsmf.py:45-51), 1.0 unless use_scaling     */
   double adam_lr, adam_lr_end, adam_lr_steps; /* lr (Constant) or lr_start/lr_end/steps
                             (ExponentialLearningRate, learning_rate.py:20-27; steps = 0 ->
@@ -132,11 +135,13 @@ int psmf_comm_init(psmf_handle h, int nranks, int rank, const void* unique_id);
 int psmf_run_timed(psmf_handle h, int64_t k_begin, int64_t k_end, float* ms);
 /* average duration (microseconds) of `iters` back-to-back launches of one kernel of the step
  * on the handle's stream, HIP-event timed: which = 0 row sweep (+ concurrent r x r solve),
- * 1 = serial r x r stage.  State is saved and restored around the measurement. */
+ * 1 = serial r x r stage.  Blocked engine: 0 = coefficient-space filter of one full block,
+ * 1 = block Gram (+ reduction), 2 = apply.  State is saved and restored around the measurement. */
 int psmf_time_kernel(psmf_handle h, int which, int iters, float* avg_us);
 /* geometry actually used: out[0] = sweep workgroups, out[1] = rows per workgroup,
- * out[2] = padded row length (elements), out[3] = lanes per row, out[4] = graph chunk steps */
-int psmf_geometry(psmf_handle h, int32_t* out5);
+ * out[2] = padded row length (elements), out[3] = lanes per row, out[4] = graph chunk steps,
+ * out[5] = engine in use (1 per-step, 2 blocked), out[6] = steps per block (blocked engine) */
+int psmf_geometry(psmf_handle h, int32_t* out7);
 
 /* ================= masked, batched small-d filter (ExperimentImpute) ==================== */
 typedef struct {

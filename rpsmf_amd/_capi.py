@@ -29,7 +29,7 @@ class PsmfConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "abi_version", "d", "r", "row0", "d_local", "robust", "coef_update", "eta_full", "pbar_predict",
         "fixed_lambda", "dyn_kind", "n_theta", "storage", "store_y_pred", "recursive", "update_every",
-        "gram_refresh", "device", "use_graph", "n_workgroups")] + [(n, C.c_double) for n in (
+        "gram_refresh", "device", "use_graph", "n_workgroups", "engine")] + [(n, C.c_double) for n in (
         "alpha", "beta", "adam_lr", "adam_lr_end", "adam_lr_steps", "adam_b1", "adam_b2")]
 
 
@@ -107,7 +107,7 @@ class DeviceFilter:
     def __init__(self, d, r, *, robust=False, coef_update=True, eta_full=True, pbar_predict=True,
                  fixed_lambda=False, dyn_kind=DYN_RANDOM_WALK, storage="f32", store_y_pred=True,
                  recursive=False, update_every=1, gram_refresh=0, device=0, use_graph=True,
-                 n_workgroups=0, alpha=1.0, beta=1.0, adam_lr=1e-3, adam_lr_end=0.0, adam_lr_steps=0.0,
+                 n_workgroups=0, engine="auto", alpha=1.0, beta=1.0, adam_lr=1e-3, adam_lr_end=0.0, adam_lr_steps=0.0,
                  adam_b1=0.9, adam_b2=0.999, row0=0, d_local=None):
         self._lib = load_library()
         self._h = C.c_void_p()
@@ -124,6 +124,7 @@ class DeviceFilter:
             n_theta=self.n_theta, storage=self.storage, store_y_pred=int(store_y_pred),
             recursive=int(recursive), update_every=int(update_every), gram_refresh=int(gram_refresh),
             device=int(device), use_graph=int(use_graph), n_workgroups=int(n_workgroups),
+            engine={"auto": 0, "step": 1, "block": 2}.get(engine, engine),
             alpha=float(alpha), beta=float(beta), adam_lr=float(adam_lr), adam_lr_end=float(adam_lr_end),
             adam_lr_steps=float(adam_lr_steps), adam_b1=float(adam_b1), adam_b2=float(adam_b2))
         rc = self._lib.psmf_create(C.byref(self._h), C.byref(cfg))
@@ -222,9 +223,10 @@ class DeviceFilter:
         return us.value
 
     def geometry(self):
-        g = (C.c_int32 * 5)()
+        g = (C.c_int32 * 7)()
         self._check(self._lib.psmf_geometry(self._h, g))
-        return dict(n_sweep_wg=g[0], rows_per_wg=g[1], row_stride=g[2], lanes_per_row=g[3], graph_chunk=g[4])
+        return dict(n_sweep_wg=g[0], rows_per_wg=g[1], row_stride=g[2], lanes_per_row=g[3], graph_chunk=g[4],
+                    engine={1: "step", 2: "block"}.get(g[5], g[5]), block_steps=g[6])
 
     def y_pred(self, t0, nt, dtype=np.float64):
         out = np.empty((nt, self.d_local), dtype=dtype)

@@ -3,6 +3,7 @@
 // per-step launches replayed over the series.  No torch, no hipBLAS: plain HIP + RCCL.
 #include "../../include/psmf_hip.h"
 #include "psmf_kernels.hip"
+#include "psmf_block.hip"
 
 #include <rccl/rccl.h>
 
@@ -43,6 +44,13 @@ struct psmf_filter {
   double* partials = nullptr;
   double* gpart = nullptr;
   double* scratch = nullptr;   // sq-error partials / predict staging
+  // blocked engine
+  int engine = 1;              // 1 per-step, 2 blocked
+  int block_steps = 0;         // B = RB - r
+  double* Kpart = nullptr;
+  double* Kmat = nullptr;
+  double* Acoef = nullptr;
+  double* Bcoef = nullptr;
   size_t scratch_bytes = 0;
   int64_t T_cap = 0;
   StepParams sp;
@@ -142,6 +150,51 @@ int enqueue_step(psmf_filter* h) {
   return PSMF_OK;
 }
 
+// one block of nb steps of the blocked engine: Gram, reduction, (all-reduce), coefficient-space filter, apply
+void fill_block_params(psmf_filter* h, psmf::BlockParams& b, int64_t k0, int nb) {
+  b.sp = h->sp;
+  b.Kpart = h->Kpart; b.K = h->Kmat; b.Acoef = h->Acoef; b.Bcoef = h->Bcoef;
+  b.k0 = k0; b.nb = nb;
+  b.gram_rows = (h->cfg.d_local + psmf::BLK_GRAM_WG - 1) / psmf::BLK_GRAM_WG;
+}
+
+void launch_blk_gram(psmf_filter* h, const psmf::BlockParams& b) {
+  if (h->cfg.storage == PSMF_F64)
+    hipLaunchKernelGGL(psmf::psmf_blk_gram<double>, dim3(psmf::BLK_GRAM_WG), dim3(psmf::WG), 0, h->stream, b);
+  else
+    hipLaunchKernelGGL(psmf::psmf_blk_gram<float>, dim3(psmf::BLK_GRAM_WG), dim3(psmf::WG), 0, h->stream, b);
+  hipLaunchKernelGGL(psmf::psmf_blk_reduce, dim3(psmf::RB * psmf::RB / 128), dim3(128), 0, h->stream, b);
+}
+
+void launch_blk_filter(psmf_filter* h, const psmf::BlockParams& b) {
+  const size_t lds = psmf::blk_filter_lds_bytes();
+  switch (h->geo.rpad) {
+    case 8: hipLaunchKernelGGL(psmf::psmf_blk_filter<8>, dim3(1), dim3(psmf::WG), lds, h->stream, b); break;
+    case 16: hipLaunchKernelGGL(psmf::psmf_blk_filter<16>, dim3(1), dim3(psmf::WG), lds, h->stream, b); break;
+    default: hipLaunchKernelGGL(psmf::psmf_blk_filter<32>, dim3(1), dim3(psmf::WG), lds, h->stream, b); break;
+  }
+}
+
+void launch_blk_apply(psmf_filter* h, const psmf::BlockParams& b) {
+  int grid = (h->cfg.d_local + psmf::WG - 1) / psmf::WG;
+  if (grid > 1024) grid = 1024;
+  if (h->cfg.storage == PSMF_F64)
+    hipLaunchKernelGGL(psmf::psmf_blk_apply<double>, dim3(grid), dim3(psmf::WG), 0, h->stream, b);
+  else
+    hipLaunchKernelGGL(psmf::psmf_blk_apply<float>, dim3(grid), dim3(psmf::WG), 0, h->stream, b);
+}
+
+int enqueue_block(psmf_filter* h, int64_t k0, int nb) {
+  psmf::BlockParams b;
+  fill_block_params(h, b, k0, nb);
+  launch_blk_gram(h, b);
+  if (h->use_coll)
+    NCCL_TRY(h, ncclAllReduce(h->Kmat, h->Kmat, psmf::RB * psmf::RB, ncclDouble, ncclSum, h->comm, h->stream));
+  launch_blk_filter(h, b);
+  launch_blk_apply(h, b);
+  return PSMF_OK;
+}
+
 int enqueue_gram(psmf_filter* h) {
   const int r = h->cfg.r;
   const int rows = (h->cfg.d_local + kGramWG - 1) / kGramWG;
@@ -229,6 +282,11 @@ int prepare(psmf_filter* h, int64_t k_begin) {
   HIP_TRY(h, hipMemcpyAsync(&h->st->k, &k, sizeof(k), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipMemcpyAsync(&h->st->err, &zero, sizeof(zero), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));   // the two sources above are stack variables
+  if (h->engine == 2) {   // the blocked engine derives everything it needs from the block Gram
+    h->need_prep = false;
+    h->k_done = k_begin;
+    return PSMF_OK;
+  }
   if (h->sp.track_g) {
     int rc = enqueue_gram(h);
     if (rc != PSMF_OK) return rc;
@@ -287,6 +345,26 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
   CREATE_TRY(hipMalloc(&h->C, (size_t)cfg->d_local * h->geo.rp * h->elem()));
   CREATE_TRY(hipMalloc((void**)&h->partials, (size_t)h->geo.n_sweep_wg * h->geo.ps * sizeof(double)));
   CREATE_TRY(hipMalloc((void**)&h->gpart, (size_t)kGramWG * cfg->r * cfg->r * sizeof(double)));
+  {
+    const bool can_block = cfg->r <= psmf::RM / 2 && !cfg->recursive;
+    if (cfg->engine == 2 && !can_block) { h->err = "psmf_create: the blocked engine needs r <= 32 and recursive = 0"; return bail(PSMF_ERR_ARG); }
+    if (cfg->engine < 0 || cfg->engine > 2) { h->err = "psmf_create: engine must be 0 (auto), 1 (per-step) or 2 (blocked)"; return bail(PSMF_ERR_ARG); }
+    // auto: blocked whenever it applies -- it is exact and removes the per-step launches and row sweeps
+    h->engine = cfg->engine == 0 ? (can_block ? 2 : 1) : cfg->engine;
+    if (const char* e = getenv("PSMF_ENGINE")) { const int v = atoi(e); if (v == 1 || (v == 2 && can_block)) h->engine = v; }
+  }
+  if (h->engine == 2) {
+    h->block_steps = psmf::RB - cfg->r;
+    CREATE_TRY(hipMalloc((void**)&h->Kpart, (size_t)psmf::BLK_GRAM_WG * psmf::RB * psmf::RB * sizeof(double)));
+    CREATE_TRY(hipMalloc((void**)&h->Kmat, (size_t)psmf::RB * psmf::RB * sizeof(double)));
+    CREATE_TRY(hipMalloc((void**)&h->Acoef, (size_t)psmf::RB * psmf::RM * sizeof(double)));
+    CREATE_TRY(hipMalloc((void**)&h->Bcoef, (size_t)psmf::RB * psmf::RB * sizeof(double)));
+    CREATE_TRY(hipMemset(h->Bcoef, 0, (size_t)psmf::RB * psmf::RB * sizeof(double)));
+    const size_t flds = psmf::blk_filter_lds_bytes();
+    CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_filter<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
+    CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_filter<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
+    CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_filter<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
+  }
   if (h->geo.sweep_lds > 48 * 1024)
     CREATE_TRY(hipFuncSetAttribute((const void*)sweep_kernel(h), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->geo.sweep_lds));
 #undef CREATE_TRY
@@ -323,6 +401,10 @@ void psmf_destroy(psmf_handle h) {
   if (h->YP) hipFree(h->YP);
   if (h->partials) hipFree(h->partials);
   if (h->gpart) hipFree(h->gpart);
+  if (h->Kpart) hipFree(h->Kpart);
+  if (h->Kmat) hipFree(h->Kmat);
+  if (h->Acoef) hipFree(h->Acoef);
+  if (h->Bcoef) hipFree(h->Bcoef);
   if (h->scratch) hipFree(h->scratch);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
@@ -478,6 +560,18 @@ int psmf_run(psmf_handle h, int64_t k_begin, int64_t k_end) {
     if (rc) return rc;
   }
   int64_t n = k_end - k_begin;
+  if (h->engine == 2) {
+    int64_t k = k_begin;
+    while (k < k_end) {
+      const int nb = (int)((k_end - k) < h->block_steps ? (k_end - k) : h->block_steps);
+      rc = enqueue_block(h, k, nb);
+      if (rc) return rc;
+      k += nb;
+    }
+    HIP_TRY(h, hipGetLastError());
+    h->k_done = k_end;
+    return PSMF_OK;
+  }
   const int64_t refresh = h->cfg.gram_refresh > 0 && h->sp.track_g ? h->cfg.gram_refresh : 0;
   while (n > 0) {
     int64_t seg = n;
@@ -546,10 +640,43 @@ int psmf_run_timed(psmf_handle h, int64_t k_begin, int64_t k_end, float* ms) {
 }
 
 int psmf_time_kernel(psmf_handle h, int which, int iters, float* avg_us) {
-  if (!h || !avg_us || iters < 1 || (which != 0 && which != 1)) return PSMF_ERR_ARG;
+  if (!h || !avg_us || iters < 1 || which < 0 || which > 2) return PSMF_ERR_ARG;
   if (!h->have_state || !h->Y) return fail(h, PSMF_ERR_STATE, "psmf_time_kernel: needs state and series");
   int rc = set_device(h);
   if (rc) return rc;
+  if (h->engine == 2) {
+    const int nb = (int)(h->T_cap < h->block_steps ? h->T_cap : h->block_steps);
+    psmf::BlockParams b;
+    fill_block_params(h, b, h->sp.series_t0, nb);
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const size_t cbytes = (size_t)h->cfg.d_local * h->geo.rp * h->elem();
+    void* Csave = nullptr; DevState* ssave = nullptr;
+    HIP_TRY(h, hipMalloc(&Csave, cbytes));
+    HIP_TRY(h, hipMalloc((void**)&ssave, sizeof(DevState)));
+    HIP_TRY(h, hipMemcpy(Csave, h->C, cbytes, hipMemcpyDeviceToDevice));
+    HIP_TRY(h, hipMemcpy(ssave, h->st, sizeof(DevState), hipMemcpyDeviceToDevice));
+    launch_blk_gram(h, b);           // a valid K for the filter / apply measurements
+    launch_blk_filter(h, b);
+    auto one = [&]() {
+      if (which == 0) { HIP_TRY(h, hipMemcpyAsync(h->st, ssave, sizeof(DevState), hipMemcpyDeviceToDevice, h->stream)); launch_blk_filter(h, b); }
+      else if (which == 1) launch_blk_gram(h, b);
+      else launch_blk_apply(h, b);
+      return (int)PSMF_OK;
+    };
+    for (int i = 0; i < 2; ++i) { rc = one(); if (rc) return rc; }
+    HIP_TRY(h, hipEventRecord(h->ev0, h->stream));
+    for (int i = 0; i < iters; ++i) { rc = one(); if (rc) return rc; }
+    HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
+    HIP_TRY(h, hipEventSynchronize(h->ev1));
+    float ms = 0.f;
+    HIP_TRY(h, hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    *avg_us = ms * 1000.f / iters;
+    HIP_TRY(h, hipMemcpy(h->C, Csave, cbytes, hipMemcpyDeviceToDevice));
+    HIP_TRY(h, hipMemcpy(h->st, ssave, sizeof(DevState), hipMemcpyDeviceToDevice));
+    HIP_TRY(h, hipFree(Csave));
+    HIP_TRY(h, hipFree(ssave));
+    return PSMF_OK;
+  }
   if (h->need_prep) { rc = prepare(h, h->k_done); if (rc) return rc; }
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   // save everything the kernels mutate
@@ -580,10 +707,10 @@ int psmf_time_kernel(psmf_handle h, int which, int iters, float* avg_us) {
   return PSMF_OK;
 }
 
-int psmf_geometry(psmf_handle h, int32_t* out5) {
-  if (!h || !out5) return PSMF_ERR_ARG;
-  out5[0] = h->geo.n_sweep_wg; out5[1] = h->geo.rows_per_wg; out5[2] = h->geo.rp; out5[3] = h->geo.gs;
-  out5[4] = h->chunk;
+int psmf_geometry(psmf_handle h, int32_t* out7) {
+  if (!h || !out7) return PSMF_ERR_ARG;
+  out7[0] = h->geo.n_sweep_wg; out7[1] = h->geo.rows_per_wg; out7[2] = h->geo.rp; out7[3] = h->geo.gs;
+  out7[4] = h->chunk; out7[5] = h->engine; out7[6] = h->block_steps;
   return PSMF_OK;
 }
 

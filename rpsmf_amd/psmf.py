@@ -119,7 +119,7 @@ class PSMFIter:
     robust = False
 
     def __init__(self, theta0, C0, V0, mu0, P0, Qs, Rs, nonlinearity, optim="adam", backend="hip",
-                 device=0, storage="f32", gram_refresh=0):
+                 device=0, storage="f32", gram_refresh=0, engine="auto"):
         assert optim in ["adam", "sgd"]
         if backend not in ("hip", "numpy"):
             raise ValueError("backend must be 'hip' or 'numpy'")
@@ -143,7 +143,7 @@ class PSMFIter:
         self._y_pred = {}
         self._gradsum = np.zeros(np.asarray(theta0).shape)
         self._dev = None
-        self._dev_opts = dict(device=device, storage=storage, gram_refresh=gram_refresh)
+        self._dev_opts = dict(device=device, storage=storage, gram_refresh=gram_refresh, engine=engine)
         self._dev_epoch = 0
         self._series_key = None
         if backend == "hip":

@@ -23,6 +23,12 @@ def _capi():
     return _capi
 
 
+@pytest.fixture(params=["step", "block"])
+def engine(request):
+    """Both device engines: one row sweep per timestep, and the exact time-blocked engine."""
+    return request.param
+
+
 def _mode_kwargs(mode):
     return dict(robust=mode.robust, coef_update=mode.coef_update, eta_full=mode.eta_full,
                 pbar_predict=mode.pbar_predict, fixed_lambda=mode.fixed_lambda, alpha=mode.alpha, beta=mode.beta)
@@ -39,14 +45,15 @@ def _compare(dev_state, st, tol, what=("C", "V", "mu", "P")):
 
 @pytest.mark.parametrize("storage", ["f64", "f32"])
 @pytest.mark.parametrize("name,robust", [("psmf_full_rw", False), ("rpsmf_full_rw", True)])
-def test_golden_full_filter(name, robust, storage):
+def test_golden_full_filter(name, robust, storage, engine):
     """PSMFIter / rPSMFIter as shipped (d=20, r=5, T=200, two epochs) against the reference's outputs."""
     c = _capi()
     g = load_golden(name)
     Y = g["Y"]
     T, d = Y.shape
     r = g["C0"].shape[1]
-    f = c.DeviceFilter(d, r, robust=robust, storage=storage)
+    f = c.DeviceFilter(d, r, robust=robust, storage=storage, engine=engine)
+    assert f.geometry()["engine"] == engine
     f.upload_series(Y)
     f.set_state(g["C0"], g["V0"], g["P0"], g["Q"], g["mu0"], rho=float(g["rho"]), lambda0=float(g["lambda0"]))
     tol = TOL[storage]
@@ -82,9 +89,11 @@ def _problem(d, r, T, seed, noise="normal"):
 @pytest.mark.parametrize("storage", ["f64", "f32"])
 @pytest.mark.parametrize("robust", [False, True])
 @pytest.mark.parametrize("d,r,T", [(3000, 20, 150), (777, 7, 60), (4096, 32, 80), (260, 64, 40), (50, 1, 30)])
-def test_full_filter_vs_oracle(d, r, T, robust, storage):
+def test_full_filter_vs_oracle(d, r, T, robust, storage, engine):
     """Full filter, random walk, ragged shapes (rows not a multiple of the tile, r not a multiple of 4)."""
     c = _capi()
+    if engine == "block" and r > 32:
+        pytest.skip("the blocked engine needs r <= 32")
     Y, C0 = _problem(d, r, T, 100 + d + r, "t" if robust else "normal")
     if storage == "f32":
         Y = Y.astype(np.float32).astype(np.float64)
@@ -93,7 +102,7 @@ def test_full_filter_vs_oracle(d, r, T, robust, storage):
     st = O.State(C=C0, V=V0, mu=np.zeros(r), P=P0, Q=Q, rho=1.0, lam=1.8)
     mode = O.Mode(robust=robust)
     st, Yp, _ = O.run_epoch(st, Y, mode, O.RandomWalkDyn())
-    f = c.DeviceFilter(d, r, storage=storage, **_mode_kwargs(mode))
+    f = c.DeviceFilter(d, r, storage=storage, engine=engine, **_mode_kwargs(mode))
     f.upload_series(Y)
     f.set_state(C0, V0, P0, Q, np.zeros(r), rho=1.0, lambda0=1.8)
     f.run(0, T)
@@ -112,7 +121,7 @@ def test_full_filter_vs_oracle(d, r, T, robust, storage):
 
 @pytest.mark.parametrize("storage", ["f64", "f32"])
 @pytest.mark.parametrize("robust", [False, True])
-def test_simplified_cos_mode(robust, storage):
+def test_simplified_cos_mode(robust, storage, engine):
     """ExperimentSynthetic configuration on the device: P = 0, eta = tr(R)/d, no coefficient update,
     cos dynamics with theta, closed-form theta gradient (synthetic_psmf.py:78-100)."""
     c = _capi()
@@ -121,7 +130,7 @@ def test_simplified_cos_mode(robust, storage):
     Y = g["Y_obs"][:T]
     d, r = g["C0"].shape
     mode = O.Mode(robust=robust, coef_update=False, eta_full=False, pbar_predict=False)
-    f = c.DeviceFilter(d, r, storage=storage, dyn_kind=c.DYN_COS_PHASE, **_mode_kwargs(mode))
+    f = c.DeviceFilter(d, r, storage=storage, dyn_kind=c.DYN_COS_PHASE, engine=engine, **_mode_kwargs(mode))
     f.upload_series(Y)
     f.set_state(g["C0"], g["V0"], g["P0"], np.zeros((r, r)), g["mu0"], rho=1.0, lambda0=1.8, theta=g["theta0"])
     f.zero_gradsum()
@@ -177,7 +186,7 @@ def test_graph_and_eager_agree_bitwise():
     Y, C0 = _problem(d, r, T, 5)
     outs = []
     for use_graph in (True, False):
-        f = c.DeviceFilter(d, r, storage="f32", use_graph=use_graph)
+        f = c.DeviceFilter(d, r, storage="f32", use_graph=use_graph, engine="step")
         f.upload_series(Y.astype(np.float32))
         f.set_state(C0, 0.1 * np.eye(r), np.eye(r), 0.1 * np.eye(r), np.zeros(r), rho=1.0, lambda0=0.0)
         f.run(0, T)
@@ -193,7 +202,7 @@ def test_gram_refresh_changes_nothing_material():
     Y, C0 = _problem(d, r, T, 9)
     res = []
     for refresh in (0, 64):
-        f = c.DeviceFilter(d, r, storage="f32", gram_refresh=refresh)
+        f = c.DeviceFilter(d, r, storage="f32", gram_refresh=refresh, engine="step")
         f.upload_series(Y.astype(np.float32))
         f.set_state(C0, 0.1 * np.eye(r), np.eye(r), 0.1 * np.eye(r), np.zeros(r), rho=1.0, lambda0=0.0)
         f.run(0, T)
@@ -203,13 +212,13 @@ def test_gram_refresh_changes_nothing_material():
         assert relerr(res[0][k], res[1][k]) < 1e-5  # fp32 storage: different rounding path, same bar
 
 
-def test_collective_path_single_rank_matches_plain():
+def test_collective_path_single_rank_matches_plain(engine):
     """The multi-GPU code path (local reduce kernel -> RCCL all-reduce of h, ee -> serial stage, all
     captured in the hipGraph) run with a one-rank communicator must equal the plain path."""
     c = _capi()
     d, r, T = 1500, 12, 40
     Y, C0 = _problem(d, r, T, 21)
-    full = c.DeviceFilter(d, r, storage="f64")
+    full = c.DeviceFilter(d, r, storage="f64", engine=engine)
     full.upload_series(Y)
     full.set_state(C0, 0.1 * np.eye(r), np.eye(r), 0.1 * np.eye(r), np.zeros(r), rho=1.0, lambda0=0.0)
     full.run(0, T)
@@ -220,7 +229,7 @@ def test_collective_path_single_rank_matches_plain():
 
     os.environ["PSMF_FORCE_COLLECTIVE"] = "1"
     try:
-        one = c.DeviceFilter(d, r, storage="f64")
+        one = c.DeviceFilter(d, r, storage="f64", engine=engine)
         one.comm_init(1, 0, c.DeviceFilter.comm_unique_id())
         one.upload_series(Y)
         one.set_state(C0, 0.1 * np.eye(r), np.eye(r), 0.1 * np.eye(r), np.zeros(r), rho=1.0, lambda0=0.0)
@@ -233,18 +242,42 @@ def test_collective_path_single_rank_matches_plain():
         assert relerr(s_one[k], s_full[k]) < 1e-12, k
 
 
-def test_singular_system_raises_linalgerror():
+def test_singular_system_raises_linalgerror(engine):
     """Non-finite state -> the r x r solve has no usable pivot -> LinAlgError, as numpy.linalg.inv would raise."""
     c = _capi()
     d, r, T = 64, 4, 3
     Y = np.zeros((T, d))
-    f = c.DeviceFilter(d, r, storage="f64")
+    f = c.DeviceFilter(d, r, storage="f64", engine=engine)
     f.upload_series(Y)
     P0 = np.full((r, r), np.nan)
     f.set_state(np.ones((d, r)), np.eye(r), P0, np.eye(r), np.zeros(r), rho=1.0, lambda0=0.0)
     with pytest.raises(np.linalg.LinAlgError):
         f.run(0, T)
     f.close()
+
+
+def test_engines_agree_and_auto_selects_blocked():
+    """The two engines are the same recursion: float64 storage -> agreement to round-off, long series
+    (several blocks + a ragged last one)."""
+    c = _capi()
+    d, r, T = 5000, 20, 200    # block length 64 - 20 = 44: 4 full blocks + 24
+    Y, C0 = _problem(d, r, T, 77)
+    out = {}
+    for eng in ("step", "block", "auto"):
+        f = c.DeviceFilter(d, r, storage="f64", robust=True, engine=eng)
+        f.upload_series(Y)
+        f.set_state(C0, 0.1 * np.eye(r), np.eye(r), 0.1 * np.eye(r), np.zeros(r), rho=1.0, lambda0=1.8)
+        f.run(0, T)
+        out[eng] = (f.get_state(), f.y_pred(0, T), f.geometry())
+        f.close()
+    assert out["auto"][2]["engine"] == "block" and out["block"][2]["block_steps"] == 44
+    for k in ("C", "V", "mu", "P", "rho"):
+        assert relerr(out["block"][0][k], out["step"][0][k]) < 1e-10, k
+    assert relerr(out["block"][1], out["step"][1]) < 1e-10
+    with pytest.raises(ValueError):
+        c.DeviceFilter(100, 40, engine="block")      # r > 32
+    with pytest.raises(ValueError):
+        c.DeviceFilter(100, 8, engine="block", recursive=True, dyn_kind=c.DYN_COS_PHASE)
 
 
 def test_argument_errors():
