@@ -15,11 +15,24 @@
 //   psmf_blk_apply<T>     C <- Z A_nb (rounded once), y_hat_j = Z b_j
 #pragma once
 #include "psmf_kernels.hip"
+#include "psmf_ns.hip"
 
 namespace psmf {
 
+// per-phase cycle accumulation for tools/blk_prof.hip (PSMF_BLK_STAMPS); no-ops in the product
+#ifdef PSMF_BLK_STAMPS
+#define BLK_T0() unsigned long long bt_[12] = {0,0,0,0,0,0,0,0,0,0,0,0}, bl_, bn_; { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(bl_) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#define BLK_T(n) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(bn_) :: "memory"); __builtin_amdgcn_sched_barrier(0); bt_[n] += bn_ - bl_; bl_ = bn_; }
+#define BLK_TOUT() if ((threadIdx.x & 63) == 0) for (int q_ = 0; q_ < 12; ++q_) reinterpret_cast<unsigned long long*>(b.Kpart)[(threadIdx.x >> 6) * 12 + q_] = bt_[q_];
+#else
+#define BLK_T0()
+#define BLK_T(n)
+#define BLK_TOUT()
+#endif
+
 constexpr int RB = 64;           // r + B, padded coefficient dimension (r <= 32)
-constexpr int BLK_GRAM_WG = 128; // workgroups (= partials) of the block Gram
+constexpr int RS = RM / 2 + 1;   // LDS row stride of the RB x r coefficient matrices (odd: lane = row reads are conflict-free)
+constexpr int BLK_GRAM_WG = 256; // workgroups (= partials) of the block Gram
 
 struct BlockParams {
   StepParams sp;
@@ -80,9 +93,139 @@ __global__ __launch_bounds__(WG) void psmf_blk_gram(BlockParams b) {
     for (int y = 0; y < 4; ++y) out[(4 * ta + x) * RB + 4 * tb + y] = acc[x][y];
 }
 
-__global__ __launch_bounds__(128) void psmf_blk_reduce(BlockParams b) {
+// ---- f64-MFMA versions of the two d-sized products of a block -------------------------------
+// K = Z^T Z with v_mfma_f64_16x16x4_f64: a tile of 32 rows of Z is staged in LDS as float64 (row
+// stride GZ_S = 80 doubles: the two rows a 32-lane group touches sit 32 banks apart -> conflict-free);
+// wave w accumulates the four 16 x 16 output tiles (w, 0..3) -- both operands are read with the same
+// (row k, column) pattern because A = Z^T.  One partial per workgroup, reduced in fixed order.
+constexpr int GZ_S = 80;
+constexpr int GZ_TR = 32;
+template <typename T>
+__global__ __launch_bounds__(WG) void psmf_blk_gram_mfma(BlockParams b) {
+  __shared__ double sZ[GZ_TR * GZ_S];
+  const StepParams& p = b.sp;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lk = lane >> 4;
+  const int r = p.r, rp = p.rp, dl = p.d_local, nb = b.nb;
+  const T* __restrict__ C = reinterpret_cast<const T*>(p.C);
+  const T* __restrict__ Y = reinterpret_cast<const T*>(p.Y) + (size_t)(b.k0 - p.series_t0) * dl;
+  f64x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+  // zero the never-written columns once (r + nb .. RB)
+  for (int idx = tid; idx < GZ_TR * RB; idx += WG) sZ[(idx / RB) * GZ_S + (idx % RB)] = 0.0;
+  const int row_begin = blockIdx.x * b.gram_rows;
+  const int row_end = min(row_begin + b.gram_rows, dl);
+  for (int base = row_begin; base < row_end; base += GZ_TR) {
+    __syncthreads();
+    // C part: thread = (row, column) with columns fastest (row-major C); clamped row, masked value
+    for (int idx = tid; idx < GZ_TR * r; idx += WG) {
+      const int rr = idx / r, c = idx - rr * r;
+      const double v = (double)C[(size_t)min(base + rr, row_end - 1) * rp + c];
+      sZ[rr * GZ_S + c] = (base + rr < row_end) ? v : 0.0;
+    }
+    // series part: rows fastest (Y is time-major)
+    for (int idx = tid; idx < GZ_TR * nb; idx += WG) {
+      const int q = idx / GZ_TR, rr = idx - q * GZ_TR;
+      const double v = (double)Y[(size_t)q * dl + min(base + rr, row_end - 1)];
+      sZ[rr * GZ_S + r + q] = (base + rr < row_end) ? v : 0.0;
+    }
+    __syncthreads();
+    double av[GZ_TR / 4], bv[4][GZ_TR / 4];
+#pragma unroll
+    for (int q = 0; q < GZ_TR / 4; ++q) {
+      av[q] = sZ[(4 * q + lk) * GZ_S + 16 * w + lr];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) bv[t][q] = sZ[(4 * q + lk) * GZ_S + 16 * t + lr];
+    }
+#pragma unroll
+    for (int q = 0; q < GZ_TR / 4; ++q)
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[t][q], acc[t], 0, 0, 0);
+  }
+  double* out = b.Kpart + (size_t)blockIdx.x * RB * RB;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) out[(16 * w + lk + 4 * q) * RB + 16 * t + lr] = acc[t][q];
+}
+
+// [C_new | Y_hat] = Z [A | Bc]  with f64 MFMA: one wave per slab of 16 rows (wave-private LDS image of
+// the slab, no workgroup barrier in the loop), the 64 x 64 coefficient matrix in LDS for all waves.
+constexpr int AP_S = 66;     // slab row stride (A operand: lanes = rows)
+template <typename T>
+__global__ __launch_bounds__(WG) void psmf_blk_apply_mfma(BlockParams b) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* sW = reinterpret_cast<double*>(smem_raw);     // RB x GZ_S: rows = coefficient index, cols [0,r) = A, [r, r+nb) = b_j
+  double* sZall = sW + RB * GZ_S;                      // 4 waves x 16 x AP_S
+  const StepParams& p = b.sp;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lk = lane >> 4;
+  const int r = p.r, rp = p.rp, dl = p.d_local, nb = b.nb;
+  for (int idx = tid; idx < RB * RB; idx += WG) {
+    const int m = idx / RB, c = idx - m * RB;
+    double v = 0.0;
+    if (c < r) v = b.Acoef[m * r + c];
+    else if (c < r + nb) v = b.Bcoef[(size_t)(c - r) * RB + m];
+    sW[m * GZ_S + c] = v;
+  }
+  double* sZ = sZall + w * 16 * AP_S;
+  for (int idx = lane; idx < 16 * AP_S; idx += 64) sZ[idx] = 0.0;
+  __syncthreads();
+  T* __restrict__ C = reinterpret_cast<T*>(p.C);
+  const T* __restrict__ Y = reinterpret_cast<const T*>(p.Y) + (size_t)(b.k0 - p.series_t0) * dl;
+  T* __restrict__ YP = p.store_yp ? reinterpret_cast<T*>(p.YP) + (size_t)(b.k0 - p.series_t0) * dl : nullptr;
+  const int nslab = (dl + 15) / 16;
+  for (int slab = blockIdx.x * 4 + w; slab < nslab; slab += gridDim.x * 4) {
+    const int row0 = slab * 16;
+    // stage the slab (wave-private): C part columns fastest, series part rows fastest
+    for (int idx = lane; idx < 16 * r; idx += 64) {
+      const int rr = idx / r, c = idx - rr * r;
+      sZ[rr * AP_S + c] = (double)C[(size_t)min(row0 + rr, dl - 1) * rp + c];
+    }
+    for (int idx = lane; idx < 16 * nb; idx += 64) {
+      const int q = idx >> 4, rr = idx & 15;
+      sZ[rr * AP_S + r + q] = (double)Y[(size_t)q * dl + min(row0 + rr, dl - 1)];
+    }
+    __builtin_amdgcn_s_waitcnt(0);          // wave-private LDS image complete (vmcnt, lgkmcnt = 0)
+    __builtin_amdgcn_wave_barrier();
+    f64x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      double av[8], bv[4][8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int k = 32 * half + 4 * q + lk;
+        av[q] = sZ[lr * AP_S + k];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) bv[t][q] = sW[k * GZ_S + 16 * t + lr];
+      }
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[t][q], acc[t], 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();         // the slab image may be overwritten by the next iteration
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int col = 16 * t + lr;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int row = row0 + lk + 4 * q;
+        if (row < dl) {
+          if (col < r) C[(size_t)row * rp + col] = (T)acc[t][q];
+          else if (col < r + nb && YP) YP[(size_t)(col - r) * dl + row] = (T)acc[t][q];
+        }
+      }
+    }
+  }
+}
+
+inline size_t blk_apply_lds_bytes() { return ((size_t)RB * GZ_S + 4 * 16 * AP_S) * 8; }
+
+__global__ __launch_bounds__(128) void psmf_blk_reduce(BlockParams b, int nparts) {
   const int e = blockIdx.x * 128 + threadIdx.x;   // RB*RB = 4096 = 32 x 128
-  b.K[e] = strided_sum(b.Kpart + e, 0, 1, BLK_GRAM_WG, RB * RB);
+  b.K[e] = strided_sum(b.Kpart + e, 0, 1, nparts, RB * RB);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -104,8 +247,8 @@ __global__ __launch_bounds__(WG) void psmf_blk_filter(BlockParams b) {
   // ---- LDS carve ----
   double* sK = sm;                    // RB x RB
   double* sA = sK + RB * RB;          // RB x r
-  double* sKA = sA + RB * RM / 2;     // RB x r   (r <= 32 = RM / 2)
-  double* s_red = sKA + RB * RM / 2;  // WG
+  double* sKA = sA + RB * RS;         // RB x r   (r <= 32 = RM / 2)
+  double* s_red = sKA + RB * RS;      // WG
   double* s_mub = s_red + WG;         // RM each below
   double* s_f = s_mub + RM;
   double* s_w = s_f + RM;
@@ -143,8 +286,8 @@ __global__ __launch_bounds__(WG) void psmf_blk_filter(BlockParams b) {
   // A_0 = [I; 0], K A_0 = first r columns of K, G_0 = K[0:r, 0:r] (exact Gram of the stored C)
   for (int idx = tid; idx < RB * r; idx += WG) {
     const int m = idx / r, c = idx - m * r;
-    sA[idx] = (m == c) ? 1.0 : 0.0;
-    sKA[idx] = sK[m * RB + c];
+    sA[m * RS + c] = (m == c) ? 1.0 : 0.0;
+    sKA[m * RS + c] = sK[m * RB + c];
   }
 #pragma unroll
   for (int m = 0; m < M; ++m) Gv[m] = val[m] ? sK[ii[m] * RB + j] : 0.0;
@@ -206,8 +349,8 @@ __global__ __launch_bounds__(WG) void psmf_blk_filter(BlockParams b) {
       double pb = 0.0, pk = 0.0;
       for (int c = c0; c < c1; ++c) {
         const double mu_c = s_mub[c];
-        pb += sA[mrow * r + c] * mu_c;
-        pk += sKA[mrow * r + c] * mu_c;
+        pb += sA[mrow * RS + c] * mu_c;
+        pk += sKA[mrow * RS + c] * mu_c;
       }
       s_p2[(qtr * RB + mrow) * 2] = pb;
       s_p2[(qtr * RB + mrow) * 2 + 1] = pk;
@@ -228,7 +371,7 @@ __global__ __launch_bounds__(WG) void psmf_blk_filter(BlockParams b) {
     {
       double ph = 0.0;
       if (j < r) {
-        for (int m = ig; m < RB; m += RG) ph += sA[m * r + j] * s_Ka[m];
+        for (int m = ig; m < RB; m += RG) ph += sA[m * RS + j] * s_Ka[m];
       }
       col_reduce<RPAD>(ph, s_red, s_h);
     }
@@ -288,11 +431,14 @@ __global__ __launch_bounds__(WG) void psmf_blk_filter(BlockParams b) {
         Qv[m] *= qscale;
       }
     }
-    for (int idx = tid; idx < RB * r; idx += WG) {
-      const int m = idx / r, c = idx - m * r;
-      const double wc = s_w[c] * invN;
-      sA[idx] += s_a[m] * wc;
-      sKA[idx] += s_Ka[m] * wc;
+    {   // thread = row m (lane) x column class: no integer division, conflict-free (odd row stride)
+      const int m = tid & (RB - 1);
+      const double am = s_a[m], km = s_Ka[m];
+      for (int c = tid >> 6; c < r; c += WG / RB) {
+        const double wc = s_w[c] * invN;
+        sA[m * RS + c] += am * wc;
+        sKA[m * RS + c] += km * wc;
+      }
     }
     __syncthreads();           // all reads of s_mu, s_w, s_h, s_a, s_Ka of this step are done
     if (tid < r) s_mu[tid] = mu_new;
@@ -301,7 +447,7 @@ __global__ __launch_bounds__(WG) void psmf_blk_filter(BlockParams b) {
   }
 
   // ---- block end: coefficients and state back to memory ----
-  for (int idx = tid; idx < RB * r; idx += WG) b.Acoef[idx] = sA[idx];
+  for (int idx = tid; idx < RB * r; idx += WG) { const int m = idx / r; b.Acoef[idx] = sA[m * RS + (idx - m * r)]; }
 #pragma unroll
   for (int m = 0; m < M; ++m) {
     if (val[m]) {
@@ -322,8 +468,355 @@ __global__ __launch_bounds__(WG) void psmf_blk_filter(BlockParams b) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Two-group variant for the common configuration (full filter, random-walk dynamics, Q = q I):
+// 512 threads; half X owns the r x r state machine, half Y owns the coefficient-space matrices.
+// The two r x r inversions of a step are made independent,
+//     P+_k      = M_k^-1,                       M_k = Lbar_k + kappa_k G_{k-1}      (half X)
+//     Lbar_{k+1} = Pbar_{k+1}^-1 = (1/omega_k) [ I/q - W_k / q^2 ],  W_k = (M_k / beta + I/q)^-1   (half Y)
+// (Woodbury on Pbar_{k+1} = omega_k (beta M_k^-1 + q I)), and run in lockstep sharing the barriers,
+// while the coefficient-space products of the step overlap with the r x r scalar work.
+// ------------------------------------------------------------------------------------------
+template <int RPAD>
+__global__ __launch_bounds__(2 * WG) void psmf_blk_filter2(BlockParams b) {
+  constexpr int RG = WG / RPAD;
+  constexpr int M = (RPAD * RPAD) / WG > 0 ? (RPAD * RPAD) / WG : 1;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* sm = reinterpret_cast<double*>(smem_raw);
+  const StepParams& p = b.sp;
+  DevState* st = p.st;
+  const int r = p.r, tid = threadIdx.x, lt = tid & (WG - 1), j = lt % RPAD, ig = lt / RPAD;
+  const bool X = tid < WG, Yg = !X;
+  const int lw = (tid >> 6) & 3;
+  const int r2 = r + (r & 1);
+  const double dd = (double)p.d;
+  // ---- LDS carve ----
+  double* sK = sm;                    // RB x RB
+  double* sA = sK + RB * RB;          // RB x r
+  double* sKA = sA + RB * RS;         // RB x r
+  double* sL = sKA + RB * RS;         // RPAD x RPAD: Lbar (precision of the predictive state), Y -> X
+  double* s_redX = sL + RM * RM / 4;  // WG
+  double* s_redY = s_redX + WG;       // WG
+  double* s_mub = s_redY + WG;        // RM each below
+  double* s_w = s_mub + RM;
+  double* s_h = s_w + RM;
+  double* s_vec = s_h + RM;
+  double* s_mu = s_vec + RM;
+  double* s_a = s_mu + RM;            // RB
+  double* s_Ka = s_a + RB;            // RB
+  double* s_p2 = s_Ka + RB;           // 4 x RB x 2
+  double* rowbufX = s_p2 + 8 * RB;    // 4 * RM
+  double* rowbufY = rowbufX + 4 * RM; // 4 * RM
+  double* s4X = rowbufY + 4 * RM;     // 4
+  double* s4Y = s4X + 4;              // 4
+  double* s_sc = s4Y + 4;             // 16 scalars: 0 kappa 1 N 2 invN 3 ee 4 omega 5 phi 6 vscale 7 pscale
+  double* s_nrm = s_sc + 16;          // 8: Newton-Schulz residual norms^2, [half][wave]
+  double* nsM = s_nrm + 8 + (X ? 0 : 3 * NS_N * NS_S);   // per half: matrix, iterate, residual (NS_N x NS_S each)
+  double* nsX = nsM + NS_N * NS_S;
+  double* nsR = nsX + NS_N * NS_S;
+  int* errflag = reinterpret_cast<int*>(s_nrm + 8 + 6 * NS_N * NS_S);
+  constexpr int NT = RPAD > 16 ? 32 : 16;      // Newton-Schulz tile size
+  const int nti = lw >> 1, ntj = lw & 1, lane = tid & 63;
+  const bool ns_wave = (NT == 32) || lw == 0;
+
+  for (int idx = tid; idx < RB * RB; idx += 2 * WG) sK[idx] = b.K[idx];
+  if (tid == 0) *errflag = 0;
+  for (int idx = lt; idx < NS_N * NS_S; idx += WG) {       // identity padding of the Newton-Schulz images
+    const int i = idx / NS_S, c = idx - i * NS_S;
+    nsM[idx] = (i == c) ? 1.0 : 0.0;
+    nsX[idx] = (i == c) ? 1.0 : 0.0;
+    nsR[idx] = 0.0;
+  }
+  if (tid < RM) { s_mub[tid] = 0.0; s_h[tid] = 0.0; s_w[tid] = 0.0; s_vec[tid] = 0.0; }
+  if (tid < r) s_mu[tid] = st->mu[tid];
+  double Vv[M], Pv[M], Gv[M], Lv[M];
+  bool val[M];
+  int ii[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    ii[m] = ig + m * RG;
+    val[m] = (j < r) && (ii[m] < r);
+    const int idx = val[m] ? ii[m] * r + j : 0;
+    const double lv = st->V[idx], lp = st->P[idx];
+    Vv[m] = val[m] ? lv : 0.0;
+    Pv[m] = val[m] ? lp : 0.0;
+    Lv[m] = 0.0;
+  }
+  double q = st->Q[0];                 // Q = q I (checked by the host)
+  double rho = st->rho, lam = st->lam;
+  __syncthreads();
+  for (int idx = tid; idx < RB * r; idx += 2 * WG) {
+    const int m = idx / r, c = idx - m * r;
+    sA[m * RS + c] = (m == c) ? 1.0 : 0.0;
+    sKA[m * RS + c] = sK[m * RB + c];
+  }
+#pragma unroll
+  for (int m = 0; m < M; ++m) Gv[m] = val[m] ? sK[ii[m] * RB + j] : 0.0;
+  // Lbar_1 = (P + q I)^-1: both halves run the same sweep in lockstep (one result is kept)
+  {
+    double A1[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) A1[m] = val[m] ? Pv[m] + (ii[m] == j ? q : 0.0) : ((ii[m] == j && j < r2) ? 1.0 : 0.0);
+    sweep_all<RPAD>(A1, r2, j, ig, X ? rowbufX : rowbufY, errflag);
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      Lv[m] = val[m] ? -A1[m] : 0.0;
+      if (Yg && val[m]) sL[ii[m] * RPAD + j] = Lv[m];
+    }
+  }
+  if (tid < r) s_mub[tid] = s_mu[tid];          // random walk: mu_bar_1 = mu_0
+  __syncthreads();
+
+  double s_last = 0.0, eta_last = 0.0, N_last = 0.0, phi = 1.0, omega = 1.0, ee_last = 0.0;
+  double Xp[M];                       // inverse found at the previous step (Newton-Schulz start)
+#pragma unroll
+  for (int m = 0; m < M; ++m) Xp[m] = 0.0;
+  BLK_T0();
+  for (int jb = 0; jb < b.nb; ++jb) {
+    // ---- P2: X: Pbar, partial w, <G, Pbar>;  Y: partial row dots of A mu_bar and KA mu_bar ----
+    double Pb[M];
+    if (X) {
+      double part = 0.0, gp = 0.0;
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        Pb[m] = val[m] ? Pv[m] + (ii[m] == j ? q : 0.0) : 0.0;
+        part += Vv[m] * s_mub[ii[m] & (RM - 1)];
+        gp += Gv[m] * Pb[m];
+      }
+      s_redX[lt] = part;
+      gp = wave_sum(gp);
+      if ((tid & 63) == 0) s4X[lw] = gp;
+    } else {
+      const int mrow = lt & (RB - 1), qtr = lt >> 6;
+      const int c0 = qtr * (RPAD / 4), c1 = min(c0 + RPAD / 4, r);
+      double pb = 0.0, pk = 0.0;
+      for (int c = c0; c < c1; ++c) {
+        const double mu_c = s_mub[c];
+        pb += sA[mrow * RS + c] * mu_c;
+        pk += sKA[mrow * RS + c] * mu_c;
+      }
+      s_p2[(qtr * RB + mrow) * 2] = pb;
+      s_p2[(qtr * RB + mrow) * 2 + 1] = pk;
+    }
+    BLK_T(0);
+    __syncthreads();
+    BLK_T(1);
+    // ---- P3: X: w;  Y: b, Ka, a ----
+    if (X) {
+      if (lt < RPAD) {
+        double a = 0.0;
+#pragma unroll
+        for (int gI = 0; gI < RG; ++gI) a += s_redX[gI * RPAD + lt];
+        s_w[lt] = a;
+      }
+    } else if (lt < RB) {
+      double bm = 0.0, km = 0.0;
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) { bm += s_p2[(qq * RB + lt) * 2]; km += s_p2[(qq * RB + lt) * 2 + 1]; }
+      s_a[lt] = (lt == r + jb ? 1.0 : 0.0) - bm;
+      s_Ka[lt] = sK[lt * RB + r + jb] - km;
+      b.Bcoef[(size_t)jb * RB + lt] = bm;
+    }
+    BLK_T(2);
+    __syncthreads();
+    BLK_T(1);
+    // ---- P4: X: s, eta, N, kappa;  Y: partial h, partial ee ----
+    double kappa = 0.0, N = 0.0, invN = 0.0, s = 0.0, eta = 0.0;
+    if (X) {
+#pragma unroll 8
+      for (int l = 0; l < RPAD; ++l) s += s_mub[l] * s_w[l];
+      eta = rho + ((s4X[0] + s4X[1]) + (s4X[2] + s4X[3])) / dd;
+      N = s + eta;
+      invN = fast_rcp(N);
+      kappa = fast_rcp(rho + s);
+      if (lt == 0) { s_sc[0] = kappa; s_sc[1] = N; s_sc[2] = invN; }
+    } else {
+      double ph = 0.0;
+      if (j < r)
+        for (int m = ig; m < RB; m += RG) ph += sA[m * RS + j] * s_Ka[m];
+      s_redY[lt] = ph;
+      double e1 = (lt < RB) ? s_a[lt] * s_Ka[lt] : 0.0;
+      e1 = wave_sum(e1);
+      if ((tid & 63) == 0) s4Y[lw] = e1;
+    }
+    BLK_T(3);
+    __syncthreads();
+    BLK_T(1);
+    // ---- P5: Y: h, ee (tiny) -- then both halves enter the lockstep inversion ----
+    if (Yg) {
+      if (lt < RPAD) {
+        double a = 0.0;
+#pragma unroll
+        for (int gI = 0; gI < RG; ++gI) a += s_redY[gI * RPAD + lt];
+        s_h[lt] = a;
+      }
+      if (lt == 0) s_sc[3] = (s4Y[0] + s4Y[1]) + (s4Y[2] + s4Y[3]);
+      kappa = s_sc[0];
+    }
+    BLK_T(4);
+    // ---- P6: M = Lbar + kappa G;  X: M^-1 = P+;  Y: (M / beta + I / q)^-1 = W ----
+    double R1[M];
+    {
+      const double ib = X ? 1.0 : 1.0 / p.beta;
+      const double dq = X ? 0.0 : 1.0 / q;
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        const double lb = X ? sL[(ii[m] & (RPAD - 1)) * RPAD + j] : Lv[m];
+        R1[m] = val[m] ? (lb + kappa * Gv[m]) * ib + (ii[m] == j ? dq : 0.0) : ((ii[m] == j && j < r2) ? 1.0 : 0.0);
+      }
+      // Newton-Schulz from the previous step's inverse on the f64 matrix cores; the symmetric sweep is
+      // the fallback (first step of the block, start too far, no convergence).  Control flow is uniform
+      // over the whole workgroup: both halves see both residual norms.
+      bool done = false;
+      if (jb > 0 && p.use_ns) {
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+          if (val[m]) {
+            nsM[ii[m] * NS_S + j] = R1[m];
+            nsX[ii[m] * NS_S + j] = Xp[m];
+          }
+        }
+        __syncthreads();
+        for (int it = 0; it < 8; ++it) {
+          double nr = ns_wave ? ns_residual<NT>(nsM, nsX, nsR, nti, ntj, lane) : 0.0;
+          const float nw = wave_sum_f32_dpp((float)nr);
+          if (lane == 0) s_nrm[tid >> 6] = (double)nw;
+          __syncthreads();
+          const double nx = (s_nrm[0] + s_nrm[1]) + (s_nrm[2] + s_nrm[3]);
+          const double ny = (s_nrm[4] + s_nrm[5]) + (s_nrm[6] + s_nrm[7]);
+          const double worst = fmax(nx, ny);
+          if (worst < 1e-24) { done = true; break; }             // ||I - M X||_F < 1e-12 on both halves
+          if (!(worst < 0.09) || it == 7) break;                   // too far (||R|| > 0.3) or not converging
+          f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+          if (ns_wave) acc = ns_update_tile<NT>(nsX, nsR, nti, ntj, lane);
+          __syncthreads();                                         // every wave has read the old X and R
+          if (ns_wave) ns_store_tile(nsX, acc, nti, ntj, lane);
+          __syncthreads();
+        }
+        if (done) {
+#pragma unroll
+          for (int m = 0; m < M; ++m)
+            R1[m] = val[m] ? 0.5 * (nsX[ii[m] * NS_S + j] + nsX[j * NS_S + ii[m]]) : 0.0;
+        }
+      }
+      if (!done) {
+        sweep_all<RPAD>(R1, r2, j, ig, X ? rowbufX : rowbufY, errflag);    // R1 <- -(.)^-1; barriers shared by both halves
+#pragma unroll
+        for (int m = 0; m < M; ++m) R1[m] = val[m] ? -R1[m] : 0.0;
+      }
+#pragma unroll
+      for (int m = 0; m < M; ++m) Xp[m] = R1[m];
+    }
+    // ---- P7: X: partial P+ h ----
+    if (X) {
+      double pt = 0.0;
+#pragma unroll
+      for (int m = 0; m < M; ++m) pt += R1[m] * s_h[ii[m] & (RM - 1)];
+      s_redX[lt] = pt;
+    }
+    __syncthreads();
+    if (X && lt < RPAD) {
+      double a = 0.0;
+#pragma unroll
+      for (int gI = 0; gI < RG; ++gI) a += s_redX[gI * RPAD + lt];
+      s_vec[lt] = a;
+    }
+    __syncthreads();
+    BLK_T(6);
+    // ---- P8: X: mu, omega, phi ----
+    const double ee = s_sc[3];
+    double mu_new = 0.0;
+    if (X) {
+      double hPh = 0.0;
+#pragma unroll 8
+      for (int l = 0; l < RPAD; ++l) hPh += s_h[l] * s_vec[l];
+      const double quad = kappa * ee - kappa * kappa * hPh;
+      if (lt < r) mu_new = s_mub[lt] + kappa * s_vec[lt];
+      double om = 1.0, ph = 1.0;
+      if (p.robust) {
+        const double ild = fast_rcp(lam + dd);
+        ph = (lam + ee * invN) * ild;
+        om = (lam + quad) * ild;
+      }
+      if (lt == 0) { s_sc[4] = om; s_sc[5] = ph; }
+    }
+    __syncthreads();
+    BLK_T(7);
+    // ---- P9: X: V, P, G;  Y: G, Lbar, A, KA ----
+    omega = s_sc[4];
+    phi = s_sc[5];
+    invN = s_sc[2];
+    {
+      const double wj = s_w[j & (RM - 1)], hj = s_h[j & (RM - 1)];
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        if (val[m]) {
+          const double wi = s_w[ii[m]], hi = s_h[ii[m]];
+          Gv[m] += (hi * wj + wi * hj) * invN + ee * (wi * wj) * (invN * invN);
+          if (X) {
+            Vv[m] = (p.robust ? p.alpha * phi : 1.0) * (Vv[m] - wi * wj * invN);
+            Pv[m] = (p.robust ? p.beta * omega : 1.0) * R1[m];
+          } else {
+            // Lbar_{k+1} = (1/omega) (I/q - W/q^2)
+            Lv[m] = ((ii[m] == j ? 1.0 / q : 0.0) - R1[m] / (q * q)) / omega;
+            sL[ii[m] * RPAD + j] = Lv[m];
+          }
+        }
+      }
+    }
+    if (Yg) {   // thread = row m (lane) x column class: no integer division, conflict-free (odd row stride)
+      const int m = lt & (RB - 1);
+      const double am = s_a[m], km = s_Ka[m];
+      for (int c = lt >> 6; c < r; c += WG / RB) {
+        const double wc = s_w[c] * invN;
+        sA[m * RS + c] += am * wc;
+        sKA[m * RS + c] += km * wc;
+      }
+    }
+    if (p.robust) {
+      q *= omega;
+      rho *= omega;
+      if (!p.fixed_lambda) lam += dd;
+    }
+    s_last = s; eta_last = eta; N_last = s_sc[1]; ee_last = ee;
+    BLK_T(8);
+    __syncthreads();                       // every read of s_mub, s_w, s_h, s_a, s_Ka of this step is done
+    if (X && lt < r) { s_mu[lt] = mu_new; s_mub[lt] = mu_new; }   // random walk: mu_bar_{k+1} = mu_k
+    __syncthreads();
+    BLK_T(9);
+  }
+  BLK_TOUT();
+
+  // ---- block end ----
+  for (int idx = tid; idx < RB * r; idx += 2 * WG) { const int m = idx / r; b.Acoef[idx] = sA[m * RS + (idx - m * r)]; }
+  if (X) {
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      if (val[m]) {
+        const int idx = ii[m] * r + j;
+        st->V[idx] = Vv[m];
+        st->P[idx] = Pv[m];
+        st->G[idx] = Gv[m];
+        st->Q[idx] = (ii[m] == j) ? q : 0.0;
+      }
+    }
+    if (lt < r) st->mu[lt] = s_mu[lt];
+    if (lt == 0) {
+      st->k = b.k0 + b.nb;
+      st->rho = rho; st->lam = lam; st->phi = phi; st->omega = omega; st->ee = ee_last;
+      st->s_done = s_last; st->eta_done = eta_last; st->N_done = N_last;
+      if (*errflag && st->err == 0) st->err = (int)(b.k0 + 1);
+    }
+  }
+}
+
+inline size_t blk_filter2_lds_bytes() {
+  const size_t doubles = (size_t)RB * RB + 2 * (size_t)RB * RS + RM * RM / 4 + 2 * WG + 5 * RM + 2 * RB + 8 * RB + 8 * RM + 8 + 16 + 8 + 6 * (size_t)NS_N * NS_S + 2;
+  return (doubles * 8 + 15) & ~(size_t)15;
+}
+
 inline size_t blk_filter_lds_bytes() {
-  const size_t doubles = (size_t)RB * RB + 2 * (size_t)RB * RM / 2 + WG + 6 * RM + 2 * RB + 8 * RB + 4 * RM + 4 + 2;
+  const size_t doubles = (size_t)RB * RB + 2 * (size_t)RB * RS + WG + 6 * RM + 2 * RB + 8 * RB + 4 * RM + 4 + 2;
   return (doubles * 8 + 15) & ~(size_t)15;
 }
 

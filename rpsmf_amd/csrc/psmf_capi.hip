@@ -47,6 +47,7 @@ struct psmf_filter {
   // blocked engine
   int engine = 1;              // 1 per-step, 2 blocked
   int block_steps = 0;         // B = RB - r
+  bool q_iso = false;          // Q = q I with q > 0 as last uploaded (two-group block filter applies)
   double* Kpart = nullptr;
   double* Kmat = nullptr;
   double* Acoef = nullptr;
@@ -158,15 +159,41 @@ void fill_block_params(psmf_filter* h, psmf::BlockParams& b, int64_t k0, int nb)
   b.gram_rows = (h->cfg.d_local + psmf::BLK_GRAM_WG - 1) / psmf::BLK_GRAM_WG;
 }
 
+bool blk_use_mfma() {
+  static const bool off = getenv("PSMF_BLOCK_MFMA") && atoi(getenv("PSMF_BLOCK_MFMA")) == 0;
+  return !off;
+}
+
 void launch_blk_gram(psmf_filter* h, const psmf::BlockParams& b) {
-  if (h->cfg.storage == PSMF_F64)
+  if (blk_use_mfma()) {
+    if (h->cfg.storage == PSMF_F64)
+      hipLaunchKernelGGL(psmf::psmf_blk_gram_mfma<double>, dim3(psmf::BLK_GRAM_WG), dim3(psmf::WG), 0, h->stream, b);
+    else
+      hipLaunchKernelGGL(psmf::psmf_blk_gram_mfma<float>, dim3(psmf::BLK_GRAM_WG), dim3(psmf::WG), 0, h->stream, b);
+  } else if (h->cfg.storage == PSMF_F64) {
     hipLaunchKernelGGL(psmf::psmf_blk_gram<double>, dim3(psmf::BLK_GRAM_WG), dim3(psmf::WG), 0, h->stream, b);
-  else
+  } else {
     hipLaunchKernelGGL(psmf::psmf_blk_gram<float>, dim3(psmf::BLK_GRAM_WG), dim3(psmf::WG), 0, h->stream, b);
-  hipLaunchKernelGGL(psmf::psmf_blk_reduce, dim3(psmf::RB * psmf::RB / 128), dim3(128), 0, h->stream, b);
+  }
+  hipLaunchKernelGGL(psmf::psmf_blk_reduce, dim3(psmf::RB * psmf::RB / 128), dim3(128), 0, h->stream, b, (int)psmf::BLK_GRAM_WG);
+}
+
+bool blk_dual_ok(const psmf_filter* h) {
+  static const bool off = getenv("PSMF_BLOCK_DUAL") && atoi(getenv("PSMF_BLOCK_DUAL")) == 0;
+  return !off && h->q_iso && h->cfg.coef_update && h->cfg.pbar_predict && h->cfg.eta_full &&
+         h->cfg.dyn_kind == PSMF_DYN_RANDOM_WALK;
 }
 
 void launch_blk_filter(psmf_filter* h, const psmf::BlockParams& b) {
+  if (blk_dual_ok(h)) {
+    const size_t lds2 = psmf::blk_filter2_lds_bytes();
+    switch (h->geo.rpad) {
+      case 8: hipLaunchKernelGGL(psmf::psmf_blk_filter2<8>, dim3(1), dim3(2 * psmf::WG), lds2, h->stream, b); break;
+      case 16: hipLaunchKernelGGL(psmf::psmf_blk_filter2<16>, dim3(1), dim3(2 * psmf::WG), lds2, h->stream, b); break;
+      default: hipLaunchKernelGGL(psmf::psmf_blk_filter2<32>, dim3(1), dim3(2 * psmf::WG), lds2, h->stream, b); break;
+    }
+    return;
+  }
   const size_t lds = psmf::blk_filter_lds_bytes();
   switch (h->geo.rpad) {
     case 8: hipLaunchKernelGGL(psmf::psmf_blk_filter<8>, dim3(1), dim3(psmf::WG), lds, h->stream, b); break;
@@ -176,6 +203,17 @@ void launch_blk_filter(psmf_filter* h, const psmf::BlockParams& b) {
 }
 
 void launch_blk_apply(psmf_filter* h, const psmf::BlockParams& b) {
+  if (blk_use_mfma()) {
+    const int nslab = (h->cfg.d_local + 15) / 16;
+    int g = (nslab + 3) / 4;
+    if (g > 1024) g = 1024;
+    const size_t lds = psmf::blk_apply_lds_bytes();
+    if (h->cfg.storage == PSMF_F64)
+      hipLaunchKernelGGL(psmf::psmf_blk_apply_mfma<double>, dim3(g), dim3(psmf::WG), lds, h->stream, b);
+    else
+      hipLaunchKernelGGL(psmf::psmf_blk_apply_mfma<float>, dim3(g), dim3(psmf::WG), lds, h->stream, b);
+    return;
+  }
   int grid = (h->cfg.d_local + psmf::WG - 1) / psmf::WG;
   if (grid > 1024) grid = 1024;
   if (h->cfg.storage == PSMF_F64)
@@ -364,6 +402,13 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_filter<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_filter<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_filter<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
+    const size_t alds = psmf::blk_apply_lds_bytes();
+    CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_apply_mfma<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)alds));
+    CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_apply_mfma<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)alds));
+    const size_t flds2 = psmf::blk_filter2_lds_bytes();
+    CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_filter2<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds2));
+    CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_filter2<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds2));
+    CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_filter2<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds2));
   }
   if (h->geo.sweep_lds > 48 * 1024)
     CREATE_TRY(hipFuncSetAttribute((const void*)sweep_kernel(h), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->geo.sweep_lds));
@@ -382,6 +427,7 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
   sp.recursive = cfg->recursive; sp.update_every = cfg->update_every > 0 ? cfg->update_every : 1;
   sp.track_g = (cfg->eta_full || cfg->coef_update) ? 1 : 0;
   sp.external_reduce = 0;
+  sp.use_ns = (getenv("PSMF_NS") && atoi(getenv("PSMF_NS")) == 0) ? 0 : 1;
   sp.alpha = cfg->alpha; sp.beta = cfg->beta;
   sp.lr = cfg->adam_lr; sp.lr_end = cfg->adam_lr_end; sp.lr_steps = cfg->adam_lr_steps;
   sp.b1 = cfg->adam_b1; sp.b2 = cfg->adam_b2;
@@ -433,7 +479,14 @@ int psmf_set_state(psmf_handle h, const double* C, const double* V, const double
   const size_t rr = (size_t)r * r * sizeof(double);
   if (V) HIP_TRY(h, hipMemcpy(h->st->V, V, rr, hipMemcpyHostToDevice));
   if (P) HIP_TRY(h, hipMemcpy(h->st->P, P, rr, hipMemcpyHostToDevice));
-  if (Q) HIP_TRY(h, hipMemcpy(h->st->Q, Q, rr, hipMemcpyHostToDevice));
+  if (Q) {
+    HIP_TRY(h, hipMemcpy(h->st->Q, Q, rr, hipMemcpyHostToDevice));
+    bool iso = Q[0] > 0.0;
+    for (int i = 0; i < r && iso; ++i)
+      for (int c = 0; c < r; ++c)
+        if (Q[i * r + c] != (i == c ? Q[0] : 0.0)) { iso = false; break; }
+    h->q_iso = iso;
+  }
   if (mu) HIP_TRY(h, hipMemcpy(h->st->mu, mu, r * sizeof(double), hipMemcpyHostToDevice));
   if (theta && h->cfg.n_theta > 0)
     HIP_TRY(h, hipMemcpy(h->st->theta, theta, h->cfg.n_theta * sizeof(double), hipMemcpyHostToDevice));

@@ -45,6 +45,7 @@ struct StepParams {
   int robust, coef_update, eta_full, pbar_predict, fixed_lambda;
   int dyn_kind, n_theta, store_yp, recursive, update_every, track_g;
   int external_reduce;  // 1: partial sums were reduced into st->red (multi-GPU)
+  int use_ns;           // 1: Newton-Schulz refinement of the r x r inverses (f64 MFMA), sweep as fallback
   double alpha, beta, lr, lr_end, lr_steps, b1, b2;
 };
 

@@ -84,6 +84,8 @@ __device__ __forceinline__ double fast_rcp(double d) {
 template <int RPAD>
 __device__ __forceinline__ void sweep_all(double (&A)[(RPAD * RPAD) / WG > 0 ? (RPAD * RPAD) / WG : 1], const int r2,
                                           const int c, const int rg, double* rowbuf, int* errflag) {
+  // (a 512-thread workgroup may run two independent sweeps in lockstep, one per 256-thread half, each
+  //  with its own rowbuf: the wave id is taken modulo 4 and the barriers are shared)
   constexpr int RG = WG / RPAD;                 // row groups; wave w holds row groups [w*RGW, (w+1)*RGW)
   constexpr int RGW = RG / 4 > 0 ? RG / 4 : 1;  // (RPAD = 64: one row group per wave)
   constexpr int M = (RPAD * RPAD) / WG > 0 ? (RPAD * RPAD) / WG : 1;
@@ -94,7 +96,7 @@ __device__ __forceinline__ void sweep_all(double (&A)[(RPAD * RPAD) / WG > 0 ? (
   //   a_ic <- a_ic - [u_i w_i] Ki [u_c w_c]^T            (i, c outside the block; u = row k, w = row k+1)
   //   rows k, k+1 <- Ki [u_c; w_c]    columns k, k+1 <- the same by symmetry    block <- -Ki
   // r2 = r rounded up to even (the caller pads with an identity row/column).
-  const int wv = threadIdx.x >> 6;
+  const int wv = (threadIdx.x >> 6) & 3;
   const bool con = c < r2;
   const int cc = con ? c : r2 - 1;
   int ic[M];
@@ -155,7 +157,7 @@ __device__ __forceinline__ void sweep_all(double (&A)[(RPAD * RPAD) / WG > 0 ? (
     }
     __syncthreads();
   }
-  if (bad && threadIdx.x == 0) *errflag = 1;
+  if (bad && (threadIdx.x & (WG - 1)) == 0) *errflag = 1;
 }
 
 // A (in): symmetric Pbar elements of this thread, identity-padded to r2;  Gk (in): kappa * G elements

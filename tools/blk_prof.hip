@@ -1,0 +1,34 @@
+// GPU-box diagnostic: per-phase cycles of the two-group block filter (stamps via PSMF_BLK_STAMPS).
+#define PSMF_BLK_STAMPS 1
+#include "../rpsmf_amd/csrc/psmf_block.hip"
+#include <cstdio>
+#include <vector>
+#include <cmath>
+using namespace psmf;
+int main() {
+  const int r = 32, nb = 32;
+  DevState* st; hipMalloc((void**)&st, sizeof(DevState)); hipMemset(st, 0, sizeof(DevState));
+  std::vector<double> I(r * r, 0.0), Q(r * r, 0.0); for (int i = 0; i < r; ++i) { I[i * r + i] = 1.0; Q[i * r + i] = 0.1; }
+  hipMemcpy(st->V, I.data(), r * r * 8, hipMemcpyHostToDevice); hipMemcpy(st->P, I.data(), r * r * 8, hipMemcpyHostToDevice);
+  hipMemcpy(st->Q, Q.data(), r * r * 8, hipMemcpyHostToDevice);
+  double one = 1.0; hipMemcpy(&st->rho, &one, 8, hipMemcpyHostToDevice);
+  // an SPD Gram: K = Z^T Z for a random Z
+  std::vector<double> Z(512 * RB), K(RB * RB, 0.0);
+  unsigned s = 1; for (auto& z : Z) { s = s * 1664525u + 1013904223u; z = ((s >> 8) & 0xffff) / 65536.0 - 0.5; }
+  for (int a = 0; a < RB; ++a) for (int c = 0; c < RB; ++c) { double acc = 0; for (int i = 0; i < 512; ++i) acc += Z[i * RB + a] * Z[i * RB + c]; K[a * RB + c] = acc * 200; }
+  double *dK, *dA, *dB, *dKp; hipMalloc((void**)&dK, RB * RB * 8); hipMalloc((void**)&dA, RB * RM * 8); hipMalloc((void**)&dB, RB * RB * 8); hipMalloc((void**)&dKp, 1 << 20);
+  hipMemcpy(dK, K.data(), RB * RB * 8, hipMemcpyHostToDevice);
+  BlockParams b{}; b.sp.st = st; b.sp.r = r; b.sp.d = 100000; b.sp.d_local = 100000; b.sp.coef_update = 1; b.sp.eta_full = 1; b.sp.pbar_predict = 1;
+  b.sp.alpha = b.sp.beta = 1.0; b.K = dK; b.Acoef = dA; b.Bcoef = dB; b.Kpart = dKp; b.k0 = 0; b.nb = nb;
+  const size_t lds = blk_filter2_lds_bytes();
+  hipFuncSetAttribute((const void*)psmf_blk_filter2<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  for (int it = 0; it < 2; ++it) { psmf_blk_filter2<32><<<1, 2 * WG, lds>>>(b); hipDeviceSynchronize(); }
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  hipEventRecord(e0); psmf_blk_filter2<32><<<1, 2 * WG, lds>>>(b); hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  unsigned long long h[8 * 12]; hipMemcpy(h, dKp, sizeof(h), hipMemcpyDeviceToHost);
+  const char* nm[10] = {"P2 compute", "barriers (P2,P3,P4)", "P3", "P4", "P5 + build M", "P6 inversion", "P7 (2 barriers)", "P8 (+barrier)", "P9", "end barriers"};
+  printf("block of %d steps: %.1f us = %.2f us/step; err flag field k=%d\n", nb, ms * 1e3, ms * 1e3 / nb, 0);
+  for (int w : {0, 4}) { printf("wave %d (%s):\n", w, w < 4 ? "X" : "Y"); for (int q = 0; q < 10; ++q) printf("   %-22s %7.0f cycles/step\n", nm[q], (double)h[w * 12 + q] / nb); }
+  return 0;
+}
