@@ -23,16 +23,19 @@ namespace psmf {
 #ifdef PSMF_BLK_STAMPS
 #define BLK_T0() unsigned long long bt_[12] = {0,0,0,0,0,0,0,0,0,0,0,0}, bl_, bn_; { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(bl_) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
 #define BLK_T(n) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(bn_) :: "memory"); __builtin_amdgcn_sched_barrier(0); bt_[n] += bn_ - bl_; bl_ = bn_; }
+#define BLK_COUNT(i, v) if (threadIdx.x == 0) reinterpret_cast<unsigned long long*>(b.Kpart)[200 + (i)] += (v);
 #define BLK_TOUT() if ((threadIdx.x & 63) == 0) for (int q_ = 0; q_ < 12; ++q_) reinterpret_cast<unsigned long long*>(b.Kpart)[(threadIdx.x >> 6) * 12 + q_] = bt_[q_];
 #else
 #define BLK_T0()
 #define BLK_T(n)
+#define BLK_COUNT(i, v)
 #define BLK_TOUT()
 #endif
 
 constexpr int RB = 64;           // r + B, padded coefficient dimension (r <= 32)
 constexpr int RS = RM / 2 + 1;   // LDS row stride of the RB x r coefficient matrices (odd: lane = row reads are conflict-free)
 constexpr int BLK_GRAM_WG = 256; // workgroups (= partials) of the block Gram
+constexpr int XGB = 64;          // column capacity of the cross-Gram (>= block length)
 
 struct BlockParams {
   StepParams sp;
@@ -43,6 +46,15 @@ struct BlockParams {
   long long k0;       // first step of the block is k0 + 1 (0-based series row k0)
   int nb;             // steps in this block
   int gram_rows;      // rows per Gram workgroup
+  // pipelined blocks: K of this block is ASSEMBLED from the previous block instead of read from K:
+  //   K[0:r,0:r] = G (tracked), K[0:r, r+q] = Aprev^T XG[0:RB, q], K[r+q, r+q'] = XG[RB+q, q']
+  // with XG = [Z_prev^T Y ; Y^T Y] computed off the critical path (psmf_blk_xgram_mfma).
+  int assemble;
+  const double* XG;       // (RB + XGB) x XGB
+  const double* Aprev;    // RB x r: coefficient matrix at the end of the previous block
+  double* XGpart;         // BLK_GRAM_WG x (RB + XGB) * XGB
+  long long k1;           // xgram: first row of the NEXT block in the series
+  int nb1;                // xgram: steps of the next block
 };
 
 // ------------------------------------------------------------------------------------------
@@ -223,9 +235,109 @@ __global__ __launch_bounds__(WG) void psmf_blk_apply_mfma(BlockParams b) {
 
 inline size_t blk_apply_lds_bytes() { return ((size_t)RB * GZ_S + 4 * 16 * AP_S) * 8; }
 
+// Cross-Gram for the NEXT block, computed while the current block is being filtered:
+//   XG[0:RB, q]      = [C_k0 | Y_cur]^T y_next_q        (RB x nb1)
+//   XG[RB + q, q']   = y_next_q . y_next_q'             (nb1 x nb1)
+// Same staging and MFMA structure as psmf_blk_gram_mfma; wave w owns the row tiles 2w, 2w+1 of the
+// 8 row tiles of [Z | Y_next] (tiles 0-3 = Z, 4-7 = Y_next) against the column tiles of Y_next.
+template <typename T>
+__global__ __launch_bounds__(WG) void psmf_blk_xgram_mfma(BlockParams b) {
+  __shared__ double sZ[GZ_TR * GZ_S];
+  __shared__ double sY[GZ_TR * GZ_S];
+  const StepParams& p = b.sp;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lk = lane >> 4;
+  const int r = p.r, rp = p.rp, dl = p.d_local, nb = b.nb, nb1 = b.nb1;
+  const int nct = (nb1 + 15) >> 4;            // column tiles actually needed
+  const T* __restrict__ C = reinterpret_cast<const T*>(p.C);
+  const T* __restrict__ Y = reinterpret_cast<const T*>(p.Y) + (size_t)(b.k0 - p.series_t0) * dl;
+  const T* __restrict__ Y1 = reinterpret_cast<const T*>(p.Y) + (size_t)(b.k1 - p.series_t0) * dl;
+  f64x4 acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[a][t] = f64x4{0.0, 0.0, 0.0, 0.0};
+  for (int idx = tid; idx < GZ_TR * RB; idx += WG) { sZ[(idx / RB) * GZ_S + (idx % RB)] = 0.0; sY[(idx / RB) * GZ_S + (idx % RB)] = 0.0; }
+  const int row_begin = blockIdx.x * b.gram_rows;
+  const int row_end = min(row_begin + b.gram_rows, dl);
+  const double* sA_ = (w < 2) ? sZ : sY;      // this wave's row tiles come from Z (w = 0, 1) or Y_next (w = 2, 3)
+  const int t0 = (w & 1) * 2;                 // its first 16-column tile inside that image
+  for (int base = row_begin; base < row_end; base += GZ_TR) {
+    __syncthreads();
+    for (int idx = tid; idx < GZ_TR * r; idx += WG) {
+      const int rr = idx / r, c = idx - rr * r;
+      const double v = (double)C[(size_t)min(base + rr, row_end - 1) * rp + c];
+      sZ[rr * GZ_S + c] = (base + rr < row_end) ? v : 0.0;
+    }
+    for (int idx = tid; idx < GZ_TR * nb; idx += WG) {
+      const int q = idx / GZ_TR, rr = idx - q * GZ_TR;
+      const double v = (double)Y[(size_t)q * dl + min(base + rr, row_end - 1)];
+      sZ[rr * GZ_S + r + q] = (base + rr < row_end) ? v : 0.0;
+    }
+    for (int idx = tid; idx < GZ_TR * nb1; idx += WG) {
+      const int q = idx / GZ_TR, rr = idx - q * GZ_TR;
+      const double v = (double)Y1[(size_t)q * dl + min(base + rr, row_end - 1)];
+      sY[rr * GZ_S + q] = (base + rr < row_end) ? v : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < GZ_TR / 4; ++q) {
+      const int krow = (4 * q + lk) * GZ_S;
+      const double a0 = sA_[krow + 16 * t0 + lr], a1 = sA_[krow + 16 * (t0 + 1) + lr];
+      double bv[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) bv[t] = sY[krow + 16 * t + lr];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        if (t < nct) {
+          acc[0][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bv[t], acc[0][t], 0, 0, 0);
+          acc[1][t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bv[t], acc[1][t], 0, 0, 0);
+        }
+      }
+    }
+  }
+  double* out = b.XGpart + (size_t)blockIdx.x * (RB + XGB) * XGB;
+  const int rowbase = (w < 2 ? 0 : RB) + 16 * t0;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) out[(size_t)(rowbase + 16 * a + lk + 4 * q) * XGB + 16 * t + lr] = acc[a][t][q];
+}
+
+__global__ __launch_bounds__(128) void psmf_blk_xreduce(BlockParams b, double* XGout, int nparts) {
+  const int e = blockIdx.x * 128 + threadIdx.x;   // (RB + XGB) * XGB = 8192 = 64 x 128
+  XGout[e] = strided_sum(b.XGpart + e, 0, 1, nparts, (RB + XGB) * XGB);
+}
+
 __global__ __launch_bounds__(128) void psmf_blk_reduce(BlockParams b, int nparts) {
   const int e = blockIdx.x * 128 + threadIdx.x;   // RB*RB = 4096 = 32 x 128
   b.K[e] = strided_sum(b.Kpart + e, 0, 1, nparts, RB * RB);
+}
+
+// K of a pipelined block from the previous block's quantities (see BlockParams):
+//   staging: Aprev (RB x r) -> sA image, XG[0:RB, 0:nb] -> sKA image reused as a (RB x nb') strip per pass
+// Outputs the full symmetric sK.  Called by all NTH threads of the workgroup; ends with a barrier.
+template <int NTH>
+__device__ __forceinline__ void assemble_K(const BlockParams& b, double* sK, double* sA, double* sKA, const int r, const int tid) {
+  const int nb = b.nb;
+  const DevState* st = b.sp.st;
+  for (int idx = tid; idx < RB * RB; idx += NTH) sK[idx] = 0.0;
+  for (int idx = tid; idx < RB * r; idx += NTH) { const int m = idx / r, c = idx - m * r; sA[m * RS + c] = b.Aprev[idx]; }
+  __syncthreads();
+  // G block and the series block
+  for (int idx = tid; idx < r * r; idx += NTH) { const int i = idx / r, c = idx - i * r; sK[i * RB + c] = st->G[idx]; }
+  for (int idx = tid; idx < nb * nb; idx += NTH) { const int q = idx / nb, q2 = idx - q * nb; sK[(r + q) * RB + r + q2] = b.XG[(size_t)(RB + q) * XGB + q2]; }
+  // cross block K[i][r+q] = sum_m Aprev[m][i] XG[m][q]   (XG read straight from global: L2-resident 32 KB)
+  for (int idx = tid; idx < r * nb; idx += NTH) {
+    const int q = idx / r, i = idx - q * r;          // consecutive threads -> consecutive i (conflict-free sA reads)
+    double acc = 0.0;
+#pragma unroll 8
+    for (int m = 0; m < RB; ++m) acc += sA[m * RS + i] * b.XG[(size_t)m * XGB + q];
+    sK[i * RB + r + q] = acc;
+    sK[(r + q) * RB + i] = acc;
+  }
+  __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -262,7 +374,11 @@ __global__ __launch_bounds__(WG) void psmf_blk_filter(BlockParams b) {
   double* s4 = rowbuf + 4 * RM;       // 4 (+ errflag)
   int* errflag = reinterpret_cast<int*>(s4 + 4);
 
-  for (int idx = tid; idx < RB * RB; idx += WG) sK[idx] = b.K[idx];
+  if (!b.assemble) {
+    for (int idx = tid; idx < RB * RB; idx += WG) sK[idx] = b.K[idx];
+  } else {
+    assemble_K<WG>(b, sK, sA, sKA, r, tid);
+  }
   if (tid == 0) *errflag = 0;
   if (tid < RM) { s_mub[tid] = 0.0; s_h[tid] = 0.0; s_w[tid] = 0.0; s_f[tid] = 1.0; }
   if (tid < r) s_mu[tid] = st->mu[tid];
@@ -511,20 +627,26 @@ __global__ __launch_bounds__(2 * WG) void psmf_blk_filter2(BlockParams b) {
   double* s4Y = s4X + 4;              // 4
   double* s_sc = s4Y + 4;             // 16 scalars: 0 kappa 1 N 2 invN 3 ee 4 omega 5 phi 6 vscale 7 pscale
   double* s_nrm = s_sc + 16;          // 8: Newton-Schulz residual norms^2, [half][wave]
-  double* nsM = s_nrm + 8 + (X ? 0 : 3 * NS_N * NS_S);   // per half: matrix, iterate, residual (NS_N x NS_S each)
-  double* nsX = nsM + NS_N * NS_S;
-  double* nsR = nsX + NS_N * NS_S;
-  int* errflag = reinterpret_cast<int*>(s_nrm + 8 + 6 * NS_N * NS_S);
+  double* nsM = s_nrm + 8 + (X ? 0 : 4 * NS_N * NS_S);   // per half: matrix, iterate (ping-pong), residual (NS_N x NS_S each)
+  double* nsX0 = nsM + NS_N * NS_S;
+  double* nsX1 = nsX0 + NS_N * NS_S;
+  double* nsR = nsX1 + NS_N * NS_S;
+  int* errflag = reinterpret_cast<int*>(s_nrm + 8 + 8 * NS_N * NS_S);
   constexpr int NT = RPAD > 16 ? 32 : 16;      // Newton-Schulz tile size
   const int nti = lw >> 1, ntj = lw & 1, lane = tid & 63;
   const bool ns_wave = (NT == 32) || lw == 0;
 
-  for (int idx = tid; idx < RB * RB; idx += 2 * WG) sK[idx] = b.K[idx];
+  if (!b.assemble) {
+    for (int idx = tid; idx < RB * RB; idx += 2 * WG) sK[idx] = b.K[idx];
+  } else {
+    assemble_K<2 * WG>(b, sK, sA, sKA, r, tid);
+  }
   if (tid == 0) *errflag = 0;
   for (int idx = lt; idx < NS_N * NS_S; idx += WG) {       // identity padding of the Newton-Schulz images
     const int i = idx / NS_S, c = idx - i * NS_S;
     nsM[idx] = (i == c) ? 1.0 : 0.0;
-    nsX[idx] = (i == c) ? 1.0 : 0.0;
+    nsX0[idx] = (i == c) ? 1.0 : 0.0;
+    nsX1[idx] = (i == c) ? 1.0 : 0.0;
     nsR[idx] = 0.0;
   }
   if (tid < RM) { s_mub[tid] = 0.0; s_h[tid] = 0.0; s_w[tid] = 0.0; s_vec[tid] = 0.0; }
@@ -568,6 +690,7 @@ __global__ __launch_bounds__(2 * WG) void psmf_blk_filter2(BlockParams b) {
   __syncthreads();
 
   double s_last = 0.0, eta_last = 0.0, N_last = 0.0, phi = 1.0, omega = 1.0, ee_last = 0.0;
+  int ns_skip = 0;                    // steps to wait before the next Newton-Schulz attempt after a failure
   double Xp[M];                       // inverse found at the previous step (Newton-Schulz start)
 #pragma unroll
   for (int m = 0; m < M; ++m) Xp[m] = 0.0;
@@ -668,37 +791,47 @@ __global__ __launch_bounds__(2 * WG) void psmf_blk_filter2(BlockParams b) {
       // the fallback (first step of the block, start too far, no convergence).  Control flow is uniform
       // over the whole workgroup: both halves see both residual norms.
       bool done = false;
-      if (jb > 0 && p.use_ns) {
+      if (jb > 0 && p.use_ns && ns_skip == 0) {
 #pragma unroll
         for (int m = 0; m < M; ++m) {
           if (val[m]) {
             nsM[ii[m] * NS_S + j] = R1[m];
-            nsX[ii[m] * NS_S + j] = Xp[m];
+            nsX0[ii[m] * NS_S + j] = Xp[m];
           }
         }
         __syncthreads();
+        // per iteration: [R = I - M X, norm] barrier [X' = X + X R into the other buffer] barrier; the
+        // norms are read after the second barrier, so the decision costs no barrier of its own.  Once
+        // ||R|| < 3e-7 the update that follows brings it below 1e-13 (R <- R^2): no further check.
+        double* xc = nsX0;
+        double* xn = nsX1;
         for (int it = 0; it < 8; ++it) {
-          double nr = ns_wave ? ns_residual<NT>(nsM, nsX, nsR, nti, ntj, lane) : 0.0;
+          double nr = ns_wave ? ns_residual<NT>(nsM, xc, nsR, nti, ntj, lane) : 0.0;
           const float nw = wave_sum_f32_dpp((float)nr);
           if (lane == 0) s_nrm[tid >> 6] = (double)nw;
+          __syncthreads();
+          if (ns_wave) ns_store_tile(xn, ns_update_tile<NT>(xc, nsR, nti, ntj, lane), nti, ntj, lane);
           __syncthreads();
           const double nx = (s_nrm[0] + s_nrm[1]) + (s_nrm[2] + s_nrm[3]);
           const double ny = (s_nrm[4] + s_nrm[5]) + (s_nrm[6] + s_nrm[7]);
           const double worst = fmax(nx, ny);
-          if (worst < 1e-24) { done = true; break; }             // ||I - M X||_F < 1e-12 on both halves
+          BLK_COUNT(2 + it, 1);
+          if (it == 0) { BLK_COUNT(12, (unsigned long long)(1e6 * sqrt(worst))); }
+          double* tsw = xc; xc = xn; xn = tsw;                     // xc now holds the updated iterate
+          if (worst < 9e-14) { done = true; break; }               // ||R|| < 3e-7 before the update just made
           if (!(worst < 0.09) || it == 7) break;                   // too far (||R|| > 0.3) or not converging
-          f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-          if (ns_wave) acc = ns_update_tile<NT>(nsX, nsR, nti, ntj, lane);
-          __syncthreads();                                         // every wave has read the old X and R
-          if (ns_wave) ns_store_tile(nsX, acc, nti, ntj, lane);
-          __syncthreads();
         }
         if (done) {
 #pragma unroll
           for (int m = 0; m < M; ++m)
-            R1[m] = val[m] ? 0.5 * (nsX[ii[m] * NS_S + j] + nsX[j * NS_S + ii[m]]) : 0.0;
+            R1[m] = val[m] ? 0.5 * (xc[ii[m] * NS_S + j] + xc[j * NS_S + ii[m]]) : 0.0;
+        } else {
+          ns_skip = 3;        // far from the previous inverse (transient): do not pay for the attempt every step
         }
+      } else if (ns_skip > 0) {
+        --ns_skip;
       }
+      BLK_COUNT(done ? 0 : 1, 1);
       if (!done) {
         sweep_all<RPAD>(R1, r2, j, ig, X ? rowbufX : rowbufY, errflag);    // R1 <- -(.)^-1; barriers shared by both halves
 #pragma unroll
@@ -764,14 +897,12 @@ __global__ __launch_bounds__(2 * WG) void psmf_blk_filter2(BlockParams b) {
         }
       }
     }
-    if (Yg) {   // thread = row m (lane) x column class: no integer division, conflict-free (odd row stride)
+    {   // rank-1 updates, one matrix per half: thread = row m (lane) x column class (no integer
+        // division, odd row stride: conflict-free)
       const int m = lt & (RB - 1);
-      const double am = s_a[m], km = s_Ka[m];
-      for (int c = lt >> 6; c < r; c += WG / RB) {
-        const double wc = s_w[c] * invN;
-        sA[m * RS + c] += am * wc;
-        sKA[m * RS + c] += km * wc;
-      }
+      double* tgt = X ? sKA : sA;
+      const double cm = X ? s_Ka[m] : s_a[m];
+      for (int c = lt >> 6; c < r; c += WG / RB) tgt[m * RS + c] += cm * (s_w[c] * invN);
     }
     if (p.robust) {
       q *= omega;
@@ -811,7 +942,7 @@ __global__ __launch_bounds__(2 * WG) void psmf_blk_filter2(BlockParams b) {
 }
 
 inline size_t blk_filter2_lds_bytes() {
-  const size_t doubles = (size_t)RB * RB + 2 * (size_t)RB * RS + RM * RM / 4 + 2 * WG + 5 * RM + 2 * RB + 8 * RB + 8 * RM + 8 + 16 + 8 + 6 * (size_t)NS_N * NS_S + 2;
+  const size_t doubles = (size_t)RB * RB + 2 * (size_t)RB * RS + RM * RM / 4 + 2 * WG + 5 * RM + 2 * RB + 8 * RB + 8 * RM + 8 + 16 + 8 + 8 * (size_t)NS_N * NS_S + 2;
   return (doubles * 8 + 15) & ~(size_t)15;
 }
 

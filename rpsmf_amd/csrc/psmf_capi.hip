@@ -50,8 +50,12 @@ struct psmf_filter {
   bool q_iso = false;          // Q = q I with q > 0 as last uploaded (two-group block filter applies)
   double* Kpart = nullptr;
   double* Kmat = nullptr;
-  double* Acoef = nullptr;
-  double* Bcoef = nullptr;
+  double* Acoef = nullptr;     // 2 x RB x RM   (ping-pong across pipelined blocks)
+  double* Bcoef = nullptr;     // 2 x RB x RB
+  double* XGpart = nullptr;    // BLK_GRAM_WG x (RB + XGB) x XGB
+  double* XG = nullptr;        // 2 x (RB + XGB) x XGB
+  hipStream_t bulk = nullptr;  // Gram / cross-Gram / apply of the pipelined blocked engine
+  hipEvent_t evF[4] = {}, evA[4] = {}, evX[4] = {}, evS = nullptr;
   size_t scratch_bytes = 0;
   int64_t T_cap = 0;
   StepParams sp;
@@ -152,9 +156,13 @@ int enqueue_step(psmf_filter* h) {
 }
 
 // one block of nb steps of the blocked engine: Gram, reduction, (all-reduce), coefficient-space filter, apply
-void fill_block_params(psmf_filter* h, psmf::BlockParams& b, int64_t k0, int nb) {
+void fill_block_params(psmf_filter* h, psmf::BlockParams& b, int64_t k0, int nb, int slot = 0) {
+  memset(&b, 0, sizeof(b));
   b.sp = h->sp;
-  b.Kpart = h->Kpart; b.K = h->Kmat; b.Acoef = h->Acoef; b.Bcoef = h->Bcoef;
+  b.Kpart = h->Kpart; b.K = h->Kmat;
+  b.Acoef = h->Acoef + (size_t)slot * psmf::RB * psmf::RM;
+  b.Bcoef = h->Bcoef + (size_t)slot * psmf::RB * psmf::RB;
+  b.XGpart = h->XGpart;
   b.k0 = k0; b.nb = nb;
   b.gram_rows = (h->cfg.d_local + psmf::BLK_GRAM_WG - 1) / psmf::BLK_GRAM_WG;
 }
@@ -164,18 +172,19 @@ bool blk_use_mfma() {
   return !off;
 }
 
-void launch_blk_gram(psmf_filter* h, const psmf::BlockParams& b) {
+void launch_blk_gram(psmf_filter* h, const psmf::BlockParams& b, hipStream_t stream = nullptr) {
+  if (!stream) stream = h->stream;
   if (blk_use_mfma()) {
     if (h->cfg.storage == PSMF_F64)
-      hipLaunchKernelGGL(psmf::psmf_blk_gram_mfma<double>, dim3(psmf::BLK_GRAM_WG), dim3(psmf::WG), 0, h->stream, b);
+      hipLaunchKernelGGL(psmf::psmf_blk_gram_mfma<double>, dim3(psmf::BLK_GRAM_WG), dim3(psmf::WG), 0, stream, b);
     else
-      hipLaunchKernelGGL(psmf::psmf_blk_gram_mfma<float>, dim3(psmf::BLK_GRAM_WG), dim3(psmf::WG), 0, h->stream, b);
+      hipLaunchKernelGGL(psmf::psmf_blk_gram_mfma<float>, dim3(psmf::BLK_GRAM_WG), dim3(psmf::WG), 0, stream, b);
   } else if (h->cfg.storage == PSMF_F64) {
-    hipLaunchKernelGGL(psmf::psmf_blk_gram<double>, dim3(psmf::BLK_GRAM_WG), dim3(psmf::WG), 0, h->stream, b);
+    hipLaunchKernelGGL(psmf::psmf_blk_gram<double>, dim3(psmf::BLK_GRAM_WG), dim3(psmf::WG), 0, stream, b);
   } else {
-    hipLaunchKernelGGL(psmf::psmf_blk_gram<float>, dim3(psmf::BLK_GRAM_WG), dim3(psmf::WG), 0, h->stream, b);
+    hipLaunchKernelGGL(psmf::psmf_blk_gram<float>, dim3(psmf::BLK_GRAM_WG), dim3(psmf::WG), 0, stream, b);
   }
-  hipLaunchKernelGGL(psmf::psmf_blk_reduce, dim3(psmf::RB * psmf::RB / 128), dim3(128), 0, h->stream, b, (int)psmf::BLK_GRAM_WG);
+  hipLaunchKernelGGL(psmf::psmf_blk_reduce, dim3(psmf::RB * psmf::RB / 128), dim3(128), 0, stream, b, (int)psmf::BLK_GRAM_WG);
 }
 
 bool blk_dual_ok(const psmf_filter* h) {
@@ -202,24 +211,25 @@ void launch_blk_filter(psmf_filter* h, const psmf::BlockParams& b) {
   }
 }
 
-void launch_blk_apply(psmf_filter* h, const psmf::BlockParams& b) {
+void launch_blk_apply(psmf_filter* h, const psmf::BlockParams& b, hipStream_t stream = nullptr) {
+  if (!stream) stream = h->stream;
   if (blk_use_mfma()) {
     const int nslab = (h->cfg.d_local + 15) / 16;
     int g = (nslab + 3) / 4;
     if (g > 1024) g = 1024;
     const size_t lds = psmf::blk_apply_lds_bytes();
     if (h->cfg.storage == PSMF_F64)
-      hipLaunchKernelGGL(psmf::psmf_blk_apply_mfma<double>, dim3(g), dim3(psmf::WG), lds, h->stream, b);
+      hipLaunchKernelGGL(psmf::psmf_blk_apply_mfma<double>, dim3(g), dim3(psmf::WG), lds, stream, b);
     else
-      hipLaunchKernelGGL(psmf::psmf_blk_apply_mfma<float>, dim3(g), dim3(psmf::WG), lds, h->stream, b);
+      hipLaunchKernelGGL(psmf::psmf_blk_apply_mfma<float>, dim3(g), dim3(psmf::WG), lds, stream, b);
     return;
   }
   int grid = (h->cfg.d_local + psmf::WG - 1) / psmf::WG;
   if (grid > 1024) grid = 1024;
   if (h->cfg.storage == PSMF_F64)
-    hipLaunchKernelGGL(psmf::psmf_blk_apply<double>, dim3(grid), dim3(psmf::WG), 0, h->stream, b);
+    hipLaunchKernelGGL(psmf::psmf_blk_apply<double>, dim3(grid), dim3(psmf::WG), 0, stream, b);
   else
-    hipLaunchKernelGGL(psmf::psmf_blk_apply<float>, dim3(grid), dim3(psmf::WG), 0, h->stream, b);
+    hipLaunchKernelGGL(psmf::psmf_blk_apply<float>, dim3(grid), dim3(psmf::WG), 0, stream, b);
 }
 
 int enqueue_block(psmf_filter* h, int64_t k0, int nb) {
@@ -230,6 +240,64 @@ int enqueue_block(psmf_filter* h, int64_t k0, int nb) {
     NCCL_TRY(h, ncclAllReduce(h->Kmat, h->Kmat, psmf::RB * psmf::RB, ncclDouble, ncclSum, h->comm, h->stream));
   launch_blk_filter(h, b);
   launch_blk_apply(h, b);
+  return PSMF_OK;
+}
+
+// Pipelined blocks: the filter kernels chain back to back on the main stream; Gram of the first block,
+// cross-Grams (one block ahead) and applies run on the bulk stream, synchronised with events:
+//   bulk:  gram(0) | xgram(1) | [filter(0)] apply(0) | xgram(2) | [filter(1)] apply(1) | ...
+//   main:  [gram(0)] filter(0) | [xgram(1)] filter(1) | [xgram(2)] filter(2) | ...
+// xgram(b+1) reads C before apply(b) rewrites it (stream order on bulk); the ping-pong coefficient
+// buffers of block b are rewritten by filter(b+2), which waits for xgram(b+2), enqueued after apply(b).
+int enqueue_blocks_pipelined(psmf_filter* h, int64_t k_begin, int64_t k_end) {
+  const int B = h->block_steps;
+  const int64_t nblk = (k_end - k_begin + B - 1) / B;
+  auto k0_of = [&](int64_t b) { return k_begin + b * B; };
+  auto nb_of = [&](int64_t b) { const int64_t left = k_end - k0_of(b); return (int)(left < B ? left : B); };
+  const size_t xg_elems = (size_t)(psmf::RB + psmf::XGB) * psmf::XGB;
+  HIP_TRY(h, hipEventRecord(h->evS, h->stream));            // everything enqueued so far (state uploads) is visible to bulk
+  HIP_TRY(h, hipStreamWaitEvent(h->bulk, h->evS, 0));
+  psmf::BlockParams b;
+  // first block: plain Gram of the stored C
+  fill_block_params(h, b, k0_of(0), nb_of(0), 0);
+  launch_blk_gram(h, b, h->bulk);
+  if (h->use_coll)
+    NCCL_TRY(h, ncclAllReduce(h->Kmat, h->Kmat, psmf::RB * psmf::RB, ncclDouble, ncclSum, h->comm, h->bulk));
+  HIP_TRY(h, hipEventRecord(h->evX[0], h->bulk));
+  for (int64_t bi = 0; bi < nblk; ++bi) {
+    const int slot = (int)(bi & 1);
+    // bulk: cross-Gram for block bi + 1 (needs C as of the start of block bi)
+    if (bi + 1 < nblk) {
+      psmf::BlockParams x;
+      fill_block_params(h, x, k0_of(bi), nb_of(bi), slot);
+      x.k1 = k0_of(bi + 1);
+      x.nb1 = nb_of(bi + 1);
+      double* xg = h->XG + (size_t)((bi + 1) & 1) * xg_elems;
+      if (h->cfg.storage == PSMF_F64)
+        hipLaunchKernelGGL(psmf::psmf_blk_xgram_mfma<double>, dim3(psmf::BLK_GRAM_WG), dim3(psmf::WG), 0, h->bulk, x);
+      else
+        hipLaunchKernelGGL(psmf::psmf_blk_xgram_mfma<float>, dim3(psmf::BLK_GRAM_WG), dim3(psmf::WG), 0, h->bulk, x);
+      hipLaunchKernelGGL(psmf::psmf_blk_xreduce, dim3((int)(xg_elems / 128)), dim3(128), 0, h->bulk, x, xg, (int)psmf::BLK_GRAM_WG);
+      if (h->use_coll) NCCL_TRY(h, ncclAllReduce(xg, xg, xg_elems, ncclDouble, ncclSum, h->comm, h->bulk));
+      HIP_TRY(h, hipEventRecord(h->evX[(bi + 1) & 3], h->bulk));
+    }
+    // main: filter of block bi
+    fill_block_params(h, b, k0_of(bi), nb_of(bi), slot);
+    if (bi > 0) {
+      b.assemble = 1;
+      b.XG = h->XG + (size_t)(bi & 1) * xg_elems;
+      b.Aprev = h->Acoef + (size_t)(slot ^ 1) * psmf::RB * psmf::RM;
+    }
+    HIP_TRY(h, hipStreamWaitEvent(h->stream, h->evX[bi & 3], 0));
+    launch_blk_filter(h, b);
+    HIP_TRY(h, hipEventRecord(h->evF[bi & 3], h->stream));
+    // bulk: apply of block bi
+    HIP_TRY(h, hipStreamWaitEvent(h->bulk, h->evF[bi & 3], 0));
+    launch_blk_apply(h, b, h->bulk);
+    HIP_TRY(h, hipEventRecord(h->evA[bi & 3], h->bulk));
+  }
+  HIP_TRY(h, hipStreamWaitEvent(h->stream, h->evA[(nblk - 1) & 3], 0));   // the main stream sees the final C / y_hat
+  HIP_TRY(h, hipGetLastError());
   return PSMF_OK;
 }
 
@@ -395,9 +463,18 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
     h->block_steps = psmf::RB - cfg->r;
     CREATE_TRY(hipMalloc((void**)&h->Kpart, (size_t)psmf::BLK_GRAM_WG * psmf::RB * psmf::RB * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&h->Kmat, (size_t)psmf::RB * psmf::RB * sizeof(double)));
-    CREATE_TRY(hipMalloc((void**)&h->Acoef, (size_t)psmf::RB * psmf::RM * sizeof(double)));
-    CREATE_TRY(hipMalloc((void**)&h->Bcoef, (size_t)psmf::RB * psmf::RB * sizeof(double)));
-    CREATE_TRY(hipMemset(h->Bcoef, 0, (size_t)psmf::RB * psmf::RB * sizeof(double)));
+    CREATE_TRY(hipMalloc((void**)&h->Acoef, (size_t)2 * psmf::RB * psmf::RM * sizeof(double)));
+    CREATE_TRY(hipMalloc((void**)&h->Bcoef, (size_t)2 * psmf::RB * psmf::RB * sizeof(double)));
+    CREATE_TRY(hipMemset(h->Bcoef, 0, (size_t)2 * psmf::RB * psmf::RB * sizeof(double)));
+    CREATE_TRY(hipMalloc((void**)&h->XGpart, (size_t)psmf::BLK_GRAM_WG * (psmf::RB + psmf::XGB) * psmf::XGB * sizeof(double)));
+    CREATE_TRY(hipMalloc((void**)&h->XG, (size_t)2 * (psmf::RB + psmf::XGB) * psmf::XGB * sizeof(double)));
+    CREATE_TRY(hipStreamCreateWithFlags(&h->bulk, hipStreamNonBlocking));
+    for (int i = 0; i < 4; ++i) {
+      CREATE_TRY(hipEventCreateWithFlags(&h->evF[i], hipEventDisableTiming));
+      CREATE_TRY(hipEventCreateWithFlags(&h->evA[i], hipEventDisableTiming));
+      CREATE_TRY(hipEventCreateWithFlags(&h->evX[i], hipEventDisableTiming));
+    }
+    CREATE_TRY(hipEventCreateWithFlags(&h->evS, hipEventDisableTiming));
     const size_t flds = psmf::blk_filter_lds_bytes();
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_filter<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_filter<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
@@ -451,6 +528,11 @@ void psmf_destroy(psmf_handle h) {
   if (h->Kmat) hipFree(h->Kmat);
   if (h->Acoef) hipFree(h->Acoef);
   if (h->Bcoef) hipFree(h->Bcoef);
+  if (h->XGpart) hipFree(h->XGpart);
+  if (h->XG) hipFree(h->XG);
+  for (int i = 0; i < 4; ++i) { if (h->evF[i]) hipEventDestroy(h->evF[i]); if (h->evA[i]) hipEventDestroy(h->evA[i]); if (h->evX[i]) hipEventDestroy(h->evX[i]); }
+  if (h->evS) hipEventDestroy(h->evS);
+  if (h->bulk) { hipStreamSynchronize(h->bulk); hipStreamDestroy(h->bulk); }
   if (h->scratch) hipFree(h->scratch);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
@@ -614,6 +696,13 @@ int psmf_run(psmf_handle h, int64_t k_begin, int64_t k_end) {
   }
   int64_t n = k_end - k_begin;
   if (h->engine == 2) {
+    static const bool pipe_off = getenv("PSMF_BLOCK_PIPE") && atoi(getenv("PSMF_BLOCK_PIPE")) == 0;
+    if (!pipe_off && k_end - k_begin > h->block_steps) {
+      rc = enqueue_blocks_pipelined(h, k_begin, k_end);
+      if (rc) return rc;
+      h->k_done = k_end;
+      return PSMF_OK;
+    }
     int64_t k = k_begin;
     while (k < k_end) {
       const int nb = (int)((k_end - k) < h->block_steps ? (k_end - k) : h->block_steps);
