@@ -7,13 +7,14 @@ One "step" of this harness = one pass of the hot path (T filter timesteps, full 
 predict / y_hat = C mu_bar / innovation / r x r solve / low-rank updates of C, mu, P, V) over a
 synthetic series that is already resident in HBM.  value = K * T / elapsed  (timesteps per
 second of the whole job).  For N > 1 the d rows of C and y are sharded over the ranks
-(strong scaling, one RCCL all-reduce of r+1 doubles per timestep); launch with
+(strong scaling; blocked engine: one RCCL all-reduce of a 128 x 64 cross-Gram per block of 64 - r
+timesteps, off the critical path; per-step engine: r+1 doubles per timestep); launch with
 `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` -- torch is used
 only as rendezvous plumbing (gloo: id broadcast, barrier, max over ranks), never for compute.
 
 Extra objects on the JSON line:
-  roofline      dominant kernel (row sweep): algorithmic bytes 8 d (r+1) per launch / its average
-                duration measured with HIP events on the library's stream, vs 8 TB/s HBM.
+  roofline      dominant kernel: algorithmic bytes 8 d (r+1) per timestep x timesteps per launch / its
+                average duration measured with HIP events on the library's stream, vs 8 TB/s HBM.
   cpu_baseline  the CPU oracle (numpy restatement of the reference algorithm, O(d r^2) form)
                 timed on a bounded prefix of the same series on this box's host cores.
 """
@@ -45,6 +46,7 @@ def parse():
     ap.add_argument("--cpu-steps", type=int, default=300, help="timesteps of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-y-pred", action="store_true")
     ap.add_argument("--workgroups", type=int, default=0)
+    ap.add_argument("--engine", default="auto", choices=["auto", "step", "block"])
     return ap.parse_args()
 
 
@@ -135,7 +137,7 @@ def main():
     st0 = init_state(d, r, seed)
 
     f = _capi.DeviceFilter(d, r, robust=bool(args.robust), storage=args.storage, store_y_pred=not args.no_y_pred,
-                           device=local_rank, row0=row0, d_local=d_local, n_workgroups=args.workgroups)
+                           device=local_rank, row0=row0, d_local=d_local, n_workgroups=args.workgroups, engine=args.engine)
     if world > 1:
         import torch
 
@@ -190,12 +192,33 @@ def main():
         elapsed = float(te.item())
     value = args.steps * T / elapsed
 
-    # ---- roofline of the dominant kernel (row sweep), HIP events on the library's stream
-    bytes_per_launch = 8.0 * d_local * (r + 1) if args.storage == "f32" else 16.0 * d_local * (r + 1)
-    sweep_us = f.time_kernel(0, 300)
-    serial_us = f.time_kernel(1, 300)
-    achieved = bytes_per_launch / (sweep_us * 1e-6) / 1e9
+    # ---- roofline of the dominant kernel, HIP events on the library's stream (psmf_time_kernel)
+    bytes_per_step = (8.0 if args.storage == "f32" else 16.0) * d_local * (r + 1)   # read C, write C, read y, write y_hat
     geo = f.geometry()
+    traffic = None
+    if geo["engine"] == "block":
+        # one launch of the coefficient-space filter kernel = one block of B timesteps; the two d-sized
+        # products of the block (cross-Gram, apply) run concurrently on a second stream
+        B = geo["block_steps"]
+        t_filter = f.time_kernel(0, 20)
+        t_gram = f.time_kernel(1, 50)
+        t_apply = f.time_kernel(2, 50)
+        kernel, kernel_us, steps_per_launch = "psmf_blk_filter2", t_filter, B
+        zbytes = (4.0 if args.storage == "f32" else 8.0) * d_local * 64
+        extra = {"steps_per_launch": B,
+                 "kernels_us": {"psmf_blk_filter2": t_filter, "psmf_blk_gram_mfma+reduce": t_gram, "psmf_blk_apply_mfma": t_apply},
+                 "bulk_kernels_GBps": {"gram (reads Z)": zbytes / (t_gram * 1e-6) / 1e9,
+                                       "apply (reads Z, writes C and y_hat)": 2 * zbytes / (t_apply * 1e-6) / 1e9},
+                 "note": "blocked engine: the filter kernel is a latency-bound chain of r x r stages (one workgroup); "
+                         "achieved = step-at-a-time algorithmic bytes of the B steps it advances / its duration"}
+    else:
+        kernel, kernel_us, steps_per_launch = "psmf_sweep_solve", f.time_kernel(0, 300), 1
+        extra = {"steps_per_launch": 1, "kernels_us": {"psmf_sweep_solve": kernel_us, "psmf_serial": f.time_kernel(1, 300)}}
+        pmc = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+        if (d, r, args.storage, world) == (100_000, 32, "f32", 1) and os.path.exists(pmc):
+            traffic = json.load(open(pmc))["traffic_bytes_per_launch"]   # rocprofv3 --pmc passes of this workload
+    alg_bytes = bytes_per_step * steps_per_launch
+    achieved = alg_bytes / (kernel_us * 1e-6) / 1e9
     if rank == 0:
         line = {
             "metric": "PSMF filter timesteps/sec at d=100k r=32" if (d, r) == (100_000, 32) else f"PSMF filter timesteps/sec at d={d} r={r}",
@@ -213,12 +236,11 @@ def main():
             "config": {"workload": f"{'rPSMF' if args.robust else 'PSMF'} full filter, random-walk dynamics, d={d} r={r} "
                                    f"T={T} synthetic Gaussian series, rows sharded over {world} GPU(s)",
                        "d": d, "r": r, "T": T, "timesteps_per_pass": T, "store_y_pred": not args.no_y_pred,
-                       "us_per_timestep": 1e6 * elapsed / (args.steps * T), "geometry": geo},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "psmf_sweep_solve", "kernel_us": sweep_us, "serial_kernel_us": serial_us,
-                         "algorithmic_bytes_per_launch": bytes_per_launch,
-                         "whole_step_frac": value * 8.0 * d * (r + 1) / (world * HBM_PEAK_GBS * 1e9)},
+                       "us_per_timestep": 1e6 * elapsed / (args.steps * T), "engine": geo["engine"], "geometry": geo},
+            "roofline": dict({"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                              "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kernel, "kernel_us": kernel_us,
+                              "algorithmic_bytes_per_launch": alg_bytes,
+                              "whole_job_frac": value * 8.0 * d * (r + 1) / (world * HBM_PEAK_GBS * 1e9)}, **extra),
         }
         if cpu is not None:
             line["cpu_baseline"] = cpu

@@ -12,7 +12,7 @@ def go(d, r, T, marks, robust=False):
     st0 = bench.init_state(d, r, 35853)
     fs = {}
     for storage in ("f32", "f64"):
-        f = _capi.DeviceFilter(d, r, storage=storage, robust=robust)
+        f = _capi.DeviceFilter(d, r, storage=storage, robust=robust, engine=os.environ.get("PROBE_ENGINE", "auto"))
         f.upload_series(Y)
         f.set_state(st0["C"], st0["V"], st0["P"], st0["Q"], st0["mu"], rho=1.0, lambda0=1.8)
         fs[storage] = f
@@ -23,7 +23,7 @@ def go(d, r, T, marks, robust=False):
     for k in marks:
         for j in range(kprev, k):
             st, info = O.lowrank_step(st, Y64[j], j + 1, O.Mode(robust=robust), O.RandomWalkDyn(), want_grad=False)
-        out = dict(d=d, r=r, k=k, robust=robust)
+        out = dict(d=d, r=r, k=k, robust=robust, engine=fs["f32"].geometry()["engine"])
         for storage, f in fs.items():
             f.run(kprev, k)
             s = f.get_state()
