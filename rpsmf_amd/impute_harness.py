@@ -28,15 +28,19 @@ def prepare_missing(Ymiss, missRatio, misSeg=20):
     native = int(np.isnan(Ymiss).sum())
     Mmiss = np.zeros_like(Ymiss)
     total = d * n
+    removed = 0                      # == Mmiss.sum(), kept as a running count (the reference re-sums d*n entries per sweep)
     ratio = native / total
+    rows = np.repeat(np.arange(d), misSeg)
+    offs = np.tile(np.arange(misSeg), d)
     while ratio < missRatio:
-        for row in range(d):
-            start = np.random.randint(1, n - misSeg)
-            seg = slice(start, start + misSeg)
-            fresh = ~np.isnan(Ymiss[row, seg])
-            Mmiss[row, seg][fresh] = 1
-            Ymiss[row, seg] = np.nan
-        ratio = (native + Mmiss.sum()) / total
+        # one segment start per row, drawn in row order from the global RNG exactly as d scalar randint calls would
+        starts = np.random.randint(1, n - misSeg, size=d)
+        cols = np.repeat(starts, misSeg) + offs
+        fresh = ~np.isnan(Ymiss[rows, cols])
+        Mmiss[rows[fresh], cols[fresh]] = 1
+        Ymiss[rows, cols] = np.nan
+        removed += int(fresh.sum())
+        ratio = (native + removed) / total
     return ratio, Mmiss
 
 

@@ -216,7 +216,7 @@ def test_collective_path_single_rank_matches_plain(engine):
     """The multi-GPU code path (local reduce kernel -> RCCL all-reduce of h, ee -> serial stage, all
     captured in the hipGraph) run with a one-rank communicator must equal the plain path."""
     c = _capi()
-    d, r, T = 1500, 12, 40
+    d, r, T = 1500, 12, 130   # blocked engine: block length 52 -> 3 pipelined blocks (cross-Gram all-reduce on the bulk stream)
     Y, C0 = _problem(d, r, T, 21)
     full = c.DeviceFilter(d, r, storage="f64", engine=engine)
     full.upload_series(Y)
