@@ -674,8 +674,20 @@ __global__ __launch_bounds__(2 * WG) void psmf_blk_filter2(BlockParams b) {
   }
 #pragma unroll
   for (int m = 0; m < M; ++m) Gv[m] = val[m] ? sK[ii[m] * RB + j] : 0.0;
-  // Lbar_1 = (P + q I)^-1: both halves run the same sweep in lockstep (one result is kept)
-  {
+  int ns_skip = 0;                    // steps to wait before the next Newton-Schulz attempt after a failure
+  double Xp[M];                       // inverse found at the previous step (Newton-Schulz start)
+  const bool carried = st->ns_valid != 0;     // uniform: the previous block left Lbar and both inverses behind
+  if (carried) {
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const int idx = val[m] ? ii[m] * r + j : 0;
+      const double ll = st->Lbar[idx], xx = X ? st->XpX[idx] : st->XpY[idx];
+      Lv[m] = val[m] ? ll : 0.0;
+      Xp[m] = val[m] ? xx : 0.0;
+      if (Yg && val[m]) sL[ii[m] * RPAD + j] = Lv[m];
+    }
+  } else {
+    // Lbar_1 = (P + q I)^-1: both halves run the same sweep in lockstep (one result is kept)
     double A1[M];
 #pragma unroll
     for (int m = 0; m < M; ++m) A1[m] = val[m] ? Pv[m] + (ii[m] == j ? q : 0.0) : ((ii[m] == j && j < r2) ? 1.0 : 0.0);
@@ -683,6 +695,7 @@ __global__ __launch_bounds__(2 * WG) void psmf_blk_filter2(BlockParams b) {
 #pragma unroll
     for (int m = 0; m < M; ++m) {
       Lv[m] = val[m] ? -A1[m] : 0.0;
+      Xp[m] = 0.0;
       if (Yg && val[m]) sL[ii[m] * RPAD + j] = Lv[m];
     }
   }
@@ -690,10 +703,6 @@ __global__ __launch_bounds__(2 * WG) void psmf_blk_filter2(BlockParams b) {
   __syncthreads();
 
   double s_last = 0.0, eta_last = 0.0, N_last = 0.0, phi = 1.0, omega = 1.0, ee_last = 0.0;
-  int ns_skip = 0;                    // steps to wait before the next Newton-Schulz attempt after a failure
-  double Xp[M];                       // inverse found at the previous step (Newton-Schulz start)
-#pragma unroll
-  for (int m = 0; m < M; ++m) Xp[m] = 0.0;
   BLK_T0();
   for (int jb = 0; jb < b.nb; ++jb) {
     // ---- P2: X: Pbar, partial w, <G, Pbar>;  Y: partial row dots of A mu_bar and KA mu_bar ----
@@ -791,7 +800,7 @@ __global__ __launch_bounds__(2 * WG) void psmf_blk_filter2(BlockParams b) {
       // the fallback (first step of the block, start too far, no convergence).  Control flow is uniform
       // over the whole workgroup: both halves see both residual norms.
       bool done = false;
-      if (jb > 0 && p.use_ns && ns_skip == 0) {
+      if ((jb > 0 || carried) && p.use_ns && ns_skip == 0) {
 #pragma unroll
         for (int m = 0; m < M; ++m) {
           if (val[m]) {
@@ -872,6 +881,9 @@ __global__ __launch_bounds__(2 * WG) void psmf_blk_filter2(BlockParams b) {
         om = (lam + quad) * ild;
       }
       if (lt == 0) { s_sc[4] = om; s_sc[5] = ph; }
+      // random walk: mu_bar_{k+1} = mu_k.  s_mub[lt] is read in this phase only by this thread (above);
+      // its other readers (P2, P4) are behind the barrier below and want the NEW value.
+      if (lt < r) { s_mu[lt] = mu_new; s_mub[lt] = mu_new; }
     }
     __syncthreads();
     BLK_T(7);
@@ -911,14 +923,21 @@ __global__ __launch_bounds__(2 * WG) void psmf_blk_filter2(BlockParams b) {
     }
     s_last = s; eta_last = eta; N_last = s_sc[1]; ee_last = ee;
     BLK_T(8);
-    __syncthreads();                       // every read of s_mub, s_w, s_h, s_a, s_Ka of this step is done
-    if (X && lt < r) { s_mu[lt] = mu_new; s_mub[lt] = mu_new; }   // random walk: mu_bar_{k+1} = mu_k
-    __syncthreads();
+    __syncthreads();                       // every read of s_w, s_h, s_a, s_Ka of this step is done
     BLK_T(9);
   }
   BLK_TOUT();
 
   // ---- block end ----
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    if (val[m]) {
+      const int idx = ii[m] * r + j;
+      if (X) st->XpX[idx] = Xp[m];
+      else { st->XpY[idx] = Xp[m]; st->Lbar[idx] = Lv[m]; }
+    }
+  }
+  if (tid == 0) st->ns_valid = 1;
   for (int idx = tid; idx < RB * r; idx += 2 * WG) { const int m = idx / r; b.Acoef[idx] = sA[m * RS + (idx - m * r)]; }
   if (X) {
 #pragma unroll

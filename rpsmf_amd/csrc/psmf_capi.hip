@@ -574,6 +574,7 @@ int psmf_set_state(psmf_handle h, const double* C, const double* V, const double
     HIP_TRY(h, hipMemcpy(h->st->theta, theta, h->cfg.n_theta * sizeof(double), hipMemcpyHostToDevice));
   if (!std::isnan(rho)) HIP_TRY(h, hipMemcpy(&h->st->rho, &rho, sizeof(double), hipMemcpyHostToDevice));
   if (!std::isnan(lambda0)) HIP_TRY(h, hipMemcpy(&h->st->lam, &lambda0, sizeof(double), hipMemcpyHostToDevice));
+  { const int zero = 0; HIP_TRY(h, hipMemcpy(&h->st->ns_valid, &zero, sizeof(int), hipMemcpyHostToDevice)); }
   if (C && V && P && mu) h->have_state = true;
   h->need_prep = true;
   return PSMF_OK;

@@ -18,6 +18,10 @@ struct DevState {
   double Pbar[RM * RM];   // predictive covariance of the current step
   double Q[RM * RM];      // running Q (scaled by omega in rPSMF)
   double G[RM * RM];      // Gram matrix C^T C of the current C (tracked algebraically)
+  // carried across the blocks of the blocked engine (valid while ns_valid != 0):
+  double Lbar[RM * RM / 4];   // r x r (r <= 32): Pbar^-1 of the next step
+  double XpX[RM * RM / 4];    // last P+ (Newton-Schulz start of half X)
+  double XpY[RM * RM / 4];    // last W  (Newton-Schulz start of half Y)
   double mu[RM];          // posterior mean mu_{k-1}
   double mu_bar[RM];      // predictive mean of the current step
   double w[RM];           // V mu_bar
@@ -30,7 +34,7 @@ struct DevState {
   double s_done, eta_done, N_done;  // s, eta, N of the last finished step
   long long k;            // number of finished steps = 0-based series index of the current step
   int err;                // != 0: numeric failure (singular system) at step err
-  int pad;
+  int ns_valid;           // Lbar / XpX / XpY describe the current state (cleared by every host state upload)
 };
 
 struct StepParams {

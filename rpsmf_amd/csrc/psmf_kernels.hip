@@ -547,6 +547,7 @@ __device__ __forceinline__ void serial_body(const StepParams& p, const int first
     if (vl) st->mu[tid] = mu_new;
     if (tid == 0) {
       st->k = knext;
+      st->ns_valid = 0;
       st->rho = rho;
       st->lam = lam;
       st->phi = phi;
