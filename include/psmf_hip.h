@@ -118,6 +118,10 @@ int psmf_sync(psmf_handle h); /* waits, then reports a device-side numeric failu
 
 /* y_hat for steps t0+1..t0+nt (needs store_y_pred) -> out (nt x d_local), dtype f32/f64 */
 int psmf_download_y_pred(psmf_handle h, void* out, int dtype, int64_t t0, int64_t nt);
+/* posterior means mu_{k0} .. mu_{k0+nk-1} of the last run (row k = state after step k; the row of the
+ * run's first step index holds the mean it started from) -> out (nk x r float64).  What TrackingMixin
+ * reads as `_mu[k]` (tracking.py:140-142) when the experiment keeps `_mu` un-pruned. */
+int psmf_download_mu(psmf_handle h, double* out, int64_t k0, int64_t nk);
 /* psmf.py:182-188: mu rolled forward n_pred steps from the current state, y_hat = C mu_pred;
  * out: n_pred x d_local float64.  T = index of the last filtered step. */
 int psmf_predict(psmf_handle h, int64_t T, int64_t n_pred, double* out);

@@ -56,6 +56,7 @@ SIGNATURES = {
     "psmf_run": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64]),
     "psmf_sync": (C.c_int, [C.c_void_p]),
     "psmf_download_y_pred": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64]),
+    "psmf_download_mu": (C.c_int, [C.c_void_p, _dp, C.c_int64, C.c_int64]),
     "psmf_predict": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, _dp]),
     "psmf_sq_error": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, _dp]),
     "psmf_comm_unique_id": (C.c_int, [C.c_void_p]),
@@ -232,6 +233,11 @@ class DeviceFilter:
         out = np.empty((nt, self.d_local), dtype=dtype)
         dt = F32 if out.dtype == np.float32 else F64
         self._check(self._lib.psmf_download_y_pred(self._h, out.ctypes.data_as(C.c_void_p), dt, int(t0), int(nt)))
+        return out
+
+    def mu_history(self, k0, nk):
+        out = np.empty((nk, self.r))
+        self._check(self._lib.psmf_download_mu(self._h, _ptr(out), int(k0), int(nk)))
         return out
 
     def predict(self, T, n_pred):

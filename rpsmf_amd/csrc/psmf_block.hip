@@ -328,16 +328,30 @@ __device__ __forceinline__ void assemble_K(const BlockParams& b, double* sK, dou
   // G block and the series block
   for (int idx = tid; idx < r * r; idx += NTH) { const int i = idx / r, c = idx - i * r; sK[i * RB + c] = st->G[idx]; }
   for (int idx = tid; idx < nb * nb; idx += NTH) { const int q = idx / nb, q2 = idx - q * nb; sK[(r + q) * RB + r + q2] = b.XG[(size_t)(RB + q) * XGB + q2]; }
-  // cross block K[i][r+q] = sum_m Aprev[m][i] XG[m][q]   (XG read straight from global: L2-resident 32 KB)
-  for (int idx = tid; idx < r * nb; idx += NTH) {
-    const int q = idx / r, i = idx - q * r;          // consecutive threads -> consecutive i (conflict-free sA reads)
-    double acc = 0.0;
+  // cross block K[i][r+q] = sum_m Aprev[m][i] XG[m][q].  The top RB rows of the cross-Gram go through LDS, 32
+  // columns at a time (sKA is free until the caller fills it): one coalesced round trip instead of RB
+  // dependent L2 reads per output.
+  for (int q0 = 0; q0 < nb; q0 += 32) {
+    for (int idx = tid; idx < RB * 32; idx += NTH) {
+      const int m = idx >> 5, q = idx & 31;
+      if (q0 + q < nb) sKA[m * RS + q] = b.XG[(size_t)m * XGB + q0 + q];
+    }
+    __syncthreads();
+    const int nq = nb - q0 < 32 ? nb - q0 : 32;
+    for (int idx = tid; idx < r * nq; idx += NTH) {
+      const int q = idx / r, i = idx - q * r;          // consecutive threads -> consecutive i (conflict-free sA reads, sKA broadcast)
+      double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll 8
-    for (int m = 0; m < RB; ++m) acc += sA[m * RS + i] * b.XG[(size_t)m * XGB + q];
-    sK[i * RB + r + q] = acc;
-    sK[(r + q) * RB + i] = acc;
+      for (int m = 0; m < RB; m += 2) {
+        acc0 += sA[m * RS + i] * sKA[m * RS + q];
+        acc1 += sA[(m + 1) * RS + i] * sKA[(m + 1) * RS + q];
+      }
+      const double acc = acc0 + acc1;
+      sK[i * RB + r + q0 + q] = acc;
+      sK[(r + q0 + q) * RB + i] = acc;
+    }
+    __syncthreads();
   }
-  __syncthreads();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -557,7 +571,10 @@ __global__ __launch_bounds__(WG) void psmf_blk_filter(BlockParams b) {
       }
     }
     __syncthreads();           // all reads of s_mu, s_w, s_h, s_a, s_Ka of this step are done
-    if (tid < r) s_mu[tid] = mu_new;
+    if (tid < r) {
+      s_mu[tid] = mu_new;
+      if (p.mu_hist) p.mu_hist[(size_t)(kstep - p.series_t0) * r + tid] = mu_new;
+    }
     s_last = s; eta_last = eta; N_last = N; ee_last = ee;
     __syncthreads();
   }
@@ -883,7 +900,11 @@ __global__ __launch_bounds__(2 * WG) void psmf_blk_filter2(BlockParams b) {
       if (lt == 0) { s_sc[4] = om; s_sc[5] = ph; }
       // random walk: mu_bar_{k+1} = mu_k.  s_mub[lt] is read in this phase only by this thread (above);
       // its other readers (P2, P4) are behind the barrier below and want the NEW value.
-      if (lt < r) { s_mu[lt] = mu_new; s_mub[lt] = mu_new; }
+      if (lt < r) {
+        s_mu[lt] = mu_new;
+        s_mub[lt] = mu_new;
+        if (p.mu_hist) p.mu_hist[(size_t)(b.k0 + jb + 1 - p.series_t0) * r + lt] = mu_new;
+      }
     }
     __syncthreads();
     BLK_T(7);

@@ -43,6 +43,9 @@ struct psmf_filter {
   void* YP = nullptr;
   double* partials = nullptr;
   double* gpart = nullptr;
+  double* mu_hist = nullptr;   // (T_cap + 1) x r
+  hipStream_t fstream = nullptr;   // blocked engine, pipelined: the filter chain's own stream, pinned to reserved CUs (or nullptr)
+  int reserved_cus = 0;
   double* scratch = nullptr;   // sq-error partials / predict staging
   // blocked engine
   int engine = 1;              // 1 per-step, 2 blocked
@@ -193,21 +196,22 @@ bool blk_dual_ok(const psmf_filter* h) {
          h->cfg.dyn_kind == PSMF_DYN_RANDOM_WALK;
 }
 
-void launch_blk_filter(psmf_filter* h, const psmf::BlockParams& b) {
+void launch_blk_filter(psmf_filter* h, const psmf::BlockParams& b, hipStream_t stream = nullptr) {
+  if (!stream) stream = h->stream;
   if (blk_dual_ok(h)) {
     const size_t lds2 = psmf::blk_filter2_lds_bytes();
     switch (h->geo.rpad) {
-      case 8: hipLaunchKernelGGL(psmf::psmf_blk_filter2<8>, dim3(1), dim3(2 * psmf::WG), lds2, h->stream, b); break;
-      case 16: hipLaunchKernelGGL(psmf::psmf_blk_filter2<16>, dim3(1), dim3(2 * psmf::WG), lds2, h->stream, b); break;
-      default: hipLaunchKernelGGL(psmf::psmf_blk_filter2<32>, dim3(1), dim3(2 * psmf::WG), lds2, h->stream, b); break;
+      case 8: hipLaunchKernelGGL(psmf::psmf_blk_filter2<8>, dim3(1), dim3(2 * psmf::WG), lds2, stream, b); break;
+      case 16: hipLaunchKernelGGL(psmf::psmf_blk_filter2<16>, dim3(1), dim3(2 * psmf::WG), lds2, stream, b); break;
+      default: hipLaunchKernelGGL(psmf::psmf_blk_filter2<32>, dim3(1), dim3(2 * psmf::WG), lds2, stream, b); break;
     }
     return;
   }
   const size_t lds = psmf::blk_filter_lds_bytes();
   switch (h->geo.rpad) {
-    case 8: hipLaunchKernelGGL(psmf::psmf_blk_filter<8>, dim3(1), dim3(psmf::WG), lds, h->stream, b); break;
-    case 16: hipLaunchKernelGGL(psmf::psmf_blk_filter<16>, dim3(1), dim3(psmf::WG), lds, h->stream, b); break;
-    default: hipLaunchKernelGGL(psmf::psmf_blk_filter<32>, dim3(1), dim3(psmf::WG), lds, h->stream, b); break;
+    case 8: hipLaunchKernelGGL(psmf::psmf_blk_filter<8>, dim3(1), dim3(psmf::WG), lds, stream, b); break;
+    case 16: hipLaunchKernelGGL(psmf::psmf_blk_filter<16>, dim3(1), dim3(psmf::WG), lds, stream, b); break;
+    default: hipLaunchKernelGGL(psmf::psmf_blk_filter<32>, dim3(1), dim3(psmf::WG), lds, stream, b); break;
   }
 }
 
@@ -257,6 +261,8 @@ int enqueue_blocks_pipelined(psmf_filter* h, int64_t k_begin, int64_t k_end) {
   const size_t xg_elems = (size_t)(psmf::RB + psmf::XGB) * psmf::XGB;
   HIP_TRY(h, hipEventRecord(h->evS, h->stream));            // everything enqueued so far (state uploads) is visible to bulk
   HIP_TRY(h, hipStreamWaitEvent(h->bulk, h->evS, 0));
+  hipStream_t fs = h->fstream ? h->fstream : h->stream;    // the filter chain (its own CUs when the mask streams exist)
+  if (h->fstream) HIP_TRY(h, hipStreamWaitEvent(fs, h->evS, 0));
   psmf::BlockParams b;
   // first block: plain Gram of the stored C
   fill_block_params(h, b, k0_of(0), nb_of(0), 0);
@@ -288,9 +294,9 @@ int enqueue_blocks_pipelined(psmf_filter* h, int64_t k_begin, int64_t k_end) {
       b.XG = h->XG + (size_t)(bi & 1) * xg_elems;
       b.Aprev = h->Acoef + (size_t)(slot ^ 1) * psmf::RB * psmf::RM;
     }
-    HIP_TRY(h, hipStreamWaitEvent(h->stream, h->evX[bi & 3], 0));
-    launch_blk_filter(h, b);
-    HIP_TRY(h, hipEventRecord(h->evF[bi & 3], h->stream));
+    HIP_TRY(h, hipStreamWaitEvent(fs, h->evX[bi & 3], 0));
+    launch_blk_filter(h, b, fs);
+    HIP_TRY(h, hipEventRecord(h->evF[bi & 3], fs));
     // bulk: apply of block bi
     HIP_TRY(h, hipStreamWaitEvent(h->bulk, h->evF[bi & 3], 0));
     launch_blk_apply(h, b, h->bulk);
@@ -388,6 +394,9 @@ int prepare(psmf_filter* h, int64_t k_begin) {
   HIP_TRY(h, hipMemcpyAsync(&h->st->k, &k, sizeof(k), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipMemcpyAsync(&h->st->err, &zero, sizeof(zero), hipMemcpyHostToDevice, h->stream));
   HIP_TRY(h, hipStreamSynchronize(h->stream));   // the two sources above are stack variables
+  if (h->mu_hist)
+    HIP_TRY(h, hipMemcpyAsync(h->mu_hist + (size_t)(k_begin - h->sp.series_t0) * h->cfg.r, h->st->mu, h->cfg.r * sizeof(double),
+                              hipMemcpyDeviceToDevice, h->stream));
   if (h->engine == 2) {   // the blocked engine derives everything it needs from the block Gram
     h->need_prep = false;
     h->k_done = k_begin;
@@ -468,7 +477,32 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
     CREATE_TRY(hipMemset(h->Bcoef, 0, (size_t)2 * psmf::RB * psmf::RB * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&h->XGpart, (size_t)psmf::BLK_GRAM_WG * (psmf::RB + psmf::XGB) * psmf::XGB * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&h->XG, (size_t)2 * (psmf::RB + psmf::XGB) * psmf::XGB * sizeof(double)));
-    CREATE_TRY(hipStreamCreateWithFlags(&h->bulk, hipStreamNonBlocking));
+    {
+      // The filter chain is one workgroup on the critical path; the bulk kernels (cross-Gram, apply) run
+      // beside it and would be co-scheduled onto its CU, stretching it by 10-17 % (measured).  Partition the
+      // chip with CU masks: the filter's stream owns `nres` CUs, the bulk stream the others.
+      int nres = 8;
+      if (const char* e = getenv("PSMF_RESERVED_CUS")) nres = atoi(e);
+      hipDeviceProp_t prop;
+      CREATE_TRY(hipGetDeviceProperties(&prop, cfg->device));
+      const int ncu = prop.multiProcessorCount;
+      const int words = (ncu + 31) / 32;
+      if (nres > 0 && nres < ncu / 2 && words <= 16) {
+        uint32_t mf[16] = {0}, mb[16] = {0};
+        for (int i = 0; i < ncu; ++i) (i < nres ? mf : mb)[i >> 5] |= 1u << (i & 31);
+        hipStream_t fs = nullptr, bs = nullptr;
+        if (hipExtStreamCreateWithCUMask(&fs, words, mf) == hipSuccess && hipExtStreamCreateWithCUMask(&bs, words, mb) == hipSuccess) {
+          h->fstream = fs;
+          h->bulk = bs;
+          h->reserved_cus = nres;
+        } else {
+          (void)hipGetLastError();
+          if (fs) hipStreamDestroy(fs);
+          if (bs) hipStreamDestroy(bs);
+        }
+      }
+      if (!h->bulk) CREATE_TRY(hipStreamCreateWithFlags(&h->bulk, hipStreamNonBlocking));
+    }
     for (int i = 0; i < 4; ++i) {
       CREATE_TRY(hipEventCreateWithFlags(&h->evF[i], hipEventDisableTiming));
       CREATE_TRY(hipEventCreateWithFlags(&h->evA[i], hipEventDisableTiming));
@@ -524,6 +558,7 @@ void psmf_destroy(psmf_handle h) {
   if (h->YP) hipFree(h->YP);
   if (h->partials) hipFree(h->partials);
   if (h->gpart) hipFree(h->gpart);
+  if (h->mu_hist) hipFree(h->mu_hist);
   if (h->Kpart) hipFree(h->Kpart);
   if (h->Kmat) hipFree(h->Kmat);
   if (h->Acoef) hipFree(h->Acoef);
@@ -533,6 +568,7 @@ void psmf_destroy(psmf_handle h) {
   for (int i = 0; i < 4; ++i) { if (h->evF[i]) hipEventDestroy(h->evF[i]); if (h->evA[i]) hipEventDestroy(h->evA[i]); if (h->evX[i]) hipEventDestroy(h->evX[i]); }
   if (h->evS) hipEventDestroy(h->evS);
   if (h->bulk) { hipStreamSynchronize(h->bulk); hipStreamDestroy(h->bulk); }
+  if (h->fstream) { hipStreamSynchronize(h->fstream); hipStreamDestroy(h->fstream); }
   if (h->scratch) hipFree(h->scratch);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
@@ -648,9 +684,13 @@ int psmf_upload_series(psmf_handle h, const void* Y, int dtype, int64_t t0, int6
     destroy_graph(h);   // graph nodes hold the old buffer addresses
     if (h->Y) HIP_TRY(h, hipFree(h->Y));
     if (h->YP) HIP_TRY(h, hipFree(h->YP));
+    if (h->mu_hist) HIP_TRY(h, hipFree(h->mu_hist));
     h->Y = h->YP = nullptr;
+    h->mu_hist = nullptr;
     HIP_TRY(h, hipMalloc(&h->Y, (size_t)T_total * dl * es));
     if (h->cfg.store_y_pred) HIP_TRY(h, hipMalloc(&h->YP, (size_t)T_total * dl * es));
+    HIP_TRY(h, hipMalloc((void**)&h->mu_hist, (size_t)(T_total + 1) * h->cfg.r * sizeof(double)));
+    h->sp.mu_hist = h->mu_hist;
     h->T_cap = T_total;
     h->sp.Y = h->Y;
     h->sp.YP = h->YP;
@@ -878,6 +918,16 @@ int psmf_download_y_pred(psmf_handle h, void* out, int dtype, int64_t t0, int64_
     float* o = (float*)out;
     for (size_t i = 0; i < n; ++i) o[i] = (float)buf[i];
   }
+  return PSMF_OK;
+}
+
+int psmf_download_mu(psmf_handle h, double* out, int64_t k0, int64_t nk) {
+  if (!h || !out) return PSMF_ERR_ARG;
+  if (!h->mu_hist) return fail(h, PSMF_ERR_STATE, "psmf_download_mu: no series uploaded yet");
+  if (k0 < 0 || nk < 0 || k0 + nk > h->T_cap + 1) return fail(h, PSMF_ERR_ARG, "psmf_download_mu: range");
+  int rc = psmf_sync(h);
+  if (rc) return rc;
+  HIP_TRY(h, hipMemcpy(out, h->mu_hist + (size_t)k0 * h->cfg.r, (size_t)nk * h->cfg.r * sizeof(double), hipMemcpyDeviceToHost));
   return PSMF_OK;
 }
 

@@ -43,6 +43,7 @@ struct StepParams {
   const void* Y;      // series buffer, time-major, storage type
   void* YP;           // y_pred buffer or nullptr
   double* partials;   // n_sweep_wg x ps
+  double* mu_hist;    // (T_cap + 1) x r posterior means, row k = mu_k (row k_begin = the mean the run started from); or nullptr
   long long series_t0;  // global index of the first step held in Y
   int d, d_local, r, rp, nv;
   int n_sweep_wg, rows_per_wg, ps;

@@ -544,7 +544,10 @@ __device__ __forceinline__ void serial_body(const StepParams& p, const int first
       }
       st->gradsum[tid] = gsum;
     }
-    if (vl) st->mu[tid] = mu_new;
+    if (vl) {
+      st->mu[tid] = mu_new;
+      if (p.mu_hist) p.mu_hist[(size_t)(knext - p.series_t0) * r + tid] = mu_new;
+    }
     if (tid == 0) {
       st->k = knext;
       st->ns_valid = 0;

@@ -69,6 +69,25 @@ class _StateDict(dict):
         return dict.__getitem__(self, k)
 
 
+class _MuHist(_StateDict):
+    """`_mu[k]` -> (r, 1) for k = 0..T after a device epoch: served from the device's mean history
+    (the reference only keeps them when the experiment's `_prune` override spares `_mu`)."""
+
+    def __init__(self, owner, T, last):
+        super().__init__({T: last})
+        self._owner, self._T, self._host = owner, T, None
+
+    def __missing__(self, k):
+        if 0 <= k <= self._T:
+            if self._host is None:
+                self._host = self._owner._dev.mu_history(0, self._T + 1)
+            return self._host[k].reshape(-1, 1)
+        raise KeyError(k)
+
+    def __contains__(self, k):
+        return 0 <= k <= self._T
+
+
 class _YPred(dict):
     """`_y_pred[k]` -> (d, 1).  Steps 1..T are served from the device buffer (fetched once, whole)."""
 
@@ -410,7 +429,7 @@ class PSMFIter:
         self._C = _StateDict({T: _Lazy(self, "C", ep)})
         self._V = _StateDict({T: s["V"]})
         self._P = _StateDict({T: s["P"]})
-        self._mu = _StateDict({T: s["mu"].reshape(-1, 1)})
+        self._mu = _MuHist(self, T, s["mu"].reshape(-1, 1))
         if s["gradsum"].size:
             self._gradsum = s["gradsum"].reshape(np.asarray(self.theta0).shape)
         self._y_pred = _YPred(self, T)

@@ -280,6 +280,37 @@ def test_engines_agree_and_auto_selects_blocked():
         c.DeviceFilter(100, 8, engine="block", recursive=True, dyn_kind=c.DYN_COS_PHASE)
 
 
+@pytest.mark.parametrize("robust", [False, True])
+def test_mean_history_matches_oracle(robust, engine):
+    """`_mu[k]`, k = 0..T (what TrackingMixin reads, tracking.py:140-142), against the oracle step by step;
+    several blocks and a second run segment appended to the first."""
+    c = _capi()
+    d, r, T = 1500, 9, 140
+    Y, C0 = _problem(d, r, T, 5, "t" if robust else "normal")
+    V0, P0, Q = 0.1 * np.eye(r), np.eye(r), 0.1 * np.eye(r)
+    mu0 = 0.3 * np.ones(r)
+    st = O.State(C=C0, V=V0, mu=mu0, P=P0, Q=Q, rho=1.0, lam=1.8)
+    mode = O.Mode(robust=robust)
+    ref = [mu0.copy()]
+    for k in range(1, T + 1):
+        st, _ = O.lowrank_step(st, Y[k - 1], k, mode, O.RandomWalkDyn())
+        ref.append(st.mu.copy())
+    ref = np.array(ref)
+    f = c.DeviceFilter(d, r, storage="f64", engine=engine, **_mode_kwargs(mode))
+    f.upload_series(Y)
+    f.set_state(C0, V0, P0, Q, mu0, rho=1.0, lambda0=1.8)
+    f.run(0, 100)
+    f.run(100, T)
+    H = f.mu_history(0, T + 1)
+    assert H.shape == (T + 1, r)
+    assert np.array_equal(H[0], mu0)
+    assert relerr(H, ref) < 1e-9
+    assert np.array_equal(H[T], f.get_state()["mu"])
+    with pytest.raises(ValueError):
+        f.mu_history(0, T + 2)
+    f.close()
+
+
 def test_argument_errors():
     c = _capi()
     with pytest.raises(ValueError):

@@ -40,6 +40,9 @@ def test_classes_full_filter_on_device(name, robust):
     assert relerr(f._C[T], g["s_e2_k200_C"]) < 1e-9
     assert relerr(f._V[T], g["s_e2_k200_V"]) < 1e-9
     assert relerr(f._mu[T], g["s_e2_k200_mu"]) < 1e-9
+    for k in (1, 2, 10):     # mean history (kept by the experiments' _prune overrides), fetched lazily
+        assert f._mu[k].shape == (r, 1) and relerr(f._mu[k], g[f"s_e2_k{k}_mu"]) < 1e-9
+    assert 0 in f._mu and T + 1 not in f._mu
     assert relerr(f._P[T], g["s_e2_k200_P"]) < 1e-9
     yp = np.array([f._y_pred[k].reshape(-1) for k in range(1, T + 1)])
     assert relerr(yp, g["y_pred_e2"]) < 1e-9
