@@ -64,6 +64,7 @@ SIGNATURES = {
     "psmf_run_timed": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_float)]),
     "psmf_time_kernel": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "psmf_geometry": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "psmf_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
     "psmf_impute_run": (C.c_int, [C.POINTER(PsmfImputeConfig), _dp, _u8p, _u8p, _dp, _dp, _dp, _dp, _dp,
                                   C.c_double, _dp, _dp, _dp, _dp, _dp, _dp, C.POINTER(C.c_float)]),
 }
@@ -228,6 +229,11 @@ class DeviceFilter:
         self._check(self._lib.psmf_geometry(self._h, g))
         return dict(n_sweep_wg=g[0], rows_per_wg=g[1], row_stride=g[2], lanes_per_row=g[3], graph_chunk=g[4],
                     engine={1: "step", 2: "block"}.get(g[5], g[5]), block_steps=g[6])
+
+    def counters(self, reset=False):
+        c = (C.c_int64 * 8)()
+        self._check(self._lib.psmf_counters(self._h, c, int(bool(reset))))
+        return dict(ns_steps=c[0], sweep_steps=c[1], ns_iterations=c[2], ns_failed=c[3], sum_log10_res=[c[4] / 1000.0, c[5] / 1000.0, c[6] / 1000.0], max_log10_res0=(c[7] - 100000) / 1000.0)
 
     def y_pred(self, t0, nt, dtype=np.float64):
         out = np.empty((nt, self.d_local), dtype=dtype)

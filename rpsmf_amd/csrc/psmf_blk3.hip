@@ -1,0 +1,696 @@
+// Role-specialised coefficient-space filter of the blocked engine ("filter3") for the common
+// configuration (full filter, random-walk dynamics, Q = q I, 16 < r <= 32): same recursion as
+// psmf_blk_filter2 (psmf_block.hip), re-laid out around what bounds a step on MI355X.
+//
+// On gfx950 v_mfma_f64_16x16x4_f64 runs at the float64 VECTOR rate (64 cycles per instruction and SIMD),
+// so a step is bound by the 2 x 32 MFMAs of each Newton-Schulz matrix product, by LDS operand traffic
+// and by the number of barrier-separated phases -- not by flops elsewhere.  Hence:
+//
+//   * 8 waves, one ROLE each.  Waves 0-3 (one per SIMD) do nothing but the two r x r inversions of a
+//     step (X: P+ = M^-1, Y: W = (M/beta + I/q)^-1, psmf_block.hip), TWO waves per inversion, wave c owning
+//     the 16-column tile column c of its iterate.  Every matrix lives in registers in the MFMA OUTPUT
+//     layout ("T-layout": tile (ti, tj), register q of lane l  <->  row 16 ti + (l >> 4) + 4 q,
+//     column 16 tj + (l & 15)), which is at the same time the B-operand layout of the next product and
+//     -- for a symmetric matrix -- the A-operand layout of the transposed tile.  So
+//         R_c = I - M X_c            A = M (registers, built once per step), B = own column of X
+//         X'_c = X_c + X^T R_c       A = X (own column + the partner's), B = R_c (registers)
+//     need NO LDS operand reads; per iteration a wave publishes its new column (8 doubles per lane)
+//     and reads its partner's: one barrier per iteration instead of two, 16 MFMAs per product and SIMD.
+//     (X^T instead of X: the iterate is symmetric up to round-off and R' = (I - X M)^T R still
+//     squares the residual.)
+//   * waves 4-7 own the vector work, laid out so that no product needs a cross-lane reduction over
+//     more than two lanes: V (lane = column, 16 rows), A by rows, KA by rows, A^T by columns.
+//   * G, Lbar, the rank-2 / rank-1 updates and everything else O(r^2) is elementwise in registers and off
+//     the critical path, which per step is:  w = V mu_bar, s, kappa (wave 4) | barrier | M, Newton-
+//     Schulz iterations (one barrier each) | v = P+ h, mu (waves 0-1) | barrier.
+//
+// The direct symmetric sweep (psmf_kernels.hip) stays the fallback whenever the previous inverse is
+// not a usable start (first step, transients, no convergence); it runs on all 8 waves through LDS images.
+// Reference equations: pypsmf/psmf/psmf.py:104-165, rpsmf.py:116-171.
+#pragma once
+#include "psmf_block.hip"
+
+namespace psmf {
+
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+
+constexpr int F3_NT = 512;
+constexpr int F3_S = 34;            // row stride of the row-major 32 x 32 LDS images
+constexpr int F3_MAXIT = 8;
+
+#define F3_DPP64(x, ctrl)                                                                                  \
+  __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(x), ctrl, 0xF, 0xF, true),                \
+                   __builtin_amdgcn_update_dpp(0, __double2loint(x), ctrl, 0xF, 0xF, true))
+
+// sum over each 16-lane row, float64, DPP only; every lane of a row ends up with its row's sum
+__device__ __forceinline__ double row_sum_f64_dpp(double v) {
+  v += F3_DPP64(v, 0xB1);    // quad_perm [1,0,3,2]
+  v += F3_DPP64(v, 0x4E);    // quad_perm [2,3,0,1]
+  v += F3_DPP64(v, 0x141);   // row_half_mirror
+  v += F3_DPP64(v, 0x140);   // row_mirror
+  return v;
+}
+
+__device__ __forceinline__ double readlane_f64(double v, const int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+
+// sum over the 64 lanes, float64, fixed order; result uniform
+__device__ __forceinline__ double wave_sum_f64_dpp(double v) {
+  v = row_sum_f64_dpp(v);
+  return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+
+// bit e of a per-lane mask (element e = (ti * 2 + tj) * 4 + q of the T-layout).  The masks are loop invariants: without
+// the opaque F3_KEEP() in the loop the compiler hoists every test into an SGPR pair and spills (179 of them).
+#define F3_BIT(m, e) ((((m) >> (e)) & 1) != 0)
+#define F3_KEEP(m) asm volatile("" : "+v"(m))
+
+// scalar slots
+enum { F3_KAPPA = 0, F3_N, F3_INVN, F3_EE, F3_IOM, F3_Q, F3_IQ, F3_PSCALE, F3_NSC = 16 };
+
+struct F3Lds {
+  double* sK;       // RB x RB
+  double* sA;       // RB x RS   scratch of assemble_K
+  double* sKA;      // RB x RS
+  double* dump;     // [2 parities][4 NS waves][8 registers][64 lanes]
+  double* img;      // [2 inversions][32 x F3_S]
+  double* mub;      // RM
+  double* w;        // RM
+  double* h;        // RM
+  double* a;        // RB
+  double* Ka;       // RB
+  double* sc;       // F3_NSC
+  double* nrm;      // [2][4]
+  double* hv;       // 2
+  double* gp;       // 2
+  double* tr;       // 2
+  double* rowbufX;  // 4 RM
+  double* rowbufY;  // 4 RM
+  int* errflag;
+};
+
+inline size_t blk_filter3_lds_bytes() {
+  const size_t doubles = (size_t)RB * RB + 2 * (size_t)RB * RS + 2 * 4 * 8 * 64 + 2 * 32 * F3_S + 3 * RM + 2 * RB + F3_NSC + 8 + 6 +
+                         8 * RM + 2;
+  return (doubles * 8 + 15) & ~(size_t)15;
+}
+
+// One Newton-Schulz iteration of tile column C:  R = I - M X_c,  Xn = X_c + X^T R  (see the header).
+// Mf: the step's matrix, T-layout, tile (kt, ti) at [(kt * 2 + ti) * 4 + kk]; Xc / Xo: own / partner's column.
+// Returns this lane's share of ||R_c||_F^2.
+template <int C>
+__device__ __forceinline__ double f3_ns_iter(const double (&Mf)[16], const double (&Xc)[8], const double (&Xo)[8], double (&Xn)[8],
+                                             const int dmask) {
+  f64x4 acc[2];
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti) {
+    acc[ti] = f64x4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk)
+        acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(Mf[(kt * 2 + ti) * 4 + kk], Xc[kt * 4 + kk], acc[ti], 0, 0, 0);
+  }
+  double R[8];
+  double nrm = 0.0;
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const double v = (F3_BIT(dmask, (ti * 2 + C) * 4 + q) ? 1.0 : 0.0) - acc[ti][q];
+      R[ti * 4 + q] = v;
+      nrm += v * v;
+    }
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti) {
+    f64x4 a2 = f64x4{Xc[ti * 4 + 0], Xc[ti * 4 + 1], Xc[ti * 4 + 2], Xc[ti * 4 + 3]};
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        // A operand = tile (kt, ti) of X in T-layout: column ti is this wave's own column iff ti == C
+        const double aop = (ti == C) ? Xc[kt * 4 + kk] : Xo[kt * 4 + kk];
+        a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, R[kt * 4 + kk], a2, 0, 0, 0);
+      }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Xn[ti * 4 + q] = a2[q];
+  }
+  return nrm;
+}
+
+// Uniform bookkeeping of one step's inversion, identical in both programs (same LDS values, same decisions)
+struct F3Ctl {
+  bool have_prev;
+  int ns_skip;
+  int c_ns, c_sw, c_it, c_fail;
+};
+
+// residual norms of the iteration whose columns sit in dump parity `par` -> done / failed (uniform over the workgroup)
+#define F3_DECIDE()                                                                                        \
+  do {                                                                                                     \
+    const double nx_ = L.nrm[par * 4 + 0] + L.nrm[par * 4 + 1];                                            \
+    const double ny_ = L.nrm[par * 4 + 2] + L.nrm[par * 4 + 3];                                            \
+    const double worst_ = fmax(nx_, ny_);                                                                  \
+    ++ctl.c_it;                                                                                            \
+    if (worst_ < p.ns_tol2) done = true;          /* ||R|| below the tolerance BEFORE the update just made */ \
+    else if (!(worst_ < 0.09) || it == F3_MAXIT - 1) failed = true;  /* too far (||R|| > 0.3) or not converging */ \
+  } while (0)
+
+// The direct symmetric sweep of both matrices on all 8 waves (half X: image X, half Y: image Y), in place in
+// the images.  Called from both programs at the same point; the images were published before the barrier that
+// precedes it.
+__device__ __forceinline__ void f3_sweep_images(const F3Lds& L, const int r2, const int tid) {
+  const int lt = tid & (WG - 1), c32 = lt & 31, rg = lt >> 5;
+  const bool halfX = tid < WG;
+  double* im = halfX ? L.img : L.img + 32 * F3_S;
+  double A1[4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m) A1[m] = im[(rg + 8 * m) * F3_S + c32];
+  sweep_all<32>(A1, r2, c32, rg, halfX ? L.rowbufX : L.rowbufY, L.errflag);
+#pragma unroll
+  for (int m = 0; m < 4; ++m) {
+    const int i = rg + 8 * m;
+    if (i < r2 && c32 < r2) im[i * F3_S + c32] = -A1[m];
+  }
+  __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Program of the four inversion waves.  INV 0 = X (P+ = M^-1), 1 = Y (W = (M / beta + I / q)^-1); C = own tile column.
+// ------------------------------------------------------------------------------------------------------------
+template <int C>
+__device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds& L, const int inv, const int role, const int lane,
+                                              const bool carried) {
+  const StepParams& p = b.sp;
+  DevState* st = p.st;
+  const int r = p.r, r2 = r + (r & 1), tid = threadIdx.x;
+  const int lrow = lane >> 4, lcol = lane & 15;
+  const bool isX = inv == 0, isY = inv == 1;
+  double* imgX = L.img;
+  double* imgY = L.img + 32 * F3_S;
+  double G[16], L0[16], Xc[8], Xo[8];
+  int vmask = 0, dmask = 0;      // T-layout element e = (ti * 2 + tj) * 4 + q: inside the r x r matrix / on the diagonal
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const int row = 16 * ti + lrow + 4 * qq, col = 16 * tj + lcol;
+        const bool in = row < r && col < r;
+        const int e = (ti * 2 + tj) * 4 + qq;
+        vmask |= in ? (1 << e) : 0;
+        dmask |= (row == col) ? (1 << e) : 0;
+        G[e] = in ? L.sK[row * RB + col] : 0.0;                              // G_0: exact Gram of the stored C
+        const double l0 = carried ? st->Lbar[in ? row * r + col : 0] : imgX[row * F3_S + col];
+        L0[e] = in ? l0 : 0.0;
+      }
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      const int row = 16 * ti + lrow + 4 * qq, cc = 16 * C + lcol, co = 16 * (1 - C) + lcol;
+      const double* src = isX ? st->XpX : st->XpY;
+      const bool ic = carried && row < r && cc < r, io = carried && row < r && co < r;
+      const double xc = src[ic ? row * r + cc : 0], xo = src[io ? row * r + co : 0];
+      Xc[ti * 4 + qq] = ic ? xc : (row == cc ? 1.0 : 0.0);
+      Xo[ti * 4 + qq] = io ? xo : (row == co ? 1.0 : 0.0);
+    }
+  if (isX) {
+    // <G_0, P> and tr G_0 of the own column, for eta of the first step (Pbar_1 = P + q I)
+    double g1 = 0.0, t1 = 0.0;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const int row = 16 * ti + lrow + 4 * qq, col = 16 * C + lcol;
+        const bool in = row < r && col < r;
+        const double pv = st->P[in ? row * r + col : 0];
+        const double g = G[(ti * 2 + C) * 4 + qq];
+        g1 += in ? g * pv : 0.0;
+        t1 += (row == col) ? g : 0.0;
+      }
+    g1 = wave_sum_f64_dpp(g1);
+    t1 = wave_sum_f64_dpp(t1);
+    if (lane == 0) { L.gp[C] = g1; L.tr[C] = t1; }
+  }
+  __syncthreads();                                                       // ---- init barrier
+
+  F3Ctl ctl = {carried, 0, 0, 0, 0, 0};
+  BLK_T0();
+  for (int jb = 0; jb < b.nb; ++jb) {
+    F3_KEEP(vmask);
+    F3_KEEP(dmask);
+    // phase 0: nothing to do (wave 4 forms w, s, kappa)
+    BLK_T(0);
+    __syncthreads();                                                     // ---- B1
+    BLK_T(1);
+    // =============================== phase 1: M, first iteration ===============================
+    const bool try_ns = ctl.have_prev && p.use_ns && ctl.ns_skip == 0;
+    if (!try_ns && ctl.ns_skip > 0) --ctl.ns_skip;
+    double Mf[16], Xn[8];
+    int par = 0;
+    {
+      const double kap = L.sc[F3_KAPPA], iom = L.sc[F3_IOM], iq = L.sc[F3_IQ];
+      const double ib = isY ? 1.0 / p.beta : 1.0, dq = isY ? iq : 0.0;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const double dg = F3_BIT(dmask, e) ? 1.0 : 0.0;
+        const double m = (L0[e] * iom + kap * G[e]) * ib + dg * dq;
+        Mf[e] = F3_BIT(vmask, e) ? m : dg;
+      }
+    }
+#define F3_ITERATE(parity_out)                                                                             \
+  do {                                                                                                     \
+    const double nr_ = f3_ns_iter<C>(Mf, Xc, Xo, Xn, dmask);                                               \
+    const float nw_ = wave_sum_f32_dpp((float)nr_);                                                        \
+    f64x2* dp_ = reinterpret_cast<f64x2*>(L.dump) + (size_t)(((parity_out) * 4 + role) * 4) * 64 + lane;   \
+    _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) dp_[e_ * 64] = f64x2{Xn[2 * e_], Xn[2 * e_ + 1]};    \
+    if (lane == 0) L.nrm[(parity_out) * 4 + role] = (double)nw_;                                           \
+    _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) Xc[e_] = Xn[e_];                                      \
+  } while (0)
+#define F3_FETCH_PARTNER(parity_in)                                                                        \
+  do {                                                                                                     \
+    const f64x2* dq_ = reinterpret_cast<const f64x2*>(L.dump) + (size_t)(((parity_in) * 4 + (role ^ 1)) * 4) * 64 + lane; \
+    _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) { const f64x2 v_ = dq_[e_ * 64]; Xo[2 * e_] = v_[0]; Xo[2 * e_ + 1] = v_[1]; } \
+  } while (0)
+    if (try_ns) F3_ITERATE(0);
+    BLK_T(2);
+    __syncthreads();                                                     // ---- B2
+    BLK_T(1);
+    // =============================== phase 2: second iteration, G update ===============================
+    bool done = false, failed = !try_ns;
+    int it = 0;
+    if (try_ns) F3_DECIDE();
+    if (try_ns && !failed) {
+      F3_FETCH_PARTNER(0);
+      if (!done) F3_ITERATE(1);
+    }
+    {
+      // G_k = G_{k-1} + (h w^T + w h^T) / N + ee w w^T / N^2   (tracked Gram)
+      const double iN = L.sc[F3_INVN], ee = L.sc[F3_EE];
+      const double e2 = ee * iN * iN;
+      double hcol[2], wcol[2];
+#pragma unroll
+      for (int tj = 0; tj < 2; ++tj) { hcol[tj] = L.h[16 * tj + lcol]; wcol[tj] = L.w[16 * tj + lcol]; }
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+          const double hi = L.h[16 * ti + lrow + 4 * qq], wi = L.w[16 * ti + lrow + 4 * qq];
+#pragma unroll
+          for (int tj = 0; tj < 2; ++tj) G[(ti * 2 + tj) * 4 + qq] += (hi * wcol[tj] + wi * hcol[tj]) * iN + e2 * (wi * wcol[tj]);
+        }
+    }
+    BLK_T(3);
+    __syncthreads();                                                     // ---- B3
+    BLK_T(1);
+    // =============================== further iterations ===============================
+    if (try_ns && !done && !failed) { par = 1; it = 1; }
+    while (try_ns && !done && !failed) {
+      F3_DECIDE();
+      if (!failed) F3_FETCH_PARTNER(par);
+      if (done || failed) break;
+      F3_ITERATE(par ^ 1);
+      par ^= 1;
+      ++it;
+      __syncthreads();
+    }
+    BLK_T(4);
+    // `par` = parity of the dump that holds the columns published by the last iteration that ran
+    const bool from_img = !done;
+    if (!done) {
+      if (try_ns) { ++ctl.c_fail; ctl.ns_skip = 3; }
+      ++ctl.c_sw;
+      double* im = isX ? imgX : imgY;
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) im[(16 * ti + lrow + 4 * qq) * F3_S + 16 * C + lcol] = Mf[(ti * 2 + C) * 4 + qq];
+      __syncthreads();
+      f3_sweep_images(L, r2, tid);
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+          const int row = 16 * ti + lrow + 4 * qq;
+          Xc[ti * 4 + qq] = im[row * F3_S + 16 * C + lcol];
+          Xo[ti * 4 + qq] = im[row * F3_S + 16 * (1 - C) + lcol];
+        }
+    } else {
+      ++ctl.c_ns;
+    }
+    ctl.have_prev = true;
+    // =============================== phase F ===============================
+    {
+      // W (both columns) -> L0 = I / q - W / q^2  (Lbar_{k+1} = L0 / omega_k)
+      const double iq = L.sc[F3_IQ];
+      const double iq2 = iq * iq;
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj) {
+          double wv[4];
+          if (isY) {
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) wv[qq] = (tj == C) ? Xc[ti * 4 + qq] : Xo[ti * 4 + qq];
+          } else if (from_img) {
+#pragma unroll
+            for (int qq = 0; qq < 4; ++qq) wv[qq] = imgY[(16 * ti + lrow + 4 * qq) * F3_S + 16 * tj + lcol];
+          } else {
+            const f64x2* dq2 = reinterpret_cast<const f64x2*>(L.dump) + (size_t)((par * 4 + 2 + tj) * 4) * 64 + lane;
+            const f64x2 v0 = dq2[(ti * 2) * 64], v1 = dq2[(ti * 2 + 1) * 64];
+            wv[0] = v0[0]; wv[1] = v0[1]; wv[2] = v1[0]; wv[3] = v1[1];
+          }
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) {
+            const int e = (ti * 2 + tj) * 4 + qq;
+            L0[e] = F3_BIT(vmask, e) ? ((F3_BIT(dmask, e) ? iq : 0.0) - wv[qq] * iq2) : 0.0;
+          }
+        }
+      if (isX) {
+        // v = P+ h (own column, by symmetry), mu_k = mu_bar + kappa v (psmf.py:155-159), h.v, <G_k, P+>, tr G_k
+        const double kap = L.sc[F3_KAPPA];
+        double vp = 0.0, g1 = 0.0, t1 = 0.0;
+#pragma unroll
+        for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) {
+            const double x = Xc[ti * 4 + qq], g = G[(ti * 2 + C) * 4 + qq];
+            vp += x * L.h[16 * ti + lrow + 4 * qq];
+            g1 += g * x;                                               // G is zero outside r x r
+            t1 += F3_BIT(dmask, (ti * 2 + C) * 4 + qq) ? g : 0.0;
+          }
+        vp += __shfl_xor(vp, 16, 64);
+        vp += __shfl_xor(vp, 32, 64);
+        const int j = 16 * C + lcol;
+        const double hj = L.h[j];
+        const double mu_new = L.mub[j] + kap * vp;
+        double hvp = (lrow == 0) ? hj * vp : 0.0;
+        hvp = wave_sum_f64_dpp(hvp);
+        g1 = wave_sum_f64_dpp(g1);
+        t1 = wave_sum_f64_dpp(t1);
+        if (lrow == 0 && j < r) {
+          L.mub[j] = mu_new;                    // random walk: mu_bar_{k+1} = mu_k
+          if (p.mu_hist) p.mu_hist[(size_t)(b.k0 + jb + 1 - p.series_t0) * r + j] = mu_new;
+        }
+        if (lane == 0) { L.hv[C] = hvp; L.gp[C] = g1; L.tr[C] = t1; }
+      }
+    }
+    BLK_T(5);
+    __syncthreads();                                                     // ---- BF
+    BLK_T(1);
+  }
+  BLK_TOUT();
+  // ---- block end ----
+  __syncthreads();                       // wave 4 has published pscale and 1 / omega of the last step
+  const double ps = L.sc[F3_PSCALE], iom = L.sc[F3_IOM];
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      const int row = 16 * ti + lrow + 4 * qq, col = 16 * C + lcol;
+      if (row < r && col < r) {
+        const int idx = row * r + col;
+        if (isX) {
+          st->XpX[idx] = Xc[ti * 4 + qq];
+          st->P[idx] = ps * Xc[ti * 4 + qq];
+          st->G[idx] = G[(ti * 2 + C) * 4 + qq];
+        } else {
+          st->XpY[idx] = Xc[ti * 4 + qq];
+          st->Lbar[idx] = L0[(ti * 2 + C) * 4 + qq] * iom;
+        }
+      }
+    }
+  if (role == 0 && lane == 0) { st->cnt[0] += ctl.c_ns; st->cnt[1] += ctl.c_sw; st->cnt[2] += ctl.c_it; st->cnt[3] += ctl.c_fail; }
+#undef F3_ITERATE
+#undef F3_FETCH_PARTNER
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Program of the four vector waves: 4 = V and every scalar, 5 = A by rows, 6 = KA by rows, 7 = A^T by columns.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void f3_v_program(const BlockParams& b, const F3Lds& L, const int role, const int lane, const bool carried) {
+  const StepParams& p = b.sp;
+  DevState* st = p.st;
+  const int r = p.r, r2 = r + (r & 1), tid = threadIdx.x;
+  const double dd = (double)p.d;
+  const bool isV0 = role == 4, isV1 = role == 5, isV2 = role == 6, isV3 = role == 7;
+  // persistent registers:  V0: [0,16) V[16 hf + t][j]   V1: A[m][c]   V2: KA[m][c]   V3: A[32 hf + t][c]
+  double pr[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) pr[i] = 0.0;
+  // wave 4's running scalars (every lane holds the same values)
+  double kappa = 0.0, Nk = 0.0, invN = 0.0, s_k = 0.0, eta_k = 0.0, ee_k = 0.0, phi = 1.0, omega = 1.0, pscale = 1.0, wj = 0.0;
+  double q = st->Q[0];                  // Q = q I (checked by the host)
+  double rho = st->rho, lam = st->lam;
+  if (isV0) {
+    const int j = lane & 31, hf = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int i = 16 * hf + t;
+      const bool in = i < r && j < r;
+      const double v = st->V[in ? i * r + j : 0];
+      pr[t] = in ? v : 0.0;
+    }
+  } else if (isV1) {
+#pragma unroll
+    for (int c = 0; c < 32; ++c) pr[c] = (lane == c && c < r) ? 1.0 : 0.0;
+  } else if (isV2) {
+#pragma unroll
+    for (int c = 0; c < 32; ++c) pr[c] = (c < r) ? L.sK[lane * RB + c] : 0.0;
+  } else {
+    const int c = lane & 31, hf = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < 32; ++t) pr[t] = (32 * hf + t == c && c < r) ? 1.0 : 0.0;
+  }
+  __syncthreads();                                                       // ---- init barrier
+
+  // scalars of the step that just ended (omega needs v = P+ h): rpsmf.py:155-171
+#define F3_V0_FINISH_PREV()                                               \
+  do {                                                                    \
+    const double hPh_ = L.hv[0] + L.hv[1];                                \
+    const double quad_ = kappa * ee_k - kappa * kappa * hPh_;             \
+    omega = 1.0;                                                          \
+    pscale = 1.0;                                                         \
+    if (p.robust) {                                                       \
+      omega = (lam + quad_) * fast_rcp(lam + dd);                         \
+      pscale = p.beta * omega;                                            \
+      rho *= omega;                                                       \
+      q *= omega;                                                         \
+      if (!p.fixed_lambda) lam += dd;                                     \
+    }                                                                     \
+  } while (0)
+
+  F3Ctl ctl = {carried, 0, 0, 0, 0, 0};
+  for (int jb = 0; jb < b.nb; ++jb) {
+    // =============================== phase 0 ===============================
+    if (isV0) {
+      const int j = lane & 31, hf = lane >> 5;
+      double iom = 1.0;
+      if (jb > 0) { F3_V0_FINISH_PREV(); iom = fast_rcp(omega); }
+      const double gpv = pscale * (L.gp[0] + L.gp[1]) + q * (L.tr[0] + L.tr[1]);
+      eta_k = rho + gpv / dd;                                           // psmf.py:121-125
+      double part0 = 0.0, part1 = 0.0;
+#pragma unroll
+      for (int t = 0; t < 16; t += 2) {
+        part0 += pr[t] * L.mub[16 * hf + t];
+        part1 += pr[t + 1] * L.mub[16 * hf + t + 1];
+      }
+      const double part = part0 + part1;
+      wj = part + __shfl_xor(part, 32, 64);                             // w = V mu_bar
+      const double sj = (hf == 0) ? L.mub[j] * wj : 0.0;
+      s_k = wave_sum_f64_dpp(sj);
+      Nk = s_k + eta_k;                                                 // psmf.py:127-128
+      invN = fast_rcp(Nk);
+      kappa = fast_rcp(rho + s_k);
+      if (hf == 0) L.w[j] = wj;
+      if (lane == 0) {
+        L.sc[F3_KAPPA] = kappa; L.sc[F3_N] = Nk; L.sc[F3_INVN] = invN; L.sc[F3_IOM] = iom; L.sc[F3_Q] = q;
+        L.sc[F3_IQ] = 1.0 / q;
+      }
+    } else if (isV1 || isV2) {
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+      for (int c = 0; c < 32; c += 4) {
+        a0 += pr[c] * L.mub[c];
+        a1 += pr[c + 1] * L.mub[c + 1];
+        a2 += pr[c + 2] * L.mub[c + 2];
+        a3 += pr[c + 3] * L.mub[c + 3];
+      }
+      const double dot = (a0 + a1) + (a2 + a3);
+      if (isV1) {
+        L.a[lane] = (lane == r + jb ? 1.0 : 0.0) - dot;                 // a_j = u_{r+j} - A mu_bar
+        b.Bcoef[(size_t)jb * RB + lane] = dot;                          // y_hat_j = Z b_j
+      } else {
+        L.Ka[lane] = L.sK[lane * RB + r + jb] - dot;                    // K a_j
+      }
+    }
+    __syncthreads();                                                     // ---- B1
+    // =============================== phase 1 ===============================
+    const bool try_ns = ctl.have_prev && p.use_ns && ctl.ns_skip == 0;
+    if (!try_ns && ctl.ns_skip > 0) --ctl.ns_skip;
+    int par = 0;
+    if (isV3) {
+      const int c = lane & 31, hf = lane >> 5;
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+      for (int t = 0; t < 32; t += 4) {
+        a0 += pr[t] * L.Ka[32 * hf + t];
+        a1 += pr[t + 1] * L.Ka[32 * hf + t + 1];
+        a2 += pr[t + 2] * L.Ka[32 * hf + t + 2];
+        a3 += pr[t + 3] * L.Ka[32 * hf + t + 3];
+      }
+      const double part = (a0 + a1) + (a2 + a3);
+      const double hc = part + __shfl_xor(part, 32, 64);                // h = A^T K a
+      if (hf == 0) L.h[c] = hc;
+      const double e1 = wave_sum_f64_dpp(L.a[lane] * L.Ka[lane]);       // ee = a . K a
+      if (lane == 0) L.sc[F3_EE] = e1;
+    } else if (isV1 || isV2) {
+      // rank-1 updates of A (rows) and KA (rows): psmf.py:130-133 in coefficient space
+      const double iN = L.sc[F3_INVN];
+      const double cm = (isV1 ? L.a[lane] : L.Ka[lane]) * iN;
+#pragma unroll
+      for (int c = 0; c < 32; ++c) pr[c] += cm * L.w[c];
+    }
+    __syncthreads();                                                     // ---- B2
+    // =============================== phase 2 ===============================
+    bool done = false, failed = !try_ns;
+    int it = 0;
+    if (try_ns) F3_DECIDE();
+    if (isV3) {
+      const int c = lane & 31, hf = lane >> 5;
+      const double wn = L.w[c] * L.sc[F3_INVN];
+#pragma unroll
+      for (int t = 0; t < 32; ++t) pr[t] += L.a[32 * hf + t] * wn;
+    } else if (isV0) {
+      const int hf = lane >> 5;
+      ee_k = L.sc[F3_EE];
+      phi = 1.0;
+      double vscale = 1.0;
+      if (p.robust) {
+        phi = (lam + ee_k * invN) * fast_rcp(lam + dd);                 // rpsmf.py:133-138
+        vscale = p.alpha * phi;
+      }
+      const double wjn = wj * invN;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) pr[t] = vscale * (pr[t] - L.w[16 * hf + t] * wjn);   // psmf.py:135-138
+    }
+    __syncthreads();                                                     // ---- B3
+    if (try_ns && !done && !failed) { par = 1; it = 1; }
+    while (try_ns && !done && !failed) {
+      F3_DECIDE();
+      if (done || failed) break;
+      par ^= 1;
+      ++it;
+      __syncthreads();
+    }
+    if (!done) {
+      if (try_ns) { ++ctl.c_fail; ctl.ns_skip = 3; }
+      ++ctl.c_sw;
+      __syncthreads();
+      f3_sweep_images(L, r2, tid);
+    } else {
+      ++ctl.c_ns;
+    }
+    ctl.have_prev = true;
+    __syncthreads();                                                     // ---- BF
+  }
+
+  // ---- block end ----
+  if (isV0) {
+    if (b.nb > 0) F3_V0_FINISH_PREV();
+    if (lane == 0) { L.sc[F3_PSCALE] = pscale; L.sc[F3_IOM] = fast_rcp(omega); L.sc[F3_Q] = q; }
+  }
+  __syncthreads();
+  if (isV0) {
+    const int j = lane & 31, hf = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int i = 16 * hf + t;
+      if (i < r && j < r) {
+        st->V[i * r + j] = pr[t];
+        st->Q[i * r + j] = (i == j) ? q : 0.0;
+      }
+    }
+    if (lane < r) st->mu[lane] = L.mub[lane];
+    if (lane == 0) {
+      st->k = b.k0 + b.nb;
+      st->rho = rho; st->lam = lam; st->phi = phi; st->omega = omega; st->ee = ee_k;
+      st->s_done = s_k; st->eta_done = eta_k; st->N_done = Nk;
+      if (*L.errflag && st->err == 0) st->err = (int)(b.k0 + 1);
+      st->ns_valid = 1;
+    }
+  } else if (isV1) {
+#pragma unroll
+    for (int c = 0; c < 32; ++c)
+      if (c < r) b.Acoef[lane * r + c] = pr[c];
+  }
+#undef F3_V0_FINISH_PREV
+}
+
+__global__ __launch_bounds__(F3_NT) void psmf_blk_filter3(BlockParams b) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* sm = reinterpret_cast<double*>(smem_raw);
+  const StepParams& p = b.sp;
+  DevState* st = p.st;
+  const int r = p.r, tid = threadIdx.x, lane = tid & 63;
+  const int role = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: the role branches are scalar branches
+  const int r2 = r + (r & 1);
+  // ---- LDS carve ----
+  F3Lds L;
+  L.sK = sm;
+  L.sA = L.sK + RB * RB;
+  L.sKA = L.sA + RB * RS;
+  L.dump = L.sKA + RB * RS;
+  L.img = L.dump + 2 * 4 * 8 * 64;
+  L.mub = L.img + 2 * 32 * F3_S;
+  L.w = L.mub + RM;
+  L.h = L.w + RM;
+  L.a = L.h + RM;
+  L.Ka = L.a + RB;
+  L.sc = L.Ka + RB;
+  L.nrm = L.sc + F3_NSC;
+  L.hv = L.nrm + 8;
+  L.gp = L.hv + 2;
+  L.tr = L.gp + 2;
+  L.rowbufX = L.tr + 2;
+  L.rowbufY = L.rowbufX + 4 * RM;
+  L.errflag = reinterpret_cast<int*>(L.rowbufY + 4 * RM);
+
+  if (!b.assemble) {
+    for (int idx = tid; idx < RB * RB; idx += F3_NT) L.sK[idx] = b.K[idx];
+  } else {
+    assemble_K<F3_NT>(b, L.sK, L.sA, L.sKA, r, tid);
+  }
+  if (tid == 0) *L.errflag = 0;
+  if (tid < RM) { L.mub[tid] = (tid < r) ? st->mu[tid] : 0.0; L.w[tid] = 0.0; L.h[tid] = 0.0; }
+  if (tid < F3_NSC) L.sc[tid] = 0.0;
+  const bool carried = st->ns_valid != 0;
+  __syncthreads();
+  if (!carried) {
+    // Lbar_1 = (P + q I)^-1 by the direct sweep: both halves run it in lockstep on their own image
+    const int lt = tid & (WG - 1), c32 = lt & 31, rg = lt >> 5;
+    double* im = tid < WG ? L.img : L.img + 32 * F3_S;
+    const double q0 = st->Q[0];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int i = rg + 8 * m;
+      const bool in = (i < r) && (c32 < r);
+      const double pv = st->P[in ? i * r + c32 : 0];
+      im[i * F3_S + c32] = in ? pv + (i == c32 ? q0 : 0.0) : (i == c32 ? 1.0 : 0.0);
+    }
+    __syncthreads();
+    f3_sweep_images(L, r2, tid);          // image X now holds Lbar_1 (ends with a barrier)
+  }
+  if (role < 4) {
+    const int inv = role >> 1;
+    if (role & 1) f3_ns_program<1>(b, L, inv, role, lane, carried);
+    else f3_ns_program<0>(b, L, inv, role, lane, carried);
+  } else {
+    f3_v_program(b, L, role, lane, carried);
+  }
+}
+
+}  // namespace psmf

@@ -692,6 +692,8 @@ __global__ __launch_bounds__(2 * WG) void psmf_blk_filter2(BlockParams b) {
 #pragma unroll
   for (int m = 0; m < M; ++m) Gv[m] = val[m] ? sK[ii[m] * RB + j] : 0.0;
   int ns_skip = 0;                    // steps to wait before the next Newton-Schulz attempt after a failure
+  int c_ns = 0, c_sw = 0, c_it = 0, c_fail = 0;   // diagnostics (uniform over the workgroup)
+  float c_l0 = 0.f, c_l1 = 0.f, c_l2 = 0.f, c_m0 = -99.f;
   double Xp[M];                       // inverse found at the previous step (Newton-Schulz start)
   const bool carried = st->ns_valid != 0;     // uniform: the previous block left Lbar and both inverses behind
   if (carried) {
@@ -842,6 +844,8 @@ __global__ __launch_bounds__(2 * WG) void psmf_blk_filter2(BlockParams b) {
           const double ny = (s_nrm[4] + s_nrm[5]) + (s_nrm[6] + s_nrm[7]);
           const double worst = fmax(nx, ny);
           BLK_COUNT(2 + it, 1);
+          ++c_it;
+          { const float lg = 0.5f * __log10f((float)worst + 1e-38f); if (it == 0) { c_l0 += lg; c_m0 = fmaxf(c_m0, lg); } else if (it == 1) c_l1 += lg; else if (it == 2) c_l2 += lg; }
           if (it == 0) { BLK_COUNT(12, (unsigned long long)(1e6 * sqrt(worst))); }
           double* tsw = xc; xc = xn; xn = tsw;                     // xc now holds the updated iterate
           if (worst < 9e-14) { done = true; break; }               // ||R|| < 3e-7 before the update just made
@@ -853,11 +857,13 @@ __global__ __launch_bounds__(2 * WG) void psmf_blk_filter2(BlockParams b) {
             R1[m] = val[m] ? 0.5 * (xc[ii[m] * NS_S + j] + xc[j * NS_S + ii[m]]) : 0.0;
         } else {
           ns_skip = 3;        // far from the previous inverse (transient): do not pay for the attempt every step
+          ++c_fail;
         }
       } else if (ns_skip > 0) {
         --ns_skip;
       }
       BLK_COUNT(done ? 0 : 1, 1);
+      if (done) ++c_ns; else ++c_sw;
       if (!done) {
         sweep_all<RPAD>(R1, r2, j, ig, X ? rowbufX : rowbufY, errflag);    // R1 <- -(.)^-1; barriers shared by both halves
 #pragma unroll
@@ -958,7 +964,7 @@ __global__ __launch_bounds__(2 * WG) void psmf_blk_filter2(BlockParams b) {
       else { st->XpY[idx] = Xp[m]; st->Lbar[idx] = Lv[m]; }
     }
   }
-  if (tid == 0) st->ns_valid = 1;
+  if (tid == 0) { st->ns_valid = 1; st->cnt[0] += c_ns; st->cnt[1] += c_sw; st->cnt[2] += c_it; st->cnt[3] += c_fail; st->cnt[4] += (long long)(1000.f * c_l0); st->cnt[5] += (long long)(1000.f * c_l1); st->cnt[6] += (long long)(1000.f * c_l2); st->cnt[7] = max(st->cnt[7], (long long)(1000.f * c_m0) + 100000); }
   for (int idx = tid; idx < RB * r; idx += 2 * WG) { const int m = idx / r; b.Acoef[idx] = sA[m * RS + (idx - m * r)]; }
   if (X) {
 #pragma unroll

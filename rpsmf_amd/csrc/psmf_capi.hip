@@ -4,6 +4,7 @@
 #include "../../include/psmf_hip.h"
 #include "psmf_kernels.hip"
 #include "psmf_block.hip"
+#include "psmf_blk3.hip"
 
 #include <rccl/rccl.h>
 
@@ -190,6 +191,11 @@ void launch_blk_gram(psmf_filter* h, const psmf::BlockParams& b, hipStream_t str
   hipLaunchKernelGGL(psmf::psmf_blk_reduce, dim3(psmf::RB * psmf::RB / 128), dim3(128), 0, stream, b, (int)psmf::BLK_GRAM_WG);
 }
 
+bool blk_use_filter3() {
+  static const bool off = getenv("PSMF_FILTER3") && atoi(getenv("PSMF_FILTER3")) == 0;
+  return !off;
+}
+
 bool blk_dual_ok(const psmf_filter* h) {
   static const bool off = getenv("PSMF_BLOCK_DUAL") && atoi(getenv("PSMF_BLOCK_DUAL")) == 0;
   return !off && h->q_iso && h->cfg.coef_update && h->cfg.pbar_predict && h->cfg.eta_full &&
@@ -198,6 +204,10 @@ bool blk_dual_ok(const psmf_filter* h) {
 
 void launch_blk_filter(psmf_filter* h, const psmf::BlockParams& b, hipStream_t stream = nullptr) {
   if (!stream) stream = h->stream;
+  if (blk_dual_ok(h) && h->geo.rpad == 32 && blk_use_filter3()) {
+    hipLaunchKernelGGL(psmf::psmf_blk_filter3, dim3(1), dim3(psmf::F3_NT), psmf::blk_filter3_lds_bytes(), stream, b);
+    return;
+  }
   if (blk_dual_ok(h)) {
     const size_t lds2 = psmf::blk_filter2_lds_bytes();
     switch (h->geo.rpad) {
@@ -516,6 +526,7 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
     const size_t alds = psmf::blk_apply_lds_bytes();
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_apply_mfma<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)alds));
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_apply_mfma<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)alds));
+    CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_filter3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psmf::blk_filter3_lds_bytes()));
     const size_t flds2 = psmf::blk_filter2_lds_bytes();
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_filter2<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds2));
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_filter2<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds2));
@@ -539,6 +550,7 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
   sp.track_g = (cfg->eta_full || cfg->coef_update) ? 1 : 0;
   sp.external_reduce = 0;
   sp.use_ns = (getenv("PSMF_NS") && atoi(getenv("PSMF_NS")) == 0) ? 0 : 1;
+  sp.ns_tol2 = getenv("PSMF_NS_TOL") ? atof(getenv("PSMF_NS_TOL")) * atof(getenv("PSMF_NS_TOL")) : 9e-14;
   sp.alpha = cfg->alpha; sp.beta = cfg->beta;
   sp.lr = cfg->adam_lr; sp.lr_end = cfg->adam_lr_end; sp.lr_steps = cfg->adam_lr_steps;
   sp.b1 = cfg->adam_b1; sp.b2 = cfg->adam_b2;
@@ -894,6 +906,17 @@ int psmf_geometry(psmf_handle h, int32_t* out7) {
   if (!h || !out7) return PSMF_ERR_ARG;
   out7[0] = h->geo.n_sweep_wg; out7[1] = h->geo.rows_per_wg; out7[2] = h->geo.rp; out7[3] = h->geo.gs;
   out7[4] = h->chunk; out7[5] = h->engine; out7[6] = h->block_steps;
+  return PSMF_OK;
+}
+
+int psmf_counters(psmf_handle h, int64_t* out8, int reset) {
+  if (!h || !out8) return PSMF_ERR_ARG;
+  if (set_device(h) != PSMF_OK) return PSMF_ERR_HIP;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  long long c[8];
+  HIP_TRY(h, hipMemcpy(c, h->st->cnt, sizeof(c), hipMemcpyDeviceToHost));
+  for (int i = 0; i < 8; ++i) out8[i] = c[i];
+  if (reset) HIP_TRY(h, hipMemset(h->st->cnt, 0, sizeof(c)));
   return PSMF_OK;
 }
 

@@ -35,6 +35,8 @@ struct DevState {
   long long k;            // number of finished steps = 0-based series index of the current step
   int err;                // != 0: numeric failure (singular system) at step err
   int ns_valid;           // Lbar / XpX / XpY describe the current state (cleared by every host state upload)
+  long long cnt[8];       // diagnostics of the blocked filter: [0] steps inverted by Newton-Schulz, [1] by the sweep,
+                          // [2] Newton-Schulz iterations in total, [3] failed Newton-Schulz attempts (psmf_counters)
 };
 
 struct StepParams {
@@ -52,6 +54,7 @@ struct StepParams {
   int external_reduce;  // 1: partial sums were reduced into st->red (multi-GPU)
   int use_ns;           // 1: Newton-Schulz refinement of the r x r inverses (f64 MFMA), sweep as fallback
   double alpha, beta, lr, lr_end, lr_steps, b1, b2;
+  double ns_tol2;       // Newton-Schulz: squared Frobenius residual accepted BEFORE the last update (the update squares it)
 };
 
 }  // namespace psmf
