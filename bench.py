@@ -203,11 +203,11 @@ def main():
         t_filter = f.time_kernel(0, 20)
         t_gram = f.time_kernel(1, 50)
         t_apply = f.time_kernel(2, 50)
-        kernel, kernel_us, steps_per_launch = "psmf_blk_filter2", t_filter, B
+        kernel, kernel_us, steps_per_launch = "psmf_blk_filter3", t_filter, B
         zbytes = (4.0 if args.storage == "f32" else 8.0) * d_local * 64
         extra = {"steps_per_launch": B,
-                 "kernels_us": {"psmf_blk_filter2": t_filter, "psmf_blk_gram_mfma+reduce": t_gram, "psmf_blk_apply_mfma": t_apply},
-                 "bulk_kernels_GBps": {"gram (reads Z)": zbytes / (t_gram * 1e-6) / 1e9,
+                 "kernels_us": {"psmf_blk_filter3": t_filter, "psmf_blk_xgram2+xreduce2": t_gram, "psmf_blk_apply2": t_apply},
+                 "bulk_kernels_GBps": {"cross-Gram (reads Z and the next series block)": 1.5 * zbytes / (t_gram * 1e-6) / 1e9,
                                        "apply (reads Z, writes C and y_hat)": 2 * zbytes / (t_apply * 1e-6) / 1e9},
                  "note": "blocked engine: the filter kernel is a latency-bound chain of r x r stages (one workgroup); "
                          "achieved = step-at-a-time algorithmic bytes of the B steps it advances / its duration"}

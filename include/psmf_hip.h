@@ -140,7 +140,7 @@ int psmf_run_timed(psmf_handle h, int64_t k_begin, int64_t k_end, float* ms);
 /* average duration (microseconds) of `iters` back-to-back launches of one kernel of the step
  * on the handle's stream, HIP-event timed: which = 0 row sweep (+ concurrent r x r solve),
  * 1 = serial r x r stage.  Blocked engine: 0 = coefficient-space filter of one full block,
- * 1 = block Gram (+ reduction), 2 = apply.  State is saved and restored around the measurement. */
+ * 1 = cross-Gram of the next block (+ reduction), 2 = apply.  State is saved and restored around the measurement. */
 int psmf_time_kernel(psmf_handle h, int which, int iters, float* avg_us);
 /* geometry actually used: out[0] = sweep workgroups, out[1] = rows per workgroup,
  * out[2] = padded row length (elements), out[3] = lanes per row, out[4] = graph chunk steps,

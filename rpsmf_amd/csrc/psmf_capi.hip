@@ -5,6 +5,7 @@
 #include "psmf_kernels.hip"
 #include "psmf_block.hip"
 #include "psmf_blk3.hip"
+#include "psmf_bulk.hip"
 
 #include <rccl/rccl.h>
 
@@ -191,6 +192,34 @@ void launch_blk_gram(psmf_filter* h, const psmf::BlockParams& b, hipStream_t str
   hipLaunchKernelGGL(psmf::psmf_blk_reduce, dim3(psmf::RB * psmf::RB / 128), dim3(128), 0, stream, b, (int)psmf::BLK_GRAM_WG);
 }
 
+// streaming bulk kernels (psmf_bulk.hip): float32 storage, d_local a multiple of 4, 16 <= r <= 32
+bool blk_bulk2_ok(const psmf_filter* h) {
+  static const bool off = getenv("PSMF_BULK2") && atoi(getenv("PSMF_BULK2")) == 0;
+  return !off && blk_use_mfma() && h->cfg.storage == PSMF_F32 && (h->cfg.d_local % 4) == 0 && h->cfg.r >= 16 && h->cfg.r <= 32 &&
+         (h->geo.rp % 4) == 0;
+}
+
+void launch_blk_xgram(psmf_filter* h, const psmf::BlockParams& x, double* xg, hipStream_t stream) {
+  const size_t xg_elems = (size_t)(psmf::RB + psmf::XGB) * psmf::XGB;
+  if (blk_bulk2_ok(h)) {
+    const int nct = (h->block_steps + 15) / 16;
+    const size_t lds = psmf::blk_xgram2_lds_bytes();
+    if (nct <= 2) {
+      hipLaunchKernelGGL(psmf::psmf_blk_xgram2<2>, dim3(psmf::BK_XG_WG), dim3(psmf::BK_NT), lds, stream, x);
+      hipLaunchKernelGGL(psmf::psmf_blk_xreduce2<2>, dim3(6 * 2 * 256 / 32), dim3(256), 0, stream, (const double*)x.XGpart, xg, (int)psmf::BK_XG_WG);
+    } else {
+      hipLaunchKernelGGL(psmf::psmf_blk_xgram2<3>, dim3(psmf::BK_XG_WG), dim3(psmf::BK_NT), lds, stream, x);
+      hipLaunchKernelGGL(psmf::psmf_blk_xreduce2<3>, dim3(7 * 3 * 256 / 32), dim3(256), 0, stream, (const double*)x.XGpart, xg, (int)psmf::BK_XG_WG);
+    }
+    return;
+  }
+  if (h->cfg.storage == PSMF_F64)
+    hipLaunchKernelGGL(psmf::psmf_blk_xgram_mfma<double>, dim3(psmf::BLK_GRAM_WG), dim3(psmf::WG), 0, stream, x);
+  else
+    hipLaunchKernelGGL(psmf::psmf_blk_xgram_mfma<float>, dim3(psmf::BLK_GRAM_WG), dim3(psmf::WG), 0, stream, x);
+  hipLaunchKernelGGL(psmf::psmf_blk_xreduce, dim3((int)(xg_elems / 128)), dim3(128), 0, stream, x, xg, (int)psmf::BLK_GRAM_WG);
+}
+
 bool blk_use_filter3() {
   static const bool off = getenv("PSMF_FILTER3") && atoi(getenv("PSMF_FILTER3")) == 0;
   return !off;
@@ -227,6 +256,13 @@ void launch_blk_filter(psmf_filter* h, const psmf::BlockParams& b, hipStream_t s
 
 void launch_blk_apply(psmf_filter* h, const psmf::BlockParams& b, hipStream_t stream = nullptr) {
   if (!stream) stream = h->stream;
+  if (blk_bulk2_ok(h)) {
+    const int nyc = (h->block_steps + 15) / 16;
+    const size_t lds = psmf::blk_apply2_lds_bytes();
+    if (nyc <= 2) hipLaunchKernelGGL(psmf::psmf_blk_apply2<2>, dim3(256), dim3(psmf::BK_NT), lds, stream, b);
+    else hipLaunchKernelGGL(psmf::psmf_blk_apply2<3>, dim3(256), dim3(psmf::BK_NT), lds, stream, b);
+    return;
+  }
   if (blk_use_mfma()) {
     const int nslab = (h->cfg.d_local + 15) / 16;
     int g = (nslab + 3) / 4;
@@ -289,11 +325,7 @@ int enqueue_blocks_pipelined(psmf_filter* h, int64_t k_begin, int64_t k_end) {
       x.k1 = k0_of(bi + 1);
       x.nb1 = nb_of(bi + 1);
       double* xg = h->XG + (size_t)((bi + 1) & 1) * xg_elems;
-      if (h->cfg.storage == PSMF_F64)
-        hipLaunchKernelGGL(psmf::psmf_blk_xgram_mfma<double>, dim3(psmf::BLK_GRAM_WG), dim3(psmf::WG), 0, h->bulk, x);
-      else
-        hipLaunchKernelGGL(psmf::psmf_blk_xgram_mfma<float>, dim3(psmf::BLK_GRAM_WG), dim3(psmf::WG), 0, h->bulk, x);
-      hipLaunchKernelGGL(psmf::psmf_blk_xreduce, dim3((int)(xg_elems / 128)), dim3(128), 0, h->bulk, x, xg, (int)psmf::BLK_GRAM_WG);
+      launch_blk_xgram(h, x, xg, h->bulk);
       if (h->use_coll) NCCL_TRY(h, ncclAllReduce(xg, xg, xg_elems, ncclDouble, ncclSum, h->comm, h->bulk));
       HIP_TRY(h, hipEventRecord(h->evX[(bi + 1) & 3], h->bulk));
     }
@@ -527,6 +559,10 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_apply_mfma<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)alds));
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_apply_mfma<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)alds));
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_filter3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psmf::blk_filter3_lds_bytes()));
+    CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_xgram2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psmf::blk_xgram2_lds_bytes()));
+    CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_xgram2<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psmf::blk_xgram2_lds_bytes()));
+    CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_apply2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psmf::blk_apply2_lds_bytes()));
+    CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_apply2<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psmf::blk_apply2_lds_bytes()));
     const size_t flds2 = psmf::blk_filter2_lds_bytes();
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_filter2<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds2));
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_filter2<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds2));
@@ -854,7 +890,17 @@ int psmf_time_kernel(psmf_handle h, int which, int iters, float* avg_us) {
     launch_blk_filter(h, b);
     auto one = [&]() {
       if (which == 0) { HIP_TRY(h, hipMemcpyAsync(h->st, ssave, sizeof(DevState), hipMemcpyDeviceToDevice, h->stream)); launch_blk_filter(h, b); }
-      else if (which == 1) launch_blk_gram(h, b);
+      else if (which == 1) {
+        // the per-block d-sized contraction: the cross-Gram for the next block (+ reduction) when the series holds
+        // two blocks, else the plain block Gram
+        if (h->T_cap >= 2 * (int64_t)nb) {
+          psmf::BlockParams x = b;
+          x.k1 = b.k0 + nb; x.nb1 = nb;
+          launch_blk_xgram(h, x, h->XG, h->stream);
+        } else {
+          launch_blk_gram(h, b);
+        }
+      }
       else launch_blk_apply(h, b);
       return (int)PSMF_OK;
     };
