@@ -61,10 +61,14 @@ __device__ __forceinline__ double wave_sum_f64_dpp(double v) {
   return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 
-// bit e of a per-lane mask (element e = (ti * 2 + tj) * 4 + q of the T-layout).  The masks are loop invariants: without
-// the opaque F3_KEEP() in the loop the compiler hoists every test into an SGPR pair and spills (179 of them).
-#define F3_BIT(m, e) ((((m) >> (e)) & 1) != 0)
-#define F3_KEEP(m) asm volatile("" : "+v"(m))
+// Which T-layout elements lie inside the r x r matrix / on the diagonal (16 < r <= 32): tile (0, 0) is always inside,
+// column tile 1 is inside iff (l & 15) < r - 16, row tile 1 iff (l >> 4) + 4 q < r - 16; only the tiles (t, t) hold
+// diagonal elements, where (l & 15) == (l >> 4) + 4 q.  Nine lane predicates (kept in SGPR pairs) in all.
+struct F3Mask {
+  bool c1, r1[4], dg[4];
+};
+#define F3_VALID(mk, ti, tj, q) (((ti) == 0 || (mk).r1[q]) && ((tj) == 0 || (mk).c1))
+#define F3_DIAG(mk, ti, tj, q) (((ti) == (tj)) && (mk).dg[q])
 
 // scalar slots
 enum { F3_KAPPA = 0, F3_N, F3_INVN, F3_EE, F3_IOM, F3_Q, F3_IQ, F3_PSCALE, F3_NSC = 16 };
@@ -90,9 +94,9 @@ struct F3Lds {
   int* errflag;
 };
 
+// dynamic part (block Gram, assembly scratch, sweep images and row buffers); the per-step vectors are static LDS
 inline size_t blk_filter3_lds_bytes() {
-  const size_t doubles = (size_t)RB * RB + 2 * (size_t)RB * RS + 2 * 4 * 8 * 64 + 2 * 32 * F3_S + 3 * RM + 2 * RB + F3_NSC + 8 + 6 +
-                         8 * RM + 2;
+  const size_t doubles = (size_t)RB * RB + 2 * (size_t)RB * RS + 2 * 32 * F3_S + 8 * RM + 2;
   return (doubles * 8 + 15) & ~(size_t)15;
 }
 
@@ -101,7 +105,7 @@ inline size_t blk_filter3_lds_bytes() {
 // Returns this lane's share of ||R_c||_F^2.
 template <int C>
 __device__ __forceinline__ double f3_ns_iter(const double (&Mf)[16], const double (&Xc)[8], const double (&Xo)[8], double (&Xn)[8],
-                                             const int dmask) {
+                                             const F3Mask& mk) {
   f64x4 acc[2];
 #pragma unroll
   for (int ti = 0; ti < 2; ++ti) {
@@ -118,7 +122,7 @@ __device__ __forceinline__ double f3_ns_iter(const double (&Mf)[16], const doubl
   for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const double v = (F3_BIT(dmask, (ti * 2 + C) * 4 + q) ? 1.0 : 0.0) - acc[ti][q];
+      const double v = (F3_DIAG(mk, ti, C, q) ? 1.0 : 0.0) - acc[ti][q];
       R[ti * 4 + q] = v;
       nrm += v * v;
     }
@@ -190,7 +194,10 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
   double* imgX = L.img;
   double* imgY = L.img + 32 * F3_S;
   double G[16], L0[16], Xc[8], Xo[8];
-  int vmask = 0, dmask = 0;      // T-layout element e = (ti * 2 + tj) * 4 + q: inside the r x r matrix / on the diagonal
+  F3Mask mk;
+  mk.c1 = lcol < r - 16;
+#pragma unroll
+  for (int qq = 0; qq < 4; ++qq) { mk.r1[qq] = lrow + 4 * qq < r - 16; mk.dg[qq] = lcol == lrow + 4 * qq; }
 #pragma unroll
   for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
@@ -200,8 +207,6 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
         const int row = 16 * ti + lrow + 4 * qq, col = 16 * tj + lcol;
         const bool in = row < r && col < r;
         const int e = (ti * 2 + tj) * 4 + qq;
-        vmask |= in ? (1 << e) : 0;
-        dmask |= (row == col) ? (1 << e) : 0;
         G[e] = in ? L.sK[row * RB + col] : 0.0;                              // G_0: exact Gram of the stored C
         const double l0 = carried ? st->Lbar[in ? row * r + col : 0] : imgX[row * F3_S + col];
         L0[e] = in ? l0 : 0.0;
@@ -237,12 +242,53 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
   }
   __syncthreads();                                                       // ---- init barrier
 
+  // After a step's inversion: W (both columns) -> L0 = I / q - W / q^2 (Lbar_{k+1} = L0 / omega_k), and for the X waves
+  // <G_k, P+> and tr G_k of the own column (eta of the next step).  Runs in the next step's phase 0, while wave 4 forms
+  // w, s and kappa, and once more after the last step.  q is the one W was formed with: F3_IQ is rewritten by wave 4 in
+  // phase 0, so the value is taken over in phase 1 (iq_w).
+#define F3_LBAR_AND_TRACES()                                                                               \
+  do {                                                                                                     \
+    const double iq_ = iq_w, iq2_ = iq_w * iq_w;                                                           \
+    _Pragma("unroll") for (int ti_ = 0; ti_ < 2; ++ti_)                                                    \
+      _Pragma("unroll") for (int tj_ = 0; tj_ < 2; ++tj_) {                                                \
+        double wv_[4];                                                                                     \
+        if (isY) {                                                                                         \
+          _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) wv_[q_] = (tj_ == C) ? Xc[ti_ * 4 + q_] : Xo[ti_ * 4 + q_]; \
+        } else if (w_from_img) {                                                                           \
+          _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) wv_[q_] = imgY[(16 * ti_ + lrow + 4 * q_) * F3_S + 16 * tj_ + lcol]; \
+        } else {                                                                                           \
+          const f64x2* d2_ = reinterpret_cast<const f64x2*>(L.dump) + (size_t)((w_par * 4 + 2 + tj_) * 4) * 64 + lane; \
+          const f64x2 v0_ = d2_[(ti_ * 2) * 64], v1_ = d2_[(ti_ * 2 + 1) * 64];                            \
+          wv_[0] = v0_[0]; wv_[1] = v0_[1]; wv_[2] = v1_[0]; wv_[3] = v1_[1];                               \
+        }                                                                                                  \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                 \
+          const int e_ = (ti_ * 2 + tj_) * 4 + q_;                                                         \
+          const double l_ = (F3_DIAG(mk, ti_, tj_, q_) ? iq_ : 0.0) - wv_[q_] * iq2_;                      \
+          L0[e_] = F3_VALID(mk, ti_, tj_, q_) ? l_ : 0.0;                                                  \
+        }                                                                                                  \
+      }                                                                                                    \
+    if (isX) {                                                                                             \
+      double g1_ = 0.0, t1_ = 0.0;                                                                         \
+      _Pragma("unroll") for (int ti_ = 0; ti_ < 2; ++ti_)                                                  \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                 \
+          const double g_ = G[(ti_ * 2 + C) * 4 + q_];                                                     \
+          g1_ += g_ * Xc[ti_ * 4 + q_];                      /* G is zero outside r x r */                 \
+          t1_ += F3_DIAG(mk, ti_, C, q_) ? g_ : 0.0;                                                       \
+        }                                                                                                  \
+      g1_ = wave_sum_f64_dpp(g1_);                                                                         \
+      t1_ = wave_sum_f64_dpp(t1_);                                                                         \
+      if (lane == 0) { L.gp[C] = g1_; L.tr[C] = t1_; }                                                     \
+    }                                                                                                      \
+  } while (0)
+
   F3Ctl ctl = {carried, 0, 0, 0, 0, 0};
+  int w_par = 0;
+  bool w_from_img = false;
+  double iq_w = 0.0;
   BLK_T0();
   for (int jb = 0; jb < b.nb; ++jb) {
-    F3_KEEP(vmask);
-    F3_KEEP(dmask);
-    // phase 0: nothing to do (wave 4 forms w, s, kappa)
+    // phase 0 (wave 4 forms w, s, kappa meanwhile): what the step that just ended left to do off the critical path
+    if (jb > 0) F3_LBAR_AND_TRACES();
     BLK_T(0);
     __syncthreads();                                                     // ---- B1
     BLK_T(1);
@@ -254,16 +300,26 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
     {
       const double kap = L.sc[F3_KAPPA], iom = L.sc[F3_IOM], iq = L.sc[F3_IQ];
       const double ib = isY ? 1.0 / p.beta : 1.0, dq = isY ? iq : 0.0;
+      iq_w = iq;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const double dg = F3_BIT(dmask, e) ? 1.0 : 0.0;
-        const double m = (L0[e] * iom + kap * G[e]) * ib + dg * dq;
-        Mf[e] = F3_BIT(vmask, e) ? m : dg;
-      }
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) {
+            const int e = (ti * 2 + tj) * 4 + qq;
+            double m = (L0[e] * iom + kap * G[e]) * ib;
+            if (ti == tj) {
+              m += F3_DIAG(mk, ti, tj, qq) ? dq : 0.0;
+              Mf[e] = F3_VALID(mk, ti, tj, qq) ? m : (F3_DIAG(mk, ti, tj, qq) ? 1.0 : 0.0);
+            } else {
+              Mf[e] = F3_VALID(mk, ti, tj, qq) ? m : 0.0;
+            }
+          }
     }
 #define F3_ITERATE(parity_out)                                                                             \
   do {                                                                                                     \
-    const double nr_ = f3_ns_iter<C>(Mf, Xc, Xo, Xn, dmask);                                               \
+    const double nr_ = f3_ns_iter<C>(Mf, Xc, Xo, Xn, mk);                                               \
     const float nw_ = wave_sum_f32_dpp((float)nr_);                                                        \
     f64x2* dp_ = reinterpret_cast<f64x2*>(L.dump) + (size_t)(((parity_out) * 4 + role) * 4) * 64 + lane;   \
     _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) dp_[e_ * 64] = f64x2{Xn[2 * e_], Xn[2 * e_ + 1]};    \
@@ -342,61 +398,29 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
       ++ctl.c_ns;
     }
     ctl.have_prev = true;
-    // =============================== phase F ===============================
-    {
-      // W (both columns) -> L0 = I / q - W / q^2  (Lbar_{k+1} = L0 / omega_k)
-      const double iq = L.sc[F3_IQ];
-      const double iq2 = iq * iq;
+    // =============================== phase F: v = P+ h, mu (the only work between the inversion and the next step) ===============================
+    w_par = par;
+    w_from_img = from_img;
+    if (isX) {
+      // v = P+ h (own column, by symmetry), mu_k = mu_bar + kappa v (psmf.py:155-159), h.v
+      const double kap = L.sc[F3_KAPPA];
+      double vp = 0.0;
 #pragma unroll
       for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
-        for (int tj = 0; tj < 2; ++tj) {
-          double wv[4];
-          if (isY) {
-#pragma unroll
-            for (int qq = 0; qq < 4; ++qq) wv[qq] = (tj == C) ? Xc[ti * 4 + qq] : Xo[ti * 4 + qq];
-          } else if (from_img) {
-#pragma unroll
-            for (int qq = 0; qq < 4; ++qq) wv[qq] = imgY[(16 * ti + lrow + 4 * qq) * F3_S + 16 * tj + lcol];
-          } else {
-            const f64x2* dq2 = reinterpret_cast<const f64x2*>(L.dump) + (size_t)((par * 4 + 2 + tj) * 4) * 64 + lane;
-            const f64x2 v0 = dq2[(ti * 2) * 64], v1 = dq2[(ti * 2 + 1) * 64];
-            wv[0] = v0[0]; wv[1] = v0[1]; wv[2] = v1[0]; wv[3] = v1[1];
-          }
-#pragma unroll
-          for (int qq = 0; qq < 4; ++qq) {
-            const int e = (ti * 2 + tj) * 4 + qq;
-            L0[e] = F3_BIT(vmask, e) ? ((F3_BIT(dmask, e) ? iq : 0.0) - wv[qq] * iq2) : 0.0;
-          }
-        }
-      if (isX) {
-        // v = P+ h (own column, by symmetry), mu_k = mu_bar + kappa v (psmf.py:155-159), h.v, <G_k, P+>, tr G_k
-        const double kap = L.sc[F3_KAPPA];
-        double vp = 0.0, g1 = 0.0, t1 = 0.0;
-#pragma unroll
-        for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-          for (int qq = 0; qq < 4; ++qq) {
-            const double x = Xc[ti * 4 + qq], g = G[(ti * 2 + C) * 4 + qq];
-            vp += x * L.h[16 * ti + lrow + 4 * qq];
-            g1 += g * x;                                               // G is zero outside r x r
-            t1 += F3_BIT(dmask, (ti * 2 + C) * 4 + qq) ? g : 0.0;
-          }
-        vp += __shfl_xor(vp, 16, 64);
-        vp += __shfl_xor(vp, 32, 64);
-        const int j = 16 * C + lcol;
-        const double hj = L.h[j];
-        const double mu_new = L.mub[j] + kap * vp;
-        double hvp = (lrow == 0) ? hj * vp : 0.0;
-        hvp = wave_sum_f64_dpp(hvp);
-        g1 = wave_sum_f64_dpp(g1);
-        t1 = wave_sum_f64_dpp(t1);
-        if (lrow == 0 && j < r) {
-          L.mub[j] = mu_new;                    // random walk: mu_bar_{k+1} = mu_k
-          if (p.mu_hist) p.mu_hist[(size_t)(b.k0 + jb + 1 - p.series_t0) * r + j] = mu_new;
-        }
-        if (lane == 0) { L.hv[C] = hvp; L.gp[C] = g1; L.tr[C] = t1; }
+        for (int qq = 0; qq < 4; ++qq) vp += Xc[ti * 4 + qq] * L.h[16 * ti + lrow + 4 * qq];
+      vp += __shfl_xor(vp, 16, 64);
+      vp += __shfl_xor(vp, 32, 64);
+      const int j = 16 * C + lcol;
+      const double hj = L.h[j];
+      const double mu_new = L.mub[j] + kap * vp;
+      double hvp = (lrow == 0) ? hj * vp : 0.0;
+      hvp = wave_sum_f64_dpp(hvp);
+      if (lrow == 0 && j < r) {
+        L.mub[j] = mu_new;                    // random walk: mu_bar_{k+1} = mu_k
+        if (p.mu_hist) p.mu_hist[(size_t)(b.k0 + jb + 1 - p.series_t0) * r + j] = mu_new;
       }
+      if (lane == 0) L.hv[C] = hvp;
     }
     BLK_T(5);
     __syncthreads();                                                     // ---- BF
@@ -404,6 +428,7 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
   }
   BLK_TOUT();
   // ---- block end ----
+  if (b.nb > 0) F3_LBAR_AND_TRACES();
   __syncthreads();                       // wave 4 has published pscale and 1 / omega of the last step
   const double ps = L.sc[F3_PSCALE], iom = L.sc[F3_IOM];
 #pragma unroll
@@ -426,6 +451,7 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
   if (role == 0 && lane == 0) { st->cnt[0] += ctl.c_ns; st->cnt[1] += ctl.c_sw; st->cnt[2] += ctl.c_it; st->cnt[3] += ctl.c_fail; }
 #undef F3_ITERATE
 #undef F3_FETCH_PARTNER
+#undef F3_LBAR_AND_TRACES
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -435,7 +461,7 @@ __device__ __forceinline__ void f3_v_program(const BlockParams& b, const F3Lds& 
   const StepParams& p = b.sp;
   DevState* st = p.st;
   const int r = p.r, r2 = r + (r & 1), tid = threadIdx.x;
-  const double dd = (double)p.d;
+  const double dd = (double)p.d, idd = 1.0 / dd;
   const bool isV0 = role == 4, isV1 = role == 5, isV2 = role == 6, isV3 = role == 7;
   // persistent registers:  V0: [0,16) V[16 hf + t][j]   V1: A[m][c]   V2: KA[m][c]   V3: A[32 hf + t][c]
   double pr[32];
@@ -486,12 +512,11 @@ __device__ __forceinline__ void f3_v_program(const BlockParams& b, const F3Lds& 
   F3Ctl ctl = {carried, 0, 0, 0, 0, 0};
   for (int jb = 0; jb < b.nb; ++jb) {
     // =============================== phase 0 ===============================
+    double cm = 0.0;                       // V1: a_m, V2: (K a)_m  (kept for the rank-1 update of phase 2)
     if (isV0) {
       const int j = lane & 31, hf = lane >> 5;
       double iom = 1.0;
       if (jb > 0) { F3_V0_FINISH_PREV(); iom = fast_rcp(omega); }
-      const double gpv = pscale * (L.gp[0] + L.gp[1]) + q * (L.tr[0] + L.tr[1]);
-      eta_k = rho + gpv / dd;                                           // psmf.py:121-125
       double part0 = 0.0, part1 = 0.0;
 #pragma unroll
       for (int t = 0; t < 16; t += 2) {
@@ -499,17 +524,11 @@ __device__ __forceinline__ void f3_v_program(const BlockParams& b, const F3Lds& 
         part1 += pr[t + 1] * L.mub[16 * hf + t + 1];
       }
       const double part = part0 + part1;
-      wj = part + __shfl_xor(part, 32, 64);                             // w = V mu_bar
-      const double sj = (hf == 0) ? L.mub[j] * wj : 0.0;
-      s_k = wave_sum_f64_dpp(sj);
-      Nk = s_k + eta_k;                                                 // psmf.py:127-128
-      invN = fast_rcp(Nk);
+      s_k = wave_sum_f64_dpp(part * L.mub[j]);                          // s = mu_bar^T V mu_bar: both halves hold their 16 rows' share
       kappa = fast_rcp(rho + s_k);
+      if (lane == 0) { L.sc[F3_KAPPA] = kappa; L.sc[F3_IOM] = iom; L.sc[F3_Q] = q; L.sc[F3_IQ] = fast_rcp(q); }
+      wj = part + __shfl_xor(part, 32, 64);                             // w = V mu_bar
       if (hf == 0) L.w[j] = wj;
-      if (lane == 0) {
-        L.sc[F3_KAPPA] = kappa; L.sc[F3_N] = Nk; L.sc[F3_INVN] = invN; L.sc[F3_IOM] = iom; L.sc[F3_Q] = q;
-        L.sc[F3_IQ] = 1.0 / q;
-      }
     } else if (isV1 || isV2) {
       double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
@@ -521,10 +540,12 @@ __device__ __forceinline__ void f3_v_program(const BlockParams& b, const F3Lds& 
       }
       const double dot = (a0 + a1) + (a2 + a3);
       if (isV1) {
-        L.a[lane] = (lane == r + jb ? 1.0 : 0.0) - dot;                 // a_j = u_{r+j} - A mu_bar
+        cm = (lane == r + jb ? 1.0 : 0.0) - dot;                        // a_j = u_{r+j} - A mu_bar
+        L.a[lane] = cm;
         b.Bcoef[(size_t)jb * RB + lane] = dot;                          // y_hat_j = Z b_j
       } else {
-        L.Ka[lane] = L.sK[lane * RB + r + jb] - dot;                    // K a_j
+        cm = L.sK[lane * RB + r + jb] - dot;                            // K a_j
+        L.Ka[lane] = cm;
       }
     }
     __syncthreads();                                                     // ---- B1
@@ -547,12 +568,13 @@ __device__ __forceinline__ void f3_v_program(const BlockParams& b, const F3Lds& 
       if (hf == 0) L.h[c] = hc;
       const double e1 = wave_sum_f64_dpp(L.a[lane] * L.Ka[lane]);       // ee = a . K a
       if (lane == 0) L.sc[F3_EE] = e1;
-    } else if (isV1 || isV2) {
-      // rank-1 updates of A (rows) and KA (rows): psmf.py:130-133 in coefficient space
-      const double iN = L.sc[F3_INVN];
-      const double cm = (isV1 ? L.a[lane] : L.Ka[lane]) * iN;
-#pragma unroll
-      for (int c = 0; c < 32; ++c) pr[c] += cm * L.w[c];
+    } else if (isV0) {
+      // eta, N (psmf.py:121-128): <G, Pbar> and tr G were left by the X waves in phase 0
+      const double gpv = pscale * (L.gp[0] + L.gp[1]) + q * (L.tr[0] + L.tr[1]);
+      eta_k = rho + gpv * idd;
+      Nk = s_k + eta_k;
+      invN = fast_rcp(Nk);
+      if (lane == 0) { L.sc[F3_N] = Nk; L.sc[F3_INVN] = invN; }
     }
     __syncthreads();                                                     // ---- B2
     // =============================== phase 2 ===============================
@@ -564,6 +586,11 @@ __device__ __forceinline__ void f3_v_program(const BlockParams& b, const F3Lds& 
       const double wn = L.w[c] * L.sc[F3_INVN];
 #pragma unroll
       for (int t = 0; t < 32; ++t) pr[t] += L.a[32 * hf + t] * wn;
+    } else if (isV1 || isV2) {
+      // rank-1 updates of A (rows) and KA (rows): psmf.py:130-133 in coefficient space
+      const double cn = cm * L.sc[F3_INVN];
+#pragma unroll
+      for (int c = 0; c < 32; ++c) pr[c] += cn * L.w[c];
     } else if (isV0) {
       const int hf = lane >> 5;
       ee_k = L.sc[F3_EE];
@@ -639,13 +666,20 @@ __global__ __launch_bounds__(F3_NT) void psmf_blk_filter3(BlockParams b) {
   const int role = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: the role branches are scalar branches
   const int r2 = r + (r & 1);
   // ---- LDS carve ----
+  // Everything a step touches sits in STATIC LDS: its addresses are compile-time constants that fold into the ds
+  // instructions' immediate offsets.  (Off the dynamic-LDS base the compiler formed (lane part + constant) + base for
+  // every row / column it reads and kept each sum in a VGPR of its own across the loop: 136 spilled registers.)
+  __shared__ __attribute__((aligned(16))) double hot[2 * 4 * 8 * 64 + 3 * RM + 2 * RB + F3_NSC + 8 + 6];
   F3Lds L;
   L.sK = sm;
   L.sA = L.sK + RB * RB;
   L.sKA = L.sA + RB * RS;
-  L.dump = L.sKA + RB * RS;
-  L.img = L.dump + 2 * 4 * 8 * 64;
-  L.mub = L.img + 2 * 32 * F3_S;
+  L.img = L.sKA + RB * RS;
+  L.rowbufX = L.img + 2 * 32 * F3_S;
+  L.rowbufY = L.rowbufX + 4 * RM;
+  L.errflag = reinterpret_cast<int*>(L.rowbufY + 4 * RM);
+  L.dump = hot;
+  L.mub = L.dump + 2 * 4 * 8 * 64;
   L.w = L.mub + RM;
   L.h = L.w + RM;
   L.a = L.h + RM;
@@ -655,9 +689,6 @@ __global__ __launch_bounds__(F3_NT) void psmf_blk_filter3(BlockParams b) {
   L.hv = L.nrm + 8;
   L.gp = L.hv + 2;
   L.tr = L.gp + 2;
-  L.rowbufX = L.tr + 2;
-  L.rowbufY = L.rowbufX + 4 * RM;
-  L.errflag = reinterpret_cast<int*>(L.rowbufY + 4 * RM);
 
   if (!b.assemble) {
     for (int idx = tid; idx < RB * RB; idx += F3_NT) L.sK[idx] = b.K[idx];

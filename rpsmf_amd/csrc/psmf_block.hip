@@ -848,7 +848,7 @@ __global__ __launch_bounds__(2 * WG) void psmf_blk_filter2(BlockParams b) {
           { const float lg = 0.5f * __log10f((float)worst + 1e-38f); if (it == 0) { c_l0 += lg; c_m0 = fmaxf(c_m0, lg); } else if (it == 1) c_l1 += lg; else if (it == 2) c_l2 += lg; }
           if (it == 0) { BLK_COUNT(12, (unsigned long long)(1e6 * sqrt(worst))); }
           double* tsw = xc; xc = xn; xn = tsw;                     // xc now holds the updated iterate
-          if (worst < 9e-14) { done = true; break; }               // ||R|| < 3e-7 before the update just made
+          if (worst < p.ns_tol2) { done = true; break; }            // ||R|| below the tolerance before the update just made
           if (!(worst < 0.09) || it == 7) break;                   // too far (||R|| > 0.3) or not converging
         }
         if (done) {
