@@ -70,6 +70,27 @@ struct F3Mask {
 #define F3_VALID(mk, ti, tj, q) (((ti) == 0 || (mk).r1[q]) && ((tj) == 0 || (mk).c1))
 #define F3_DIAG(mk, ti, tj, q) (((ti) == (tj)) && (mk).dg[q])
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt: the y_hat coefficients and the
+// mean history are stored to global memory inside the step loop, and every barrier behind such a store waited for its
+// acknowledgement (~400 cycles per barrier, measured with the stamps).  Nothing in the loop READS global memory written
+// in the loop, so LDS order is all the steps need.
+__device__ __forceinline__ void f3_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// x + (x of the lane 16 rows over) and x + (x of the lane in the other half): v_permlane16_swap / v_permlane32_swap
+// (gfx950) exchange whole 16-lane rows between two registers in the VALU; ds_bpermute costs an LDS round trip.
+__device__ __forceinline__ double xor16_sum_f64(double x) {
+  const unsigned lo = __double2loint(x), hi = __double2hiint(x);
+  const auto l2 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto h2 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __hiloint2double(h2[0], l2[0]) + __hiloint2double(h2[1], l2[1]);
+}
+__device__ __forceinline__ double xor32_sum_f64(double x) {
+  const unsigned lo = __double2loint(x), hi = __double2hiint(x);
+  const auto l2 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto h2 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double(h2[0], l2[0]) + __hiloint2double(h2[1], l2[1]);
+}
+
 // scalar slots
 enum { F3_KAPPA = 0, F3_N, F3_INVN, F3_EE, F3_IOM, F3_Q, F3_IQ, F3_PSCALE, F3_NSC = 16 };
 
@@ -240,7 +261,7 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
     t1 = wave_sum_f64_dpp(t1);
     if (lane == 0) { L.gp[C] = g1; L.tr[C] = t1; }
   }
-  __syncthreads();                                                       // ---- init barrier
+  f3_barrier();                                                       // ---- init barrier
 
   // After a step's inversion: W (both columns) -> L0 = I / q - W / q^2 (Lbar_{k+1} = L0 / omega_k), and for the X waves
   // <G_k, P+> and tr G_k of the own column (eta of the next step).  Runs in the next step's phase 0, while wave 4 forms
@@ -290,15 +311,17 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
     // phase 0 (wave 4 forms w, s, kappa meanwhile): what the step that just ended left to do off the critical path
     if (jb > 0) F3_LBAR_AND_TRACES();
     BLK_T(0);
-    __syncthreads();                                                     // ---- B1
+    f3_barrier();                                                     // ---- B1
     BLK_T(1);
     // =============================== phase 1: M, first iteration ===============================
     const bool try_ns = ctl.have_prev && p.use_ns && ctl.ns_skip == 0;
     if (!try_ns && ctl.ns_skip > 0) --ctl.ns_skip;
     double Mf[16], Xn[8];
+    double hrow[8], h_j = 0.0, mub_j = 0.0, kap_k = 0.0;     // X waves: operands of phase F, loaded in phase 2
     int par = 0;
     {
       const double kap = L.sc[F3_KAPPA], iom = L.sc[F3_IOM], iq = L.sc[F3_IQ];
+      kap_k = kap;
       const double ib = isY ? 1.0 / p.beta : 1.0, dq = isY ? iq : 0.0;
       iq_w = iq;
 #pragma unroll
@@ -333,7 +356,7 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
   } while (0)
     if (try_ns) F3_ITERATE(0);
     BLK_T(2);
-    __syncthreads();                                                     // ---- B2
+    f3_barrier();                                                     // ---- B2
     BLK_T(1);
     // =============================== phase 2: second iteration, G update ===============================
     bool done = false, failed = !try_ns;
@@ -357,10 +380,13 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
           const double hi = L.h[16 * ti + lrow + 4 * qq], wi = L.w[16 * ti + lrow + 4 * qq];
 #pragma unroll
           for (int tj = 0; tj < 2; ++tj) G[(ti * 2 + tj) * 4 + qq] += (hi * wcol[tj] + wi * hcol[tj]) * iN + e2 * (wi * wcol[tj]);
+          hrow[ti * 4 + qq] = hi;
         }
+      h_j = hcol[C];
+      mub_j = L.mub[16 * C + lcol];
     }
     BLK_T(3);
-    __syncthreads();                                                     // ---- B3
+    f3_barrier();                                                     // ---- B3
     BLK_T(1);
     // =============================== further iterations ===============================
     if (try_ns && !done && !failed) { par = 1; it = 1; }
@@ -371,7 +397,7 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
       F3_ITERATE(par ^ 1);
       par ^= 1;
       ++it;
-      __syncthreads();
+      f3_barrier();
     }
     BLK_T(4);
     // `par` = parity of the dump that holds the columns published by the last iteration that ran
@@ -384,7 +410,7 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
       for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) im[(16 * ti + lrow + 4 * qq) * F3_S + 16 * C + lcol] = Mf[(ti * 2 + C) * 4 + qq];
-      __syncthreads();
+      f3_barrier();
       f3_sweep_images(L, r2, tid);
 #pragma unroll
       for (int ti = 0; ti < 2; ++ti)
@@ -402,34 +428,30 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
     w_par = par;
     w_from_img = from_img;
     if (isX) {
-      // v = P+ h (own column, by symmetry), mu_k = mu_bar + kappa v (psmf.py:155-159), h.v
-      const double kap = L.sc[F3_KAPPA];
-      double vp = 0.0;
+      // v = P+ h (own column, by symmetry), mu_k = mu_bar + kappa v (psmf.py:155-159); h.v for omega (rPSMF only)
+      double vp0 = 0.0, vp1 = 0.0;
 #pragma unroll
-      for (int ti = 0; ti < 2; ++ti)
-#pragma unroll
-        for (int qq = 0; qq < 4; ++qq) vp += Xc[ti * 4 + qq] * L.h[16 * ti + lrow + 4 * qq];
-      vp += __shfl_xor(vp, 16, 64);
-      vp += __shfl_xor(vp, 32, 64);
+      for (int qq = 0; qq < 4; ++qq) { vp0 += Xc[qq] * hrow[qq]; vp1 += Xc[4 + qq] * hrow[4 + qq]; }
+      const double vp = xor32_sum_f64(xor16_sum_f64(vp0 + vp1));
       const int j = 16 * C + lcol;
-      const double hj = L.h[j];
-      const double mu_new = L.mub[j] + kap * vp;
-      double hvp = (lrow == 0) ? hj * vp : 0.0;
-      hvp = wave_sum_f64_dpp(hvp);
+      const double mu_new = mub_j + kap_k * vp;
       if (lrow == 0 && j < r) {
         L.mub[j] = mu_new;                    // random walk: mu_bar_{k+1} = mu_k
         if (p.mu_hist) p.mu_hist[(size_t)(b.k0 + jb + 1 - p.series_t0) * r + j] = mu_new;
       }
-      if (lane == 0) L.hv[C] = hvp;
+      if (p.robust) {
+        const double hvp = wave_sum_f64_dpp((lrow == 0) ? h_j * vp : 0.0);
+        if (lane == 0) L.hv[C] = hvp;
+      }
     }
     BLK_T(5);
-    __syncthreads();                                                     // ---- BF
+    f3_barrier();                                                     // ---- BF
     BLK_T(1);
   }
   BLK_TOUT();
   // ---- block end ----
   if (b.nb > 0) F3_LBAR_AND_TRACES();
-  __syncthreads();                       // wave 4 has published pscale and 1 / omega of the last step
+  f3_barrier();                       // wave 4 has published pscale and 1 / omega of the last step
   const double ps = L.sc[F3_PSCALE], iom = L.sc[F3_IOM];
 #pragma unroll
   for (int ti = 0; ti < 2; ++ti)
@@ -463,6 +485,10 @@ __device__ __forceinline__ void f3_v_program(const BlockParams& b, const F3Lds& 
   const int r = p.r, r2 = r + (r & 1), tid = threadIdx.x;
   const double dd = (double)p.d, idd = 1.0 / dd;
   const bool isV0 = role == 4, isV1 = role == 5, isV2 = role == 6, isV3 = role == 7;
+  // Each vector wave shares its SIMD with an inversion wave.  At equal priority its ~60 VALU instructions per phase were
+  // issued about one per MFMA (64 cycles) and the barrier waited for THEM (3.7k cycles against 3.1k, stamps); with
+  // priority they issue back to back and cost the MFMA stream a few hundred cycles instead.
+  __builtin_amdgcn_s_setprio(3);
   // persistent registers:  V0: [0,16) V[16 hf + t][j]   V1: A[m][c]   V2: KA[m][c]   V3: A[32 hf + t][c]
   double pr[32];
 #pragma unroll
@@ -491,16 +517,16 @@ __device__ __forceinline__ void f3_v_program(const BlockParams& b, const F3Lds& 
 #pragma unroll
     for (int t = 0; t < 32; ++t) pr[t] = (32 * hf + t == c && c < r) ? 1.0 : 0.0;
   }
-  __syncthreads();                                                       // ---- init barrier
+  f3_barrier();                                                       // ---- init barrier
 
   // scalars of the step that just ended (omega needs v = P+ h): rpsmf.py:155-171
 #define F3_V0_FINISH_PREV()                                               \
   do {                                                                    \
-    const double hPh_ = L.hv[0] + L.hv[1];                                \
-    const double quad_ = kappa * ee_k - kappa * kappa * hPh_;             \
     omega = 1.0;                                                          \
     pscale = 1.0;                                                         \
     if (p.robust) {                                                       \
+      const double hPh_ = L.hv[0] + L.hv[1];                              \
+      const double quad_ = kappa * ee_k - kappa * kappa * hPh_;           \
       omega = (lam + quad_) * fast_rcp(lam + dd);                         \
       pscale = p.beta * omega;                                            \
       rho *= omega;                                                       \
@@ -510,6 +536,7 @@ __device__ __forceinline__ void f3_v_program(const BlockParams& b, const F3Lds& 
   } while (0)
 
   F3Ctl ctl = {carried, 0, 0, 0, 0, 0};
+  BLK_T0();
   for (int jb = 0; jb < b.nb; ++jb) {
     // =============================== phase 0 ===============================
     double cm = 0.0;                       // V1: a_m, V2: (K a)_m  (kept for the rank-1 update of phase 2)
@@ -527,8 +554,7 @@ __device__ __forceinline__ void f3_v_program(const BlockParams& b, const F3Lds& 
       s_k = wave_sum_f64_dpp(part * L.mub[j]);                          // s = mu_bar^T V mu_bar: both halves hold their 16 rows' share
       kappa = fast_rcp(rho + s_k);
       if (lane == 0) { L.sc[F3_KAPPA] = kappa; L.sc[F3_IOM] = iom; L.sc[F3_Q] = q; L.sc[F3_IQ] = fast_rcp(q); }
-      wj = part + __shfl_xor(part, 32, 64);                             // w = V mu_bar
-      if (hf == 0) L.w[j] = wj;
+      wj = part;                                                        // this half's share of w_j; completed in phase 1
     } else if (isV1 || isV2) {
       double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
@@ -548,7 +574,9 @@ __device__ __forceinline__ void f3_v_program(const BlockParams& b, const F3Lds& 
         L.Ka[lane] = cm;
       }
     }
-    __syncthreads();                                                     // ---- B1
+    BLK_T(0);
+    f3_barrier();                                                     // ---- B1
+    BLK_T(1);
     // =============================== phase 1 ===============================
     const bool try_ns = ctl.have_prev && p.use_ns && ctl.ns_skip == 0;
     if (!try_ns && ctl.ns_skip > 0) --ctl.ns_skip;
@@ -564,11 +592,13 @@ __device__ __forceinline__ void f3_v_program(const BlockParams& b, const F3Lds& 
         a3 += pr[t + 3] * L.Ka[32 * hf + t + 3];
       }
       const double part = (a0 + a1) + (a2 + a3);
-      const double hc = part + __shfl_xor(part, 32, 64);                // h = A^T K a
+      const double hc = xor32_sum_f64(part);                            // h = A^T K a
       if (hf == 0) L.h[c] = hc;
       const double e1 = wave_sum_f64_dpp(L.a[lane] * L.Ka[lane]);       // ee = a . K a
       if (lane == 0) L.sc[F3_EE] = e1;
     } else if (isV0) {
+      wj = xor32_sum_f64(wj);                                           // w = V mu_bar
+      if (lane < 32) L.w[lane] = wj;
       // eta, N (psmf.py:121-128): <G, Pbar> and tr G were left by the X waves in phase 0
       const double gpv = pscale * (L.gp[0] + L.gp[1]) + q * (L.tr[0] + L.tr[1]);
       eta_k = rho + gpv * idd;
@@ -576,7 +606,9 @@ __device__ __forceinline__ void f3_v_program(const BlockParams& b, const F3Lds& 
       invN = fast_rcp(Nk);
       if (lane == 0) { L.sc[F3_N] = Nk; L.sc[F3_INVN] = invN; }
     }
-    __syncthreads();                                                     // ---- B2
+    BLK_T(2);
+    f3_barrier();                                                     // ---- B2
+    BLK_T(1);
     // =============================== phase 2 ===============================
     bool done = false, failed = !try_ns;
     int it = 0;
@@ -604,33 +636,37 @@ __device__ __forceinline__ void f3_v_program(const BlockParams& b, const F3Lds& 
 #pragma unroll
       for (int t = 0; t < 16; ++t) pr[t] = vscale * (pr[t] - L.w[16 * hf + t] * wjn);   // psmf.py:135-138
     }
-    __syncthreads();                                                     // ---- B3
+    BLK_T(3);
+    f3_barrier();                                                     // ---- B3
     if (try_ns && !done && !failed) { par = 1; it = 1; }
     while (try_ns && !done && !failed) {
       F3_DECIDE();
       if (done || failed) break;
       par ^= 1;
       ++it;
-      __syncthreads();
+      f3_barrier();
     }
     if (!done) {
       if (try_ns) { ++ctl.c_fail; ctl.ns_skip = 3; }
       ++ctl.c_sw;
-      __syncthreads();
+      f3_barrier();
       f3_sweep_images(L, r2, tid);
     } else {
       ++ctl.c_ns;
     }
     ctl.have_prev = true;
-    __syncthreads();                                                     // ---- BF
+    BLK_T(4);
+    f3_barrier();                                                     // ---- BF
+    BLK_T(1);
   }
+  BLK_TOUT();
 
   // ---- block end ----
   if (isV0) {
     if (b.nb > 0) F3_V0_FINISH_PREV();
     if (lane == 0) { L.sc[F3_PSCALE] = pscale; L.sc[F3_IOM] = fast_rcp(omega); L.sc[F3_Q] = q; }
   }
-  __syncthreads();
+  f3_barrier();
   if (isV0) {
     const int j = lane & 31, hf = lane >> 5;
 #pragma unroll
