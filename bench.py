@@ -209,7 +209,7 @@ def main():
                  "kernels_us": {"psmf_blk_filter3": t_filter, "psmf_blk_xgram2+xreduce2": t_gram, "psmf_blk_apply2": t_apply},
                  "bulk_kernels_GBps": {"cross-Gram (reads Z and the next series block)": 1.5 * zbytes / (t_gram * 1e-6) / 1e9,
                                        "apply (reads Z, writes C and y_hat)": 2 * zbytes / (t_apply * 1e-6) / 1e9},
-                 "note": "blocked engine: the filter kernel is a latency-bound chain of r x r stages (one workgroup); "
+                 "note": "blocked engine: the filter kernel is a latency-bound chain of r x r stages (one workgroup, f64-MFMA Newton-Schulz); "
                          "achieved = step-at-a-time algorithmic bytes of the B steps it advances / its duration"}
     else:
         kernel, kernel_us, steps_per_launch = "psmf_sweep_solve", f.time_kernel(0, 300), 1
