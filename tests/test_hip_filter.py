@@ -321,3 +321,60 @@ def test_argument_errors():
     with pytest.raises(ValueError):
         f.upload_series(np.zeros((4, 11)))
     f.close()
+
+
+@pytest.mark.parametrize("robust", [False, True])
+@pytest.mark.parametrize("d,r,T", [(1004, 17, 200), (2056, 31, 100), (4100, 32, 97), (1600, 24, 130)])
+def test_streaming_block_kernels_edge_shapes(d, r, T, robust):
+    """Role-specialised filter kernel + streaming cross-Gram / apply kernels (f32 storage, d % 4 == 0, 16 <= r <= 32):
+    rows not a multiple of the 16-row tile, odd r (identity padding of the 32 x 32 iterates), r < 32 (three column
+    tiles of the next series block), a short last block, several passes over the series (carried inverses)."""
+    c = _capi()
+    Y, C0 = _problem(d, r, T, 300 + d + r, "t" if robust else "normal")
+    Y = Y.astype(np.float32).astype(np.float64)
+    C0 = C0.astype(np.float32).astype(np.float64)
+    V0, P0, Q = 0.1 * np.eye(r), np.eye(r), 0.1 * np.eye(r)
+    st = O.State(C=C0, V=V0, mu=np.zeros(r), P=P0, Q=Q, rho=1.0, lam=1.8)
+    mode = O.Mode(robust=robust)
+    f = c.DeviceFilter(d, r, storage="f32", engine="block", **_mode_kwargs(mode))
+    assert f.geometry()["block_steps"] == 64 - r
+    f.upload_series(Y)
+    f.set_state(C0, V0, P0, Q, np.zeros(r), rho=1.0, lambda0=1.8)
+    for _ in range(2):                          # second pass: state (and the Newton-Schulz starts) carried
+        st, Yp, _ = O.run_epoch(st, Y, mode, O.RandomWalkDyn())
+        f.run(0, T)
+        s = f.get_state()
+        _compare(s, st, TOL["f32"])
+        assert relerr(f.y_pred(0, T), Yp) < TOL["f32"]
+    cnt = f.counters()
+    assert cnt["ns_steps"] + cnt["sweep_steps"] == 2 * T       # every step inverted by exactly one of the two paths
+    f.close()
+
+
+def test_collective_path_single_rank_streaming_kernels():
+    """As test_collective_path_single_rank_matches_plain, on the f32 path that runs the streaming bulk kernels
+    (cross-Gram all-reduce of the pipelined blocks on the bulk stream)."""
+    import os
+
+    c = _capi()
+    d, r, T = 2000, 32, 150
+    Y, C0 = _problem(d, r, T, 23)
+    Y = Y.astype(np.float32).astype(np.float64)
+    C0 = C0.astype(np.float32).astype(np.float64)
+    out = []
+    for coll in (False, True):
+        if coll:
+            os.environ["PSMF_FORCE_COLLECTIVE"] = "1"
+        try:
+            f = c.DeviceFilter(d, r, storage="f32", engine="block")
+            if coll:
+                f.comm_init(1, 0, c.DeviceFilter.comm_unique_id())
+            f.upload_series(Y)
+            f.set_state(C0, 0.1 * np.eye(r), np.eye(r), 0.1 * np.eye(r), np.zeros(r), rho=1.0, lambda0=0.0)
+            f.run(0, T)
+            out.append(f.get_state())
+            f.close()
+        finally:
+            os.environ.pop("PSMF_FORCE_COLLECTIVE", None)
+    for k in ("C", "V", "mu", "P"):
+        assert relerr(out[1][k], out[0][k]) < 1e-12, k
