@@ -205,6 +205,9 @@ def main():
         t_apply = f.time_kernel(2, 50)
         kernel, kernel_us, steps_per_launch = "psmf_blk_filter3", t_filter, B
         zbytes = (4.0 if args.storage == "f32" else 8.0) * d_local * 64
+        pmc = os.path.join(ROOT, "profiles", "r1_pmc_traffic_block_engine.json")
+        if (d, r, args.storage, world) == (100_000, 32, "f32", 1) and os.path.exists(pmc):
+            traffic = json.load(open(pmc))["traffic_bytes_per_launch"]   # rocprofv3 --pmc passes of this workload (filter kernel)
         extra = {"steps_per_launch": B,
                  "kernels_us": {"psmf_blk_filter3": t_filter, "psmf_blk_xgram2+xreduce2": t_gram, "psmf_blk_apply2": t_apply},
                  "bulk_kernels_GBps": {"cross-Gram (reads Z and the next series block)": 1.5 * zbytes / (t_gram * 1e-6) / 1e9,
