@@ -65,9 +65,10 @@ __device__ __forceinline__ double wave_sum_f64_dpp(double v) {
 // column tile 1 is inside iff (l & 15) < r - 16, row tile 1 iff (l >> 4) + 4 q < r - 16; only the tiles (t, t) hold
 // diagonal elements, where (l & 15) == (l >> 4) + 4 q.  Nine lane predicates (kept in SGPR pairs) in all.
 struct F3Mask {
+  bool full;      // r == 32 (uniform): nothing to mask
   bool c1, r1[4], dg[4];
 };
-#define F3_VALID(mk, ti, tj, q) (((ti) == 0 || (mk).r1[q]) && ((tj) == 0 || (mk).c1))
+#define F3_VALID(mk, ti, tj, q) ((mk).full || (((ti) == 0 || (mk).r1[q]) && ((tj) == 0 || (mk).c1)))
 #define F3_DIAG(mk, ti, tj, q) (((ti) == (tj)) && (mk).dg[q])
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt: the y_hat coefficients and the
@@ -127,16 +128,16 @@ inline size_t blk_filter3_lds_bytes() {
 template <int C>
 __device__ __forceinline__ double f3_ns_iter(const double (&Mf)[16], const double (&Xc)[8], const double (&Xo)[8], double (&Xn)[8],
                                              const F3Mask& mk) {
-  f64x4 acc[2];
+  // the two 16 x 16 output tiles of a product are independent accumulator chains: alternate them, so that no MFMA
+  // waits for the one before it
+  f64x4 acc[2] = {f64x4{0.0, 0.0, 0.0, 0.0}, f64x4{0.0, 0.0, 0.0, 0.0}};
 #pragma unroll
-  for (int ti = 0; ti < 2; ++ti) {
-    acc[ti] = f64x4{0.0, 0.0, 0.0, 0.0};
+  for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+    for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk)
+      for (int ti = 0; ti < 2; ++ti)
         acc[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(Mf[(kt * 2 + ti) * 4 + kk], Xc[kt * 4 + kk], acc[ti], 0, 0, 0);
-  }
   double R[8];
   double nrm = 0.0;
 #pragma unroll
@@ -147,20 +148,23 @@ __device__ __forceinline__ double f3_ns_iter(const double (&Mf)[16], const doubl
       R[ti * 4 + q] = v;
       nrm += v * v;
     }
+  f64x4 a2[2];
 #pragma unroll
-  for (int ti = 0; ti < 2; ++ti) {
-    f64x4 a2 = f64x4{Xc[ti * 4 + 0], Xc[ti * 4 + 1], Xc[ti * 4 + 2], Xc[ti * 4 + 3]};
+  for (int ti = 0; ti < 2; ++ti) a2[ti] = f64x4{Xc[ti * 4 + 0], Xc[ti * 4 + 1], Xc[ti * 4 + 2], Xc[ti * 4 + 3]};
 #pragma unroll
-    for (int kt = 0; kt < 2; ++kt)
+  for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti) {
         // A operand = tile (kt, ti) of X in T-layout: column ti is this wave's own column iff ti == C
         const double aop = (ti == C) ? Xc[kt * 4 + kk] : Xo[kt * 4 + kk];
-        a2 = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, R[kt * 4 + kk], a2, 0, 0, 0);
+        a2[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, R[kt * 4 + kk], a2[ti], 0, 0, 0);
       }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) Xn[ti * 4 + q] = a2[q];
-  }
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Xn[ti * 4 + q] = a2[ti][q];
   return nrm;
 }
 
@@ -214,8 +218,10 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
   const bool isX = inv == 0, isY = inv == 1;
   double* imgX = L.img;
   double* imgY = L.img + 32 * F3_S;
-  double G[16], L0[16], Xc[8], Xo[8];
+  double G[16], Wf[16], Xc[8], Xo[8];       // Wf: W of the last step (zero outside r x r): Lbar = (I / q - W / q^2) / omega
+  const double q0 = st->Q[0];
   F3Mask mk;
+  mk.full = (r == 32);
   mk.c1 = lcol < r - 16;
 #pragma unroll
   for (int qq = 0; qq < 4; ++qq) { mk.r1[qq] = lrow + 4 * qq < r - 16; mk.dg[qq] = lcol == lrow + 4 * qq; }
@@ -229,8 +235,9 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
         const bool in = row < r && col < r;
         const int e = (ti * 2 + tj) * 4 + qq;
         G[e] = in ? L.sK[row * RB + col] : 0.0;                              // G_0: exact Gram of the stored C
+        // the block starts from Lbar itself (carried over, or just formed by the sweep): as a W, q I - q^2 Lbar
         const double l0 = carried ? st->Lbar[in ? row * r + col : 0] : imgX[row * F3_S + col];
-        L0[e] = in ? l0 : 0.0;
+        Wf[e] = in ? ((row == col ? q0 : 0.0) - q0 * q0 * l0) : 0.0;
       }
 #pragma unroll
   for (int ti = 0; ti < 2; ++ti)
@@ -263,13 +270,11 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
   }
   f3_barrier();                                                       // ---- init barrier
 
-  // After a step's inversion: W (both columns) -> L0 = I / q - W / q^2 (Lbar_{k+1} = L0 / omega_k), and for the X waves
-  // <G_k, P+> and tr G_k of the own column (eta of the next step).  Runs in the next step's phase 0, while wave 4 forms
-  // w, s and kappa, and once more after the last step.  q is the one W was formed with: F3_IQ is rewritten by wave 4 in
-  // phase 0, so the value is taken over in phase 1 (iq_w).
-#define F3_LBAR_AND_TRACES()                                                                               \
+  // After a step's inversion: W (both columns) into Wf, and for the X waves <G_k, P+> and tr G_k of the own column
+  // (eta of the next step).  Runs in the next step's phase 0, while wave 4 forms w, s and kappa, and once more after
+  // the last step.  Lbar_{k+1} = (I / q - W / q^2) / omega_k is never formed: M is built from W directly (phase 1).
+#define F3_W_AND_TRACES()                                                                                  \
   do {                                                                                                     \
-    const double iq_ = iq_w, iq2_ = iq_w * iq_w;                                                           \
     _Pragma("unroll") for (int ti_ = 0; ti_ < 2; ++ti_)                                                    \
       _Pragma("unroll") for (int tj_ = 0; tj_ < 2; ++tj_) {                                                \
         double wv_[4];                                                                                     \
@@ -282,11 +287,8 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
           const f64x2 v0_ = d2_[(ti_ * 2) * 64], v1_ = d2_[(ti_ * 2 + 1) * 64];                            \
           wv_[0] = v0_[0]; wv_[1] = v0_[1]; wv_[2] = v1_[0]; wv_[3] = v1_[1];                               \
         }                                                                                                  \
-        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                 \
-          const int e_ = (ti_ * 2 + tj_) * 4 + q_;                                                         \
-          const double l_ = (F3_DIAG(mk, ti_, tj_, q_) ? iq_ : 0.0) - wv_[q_] * iq2_;                      \
-          L0[e_] = F3_VALID(mk, ti_, tj_, q_) ? l_ : 0.0;                                                  \
-        }                                                                                                  \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                                                   \
+          Wf[(ti_ * 2 + tj_) * 4 + q_] = F3_VALID(mk, ti_, tj_, q_) ? wv_[q_] : 0.0;                       \
       }                                                                                                    \
     if (isX) {                                                                                             \
       double g1_ = 0.0, t1_ = 0.0;                                                                         \
@@ -305,11 +307,11 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
   F3Ctl ctl = {carried, 0, 0, 0, 0, 0};
   int w_par = 0;
   bool w_from_img = false;
-  double iq_w = 0.0;
+  double iq_w = 1.0 / q0;          // 1 / q that Wf was formed with
   BLK_T0();
   for (int jb = 0; jb < b.nb; ++jb) {
     // phase 0 (wave 4 forms w, s, kappa meanwhile): what the step that just ended left to do off the critical path
-    if (jb > 0) F3_LBAR_AND_TRACES();
+    if (jb > 0) F3_W_AND_TRACES();
     BLK_T(0);
     f3_barrier();                                                     // ---- B1
     BLK_T(1);
@@ -323,7 +325,10 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
       const double kap = L.sc[F3_KAPPA], iom = L.sc[F3_IOM], iq = L.sc[F3_IQ];
       kap_k = kap;
       const double ib = isY ? 1.0 / p.beta : 1.0, dq = isY ? iq : 0.0;
+      // M = Lbar + kappa G with Lbar = (I / qw - W / qw^2) / omega, qw = the q that W was formed with; Y: M / beta + I / q
+      const double c1 = iom * iq_w, c2 = c1 * iq_w;
       iq_w = iq;
+      const double kb = kap * ib, cb = c2 * ib, dv = c1 * ib + dq;
 #pragma unroll
       for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
@@ -331,13 +336,9 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
 #pragma unroll
           for (int qq = 0; qq < 4; ++qq) {
             const int e = (ti * 2 + tj) * 4 + qq;
-            double m = (L0[e] * iom + kap * G[e]) * ib;
-            if (ti == tj) {
-              m += F3_DIAG(mk, ti, tj, qq) ? dq : 0.0;
-              Mf[e] = F3_VALID(mk, ti, tj, qq) ? m : (F3_DIAG(mk, ti, tj, qq) ? 1.0 : 0.0);
-            } else {
-              Mf[e] = F3_VALID(mk, ti, tj, qq) ? m : 0.0;
-            }
+            const double m = kb * G[e] - cb * Wf[e];                 // zero outside r x r (G and Wf are)
+            if (ti == tj) Mf[e] = m + (F3_DIAG(mk, ti, tj, qq) ? (F3_VALID(mk, ti, tj, qq) ? dv : 1.0) : 0.0);
+            else Mf[e] = m;
           }
     }
 #define F3_ITERATE(parity_out)                                                                             \
@@ -450,7 +451,7 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
   }
   BLK_TOUT();
   // ---- block end ----
-  if (b.nb > 0) F3_LBAR_AND_TRACES();
+  if (b.nb > 0) F3_W_AND_TRACES();
   f3_barrier();                       // wave 4 has published pscale and 1 / omega of the last step
   const double ps = L.sc[F3_PSCALE], iom = L.sc[F3_IOM];
 #pragma unroll
@@ -466,14 +467,14 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
           st->G[idx] = G[(ti * 2 + C) * 4 + qq];
         } else {
           st->XpY[idx] = Xc[ti * 4 + qq];
-          st->Lbar[idx] = L0[(ti * 2 + C) * 4 + qq] * iom;
+          st->Lbar[idx] = ((row == col ? iq_w : 0.0) - Wf[(ti * 2 + C) * 4 + qq] * iq_w * iq_w) * iom;
         }
       }
     }
   if (role == 0 && lane == 0) { st->cnt[0] += ctl.c_ns; st->cnt[1] += ctl.c_sw; st->cnt[2] += ctl.c_it; st->cnt[3] += ctl.c_fail; }
 #undef F3_ITERATE
 #undef F3_FETCH_PARTNER
-#undef F3_LBAR_AND_TRACES
+#undef F3_W_AND_TRACES
 }
 
 // ------------------------------------------------------------------------------------------------------------
