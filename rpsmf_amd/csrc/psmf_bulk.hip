@@ -174,10 +174,16 @@ __global__ __launch_bounds__(256) void psmf_blk_xreduce2(const double* __restric
   __shared__ double red[8][33];
   const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
   const int e = blockIdx.x * 32 + el;                  // raw element: (tile * 4 + q) * 64 + lane
+  // every thread sums nparts / 8 partials (g, g + 8, ...), 8 loads in flight at a time; fixed order
   double a0 = 0.0, a1 = 0.0;
-  for (int pi = g; pi < nparts; pi += 16) {
-    a0 += part[(size_t)pi * PSZ + e];
-    if (pi + 8 < nparts) a1 += part[(size_t)(pi + 8) * PSZ + e];
+  for (int p0 = g; p0 < nparts; p0 += 64) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = part[(size_t)min(p0 + 8 * u, nparts - 1) * PSZ + e];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = (p0 + 8 * u < nparts) ? v[u] : 0.0;
+    a0 += (v[0] + v[2]) + (v[4] + v[6]);
+    a1 += (v[1] + v[3]) + (v[5] + v[7]);
   }
   red[g][el] = a0 + a1;
   __syncthreads();
