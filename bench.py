@@ -172,6 +172,12 @@ def main():
         parity = dict(steps=n_cpu, C=rel(s["C"], st_cpu.C), V=rel(s["V"], st_cpu.V), mu=rel(s["mu"], st_cpu.mu),
                       P=rel(s["P"], st_cpu.P))
 
+    # ---- untimed pre-warm: the HIP runtime grows its signal / kernel-argument pools the first time a whole pass worth of
+    # launches is queued ahead of the GPU (a one-off ~80 ms stall in the second pass, tools/probe_stall.py)
+    reset()
+    for _ in range(2):
+        f.run(0, T, sync=False)
+    f.sync()
     # ---- timed region: K passes of T timesteps, state carried from pass to pass
     reset()
     for _ in range(args.warmup):

@@ -148,7 +148,8 @@ int psmf_time_kernel(psmf_handle h, int which, int iters, float* avg_us);
 int psmf_geometry(psmf_handle h, int32_t* out7);
 /* diagnostics of the blocked engine's r x r inversions since the last reset: out[0] = timesteps inverted by
  * Newton-Schulz refinement, out[1] = by the direct symmetric sweep, out[2] = Newton-Schulz iterations in
- * total, out[3] = failed Newton-Schulz attempts; reset != 0 clears them.  (New: the reference has no
+ * total, out[3] = failed Newton-Schulz attempts, out[4] / out[5] = summed in-kernel durations / gaps between
+ * consecutive filter kernels in 10 ns ticks, out[7] = filter launches; reset != 0 clears them.  (New: the reference has no
  * counterpart; its np.linalg.inv calls are pypsmf/psmf/psmf.py:147-149.) */
 int psmf_counters(psmf_handle h, int64_t* out8, int reset);
 

@@ -233,7 +233,8 @@ class DeviceFilter:
     def counters(self, reset=False):
         c = (C.c_int64 * 8)()
         self._check(self._lib.psmf_counters(self._h, c, int(bool(reset))))
-        return dict(ns_steps=c[0], sweep_steps=c[1], ns_iterations=c[2], ns_failed=c[3], sum_log10_res=[c[4] / 1000.0, c[5] / 1000.0, c[6] / 1000.0], max_log10_res0=(c[7] - 100000) / 1000.0)
+        return dict(ns_steps=c[0], sweep_steps=c[1], ns_iterations=c[2], ns_failed=c[3], filter_launches=c[7],
+                    filter_us_mean=0.01 * c[4] / max(1, c[7]), filter_gap_us_mean=0.01 * c[5] / max(1, c[7] - 1))
 
     def y_pred(self, t0, nt, dtype=np.float64):
         out = np.empty((nt, self.d_local), dtype=dtype)

@@ -702,6 +702,7 @@ __global__ __launch_bounds__(F3_NT) void psmf_blk_filter3(BlockParams b) {
   const int r = p.r, tid = threadIdx.x, lane = tid & 63;
   const int role = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: the role branches are scalar branches
   const int r2 = r + (r & 1);
+  const long long t_begin = (long long)__builtin_amdgcn_s_memrealtime();      // 100 MHz: in-situ duration / gap diagnostics
   // ---- LDS carve ----
   // Everything a step touches sits in STATIC LDS: its addresses are compile-time constants that fold into the ds
   // instructions' immediate offsets.  (Off the dynamic-LDS base the compiler formed (lane part + constant) + base for
@@ -758,6 +759,14 @@ __global__ __launch_bounds__(F3_NT) void psmf_blk_filter3(BlockParams b) {
     else f3_ns_program<0>(b, L, inv, role, lane, carried);
   } else {
     f3_v_program(b, L, role, lane, carried);
+  }
+  if (tid == 0) {
+    // cnt[4]: sum of in-kernel durations, cnt[5]: sum of the gaps to the previous filter kernel, cnt[7]: launches (10 ns ticks)
+    const long long t_end = (long long)__builtin_amdgcn_s_memrealtime();
+    st->cnt[4] += t_end - t_begin;
+    if (st->cnt[6] != 0) st->cnt[5] += t_begin - st->cnt[6];
+    st->cnt[6] = t_end;
+    st->cnt[7] += 1;
   }
 }
 

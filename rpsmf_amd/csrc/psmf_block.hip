@@ -964,7 +964,7 @@ __global__ __launch_bounds__(2 * WG) void psmf_blk_filter2(BlockParams b) {
       else { st->XpY[idx] = Xp[m]; st->Lbar[idx] = Lv[m]; }
     }
   }
-  if (tid == 0) { st->ns_valid = 1; st->cnt[0] += c_ns; st->cnt[1] += c_sw; st->cnt[2] += c_it; st->cnt[3] += c_fail; st->cnt[4] += (long long)(1000.f * c_l0); st->cnt[5] += (long long)(1000.f * c_l1); st->cnt[6] += (long long)(1000.f * c_l2); st->cnt[7] = max(st->cnt[7], (long long)(1000.f * c_m0) + 100000); }
+  if (tid == 0) { st->ns_valid = 1; st->cnt[0] += c_ns; st->cnt[1] += c_sw; st->cnt[2] += c_it; st->cnt[3] += c_fail; }
   for (int idx = tid; idx < RB * r; idx += 2 * WG) { const int m = idx / r; b.Acoef[idx] = sA[m * RS + (idx - m * r)]; }
   if (X) {
 #pragma unroll

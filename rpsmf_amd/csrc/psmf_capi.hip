@@ -3,6 +3,7 @@
 // per-step launches replayed over the series.  No torch, no hipBLAS: plain HIP + RCCL.
 #include "../../include/psmf_hip.h"
 #include "psmf_kernels.hip"
+#include <chrono>
 #include "psmf_block.hip"
 #include "psmf_blk3.hip"
 #include "psmf_bulk.hip"
@@ -74,6 +75,8 @@ struct psmf_filter {
   int nranks = 1, rank = 0;
   bool use_coll = false;   // per-step all-reduce on (nranks > 1, or forced for single-GPU testing)
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  int* err_host = nullptr;     // pinned, device-mapped: a one-thread kernel publishes the device error flag here
+  int* err_host_dev = nullptr;
   std::string err;
   size_t elem() const { return cfg.storage == PSMF_F64 ? 8 : 4; }
 };
@@ -100,6 +103,19 @@ int fail(psmf_handle h, int code, const std::string& msg) {
   } while (0)
 
 int next_pow2(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+
+// Completion waits by polling: hipStreamSynchronize / hipEventSynchronize fall back to an interrupt wait that, on this
+// stack, now and then returns ~70 ms after the work is done (seen as wall time without matching event time).
+hipError_t spin_stream(hipStream_t s) {
+  hipError_t e;
+  while ((e = hipStreamQuery(s)) == hipErrorNotReady) { __builtin_ia32_pause(); }
+  return e;
+}
+hipError_t spin_event(hipEvent_t ev) {
+  hipError_t e;
+  while ((e = hipEventQuery(ev)) == hipErrorNotReady) { __builtin_ia32_pause(); }
+  return e;
+}
 
 typedef void (*sweep_fn_t)(StepParams);
 typedef void (*serial_fn_t)(StepParams, int);
@@ -299,8 +315,17 @@ int enqueue_block(psmf_filter* h, int64_t k0, int nb) {
 //   main:  [gram(0)] filter(0) | [xgram(1)] filter(1) | [xgram(2)] filter(2) | ...
 // xgram(b+1) reads C before apply(b) rewrites it (stream order on bulk); the ping-pong coefficient
 // buffers of block b are rewritten by filter(b+2), which waits for xgram(b+2), enqueued after apply(b).
+double host_now_ms() {
+  using namespace std::chrono;
+  return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+const bool g_host_timing = getenv("PSMF_HOST_TIMING") && atoi(getenv("PSMF_HOST_TIMING")) != 0;
+
 int enqueue_blocks_pipelined(psmf_filter* h, int64_t k_begin, int64_t k_end) {
   const int B = h->block_steps;
+  const double t_enq0 = g_host_timing ? host_now_ms() : 0.0;
+  double t_prev = t_enq0, t_worst = 0.0;
+  long long worst_blk = -1;
   const int64_t nblk = (k_end - k_begin + B - 1) / B;
   auto k0_of = [&](int64_t b) { return k_begin + b * B; };
   auto nb_of = [&](int64_t b) { const int64_t left = k_end - k0_of(b); return (int)(left < B ? left : B); };
@@ -343,6 +368,12 @@ int enqueue_blocks_pipelined(psmf_filter* h, int64_t k_begin, int64_t k_end) {
     HIP_TRY(h, hipStreamWaitEvent(h->bulk, h->evF[bi & 3], 0));
     launch_blk_apply(h, b, h->bulk);
     HIP_TRY(h, hipEventRecord(h->evA[bi & 3], h->bulk));
+    if (g_host_timing) { const double t = host_now_ms(); if (t - t_prev > t_worst) { t_worst = t - t_prev; worst_blk = bi; } t_prev = t; }
+  }
+  if (g_host_timing) {
+    const double t = host_now_ms();
+    if (t - t_enq0 > 20.0 || t_worst > 5.0)
+      fprintf(stderr, "[psmf host timing] enqueue of %lld blocks took %.1f ms, slowest block's calls %.1f ms (block %lld)\n", (long long)nblk, t - t_enq0, t_worst, worst_blk);
   }
   HIP_TRY(h, hipStreamWaitEvent(h->stream, h->evA[(nblk - 1) & 3], 0));   // the main stream sees the final C / y_hat
   HIP_TRY(h, hipGetLastError());
@@ -431,11 +462,9 @@ void pack_rows(const double* src, T* dst, int d_local, int r, int rp) {
 
 // start-of-run preparation: step counter, exact Gram, then everything the first sweep needs
 int prepare(psmf_filter* h, int64_t k_begin) {
-  long long k = k_begin;
-  int zero = 0;
-  HIP_TRY(h, hipMemcpyAsync(&h->st->k, &k, sizeof(k), hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(h, hipMemcpyAsync(&h->st->err, &zero, sizeof(zero), hipMemcpyHostToDevice, h->stream));
-  HIP_TRY(h, hipStreamSynchronize(h->stream));   // the two sources above are stack variables
+  // step counter and error flag by a one-thread kernel (its arguments travel with the launch): no host buffer to keep
+  // alive, so no synchronisation here -- consecutive passes over the series queue up back to back
+  hipLaunchKernelGGL(psmf::psmf_prepare_k, dim3(1), dim3(1), 0, h->stream, h->st, (long long)k_begin);
   if (h->mu_hist)
     HIP_TRY(h, hipMemcpyAsync(h->mu_hist + (size_t)(k_begin - h->sp.series_t0) * h->cfg.r, h->st->mu, h->cfg.r * sizeof(double),
                               hipMemcpyDeviceToDevice, h->stream));
@@ -497,6 +526,8 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
   CREATE_TRY(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
   CREATE_TRY(hipEventCreate(&h->ev0));
   CREATE_TRY(hipEventCreate(&h->ev1));
+  CREATE_TRY(hipHostMalloc((void**)&h->err_host, sizeof(int), hipHostMallocMapped));
+  CREATE_TRY(hipHostGetDevicePointer((void**)&h->err_host_dev, h->err_host, 0));
   CREATE_TRY(hipMalloc((void**)&h->st, sizeof(DevState)));
   CREATE_TRY(hipMemset(h->st, 0, sizeof(DevState)));
   CREATE_TRY(hipMalloc(&h->C, (size_t)cfg->d_local * h->geo.rp * h->elem()));
@@ -624,6 +655,7 @@ void psmf_destroy(psmf_handle h) {
   if (h->scratch) hipFree(h->scratch);
   if (h->ev0) hipEventDestroy(h->ev0);
   if (h->ev1) hipEventDestroy(h->ev1);
+  if (h->err_host) hipHostFree(h->err_host);
   if (h->stream) hipStreamDestroy(h->stream);
   delete h;
 }
@@ -846,9 +878,14 @@ int psmf_sync(psmf_handle h) {
   if (!h) return PSMF_ERR_ARG;
   int rc = set_device(h);
   if (rc) return rc;
-  HIP_TRY(h, hipStreamSynchronize(h->stream));
-  int err = 0;
-  HIP_TRY(h, hipMemcpy(&err, &h->st->err, sizeof(int), hipMemcpyDeviceToHost));
+  const double t_s0 = g_host_timing ? host_now_ms() : 0.0;
+  // (a 4-byte device-to-host hipMemcpy[Async] here now and then took 20-70 ms on this stack -- the copy engine waking
+  //  up -- which is half a pass of the headline workload; a store from a kernel to mapped host memory does not)
+  hipLaunchKernelGGL(psmf::psmf_publish_err_k, dim3(1), dim3(1), 0, h->stream, (const DevState*)h->st, h->err_host_dev);
+  const double t_s1 = g_host_timing ? host_now_ms() : 0.0;
+  HIP_TRY(h, spin_stream(h->stream));
+  if (g_host_timing) { const double t = host_now_ms(); if (t_s1 - t_s0 > 5.0) fprintf(stderr, "[psmf host timing] memcpyAsync call %.1f ms\n", t_s1 - t_s0); if (t - t_s1 > 5.0) fprintf(stderr, "[psmf host timing] spin wait %.1f ms\n", t - t_s1); }
+  const int err = *h->err_host;
   if (err != 0) {
     char msg[128];
     snprintf(msg, sizeof(msg), "singular r x r system (I + kappa Pbar G) at step %d", err);
@@ -869,7 +906,7 @@ int psmf_run_timed(psmf_handle h, int64_t k_begin, int64_t k_end, float* ms) {
   rc = psmf_run(h, k_begin, k_end);
   if (rc) return rc;
   HIP_TRY(h, hipEventRecord(h->ev1, h->stream));
-  HIP_TRY(h, hipEventSynchronize(h->ev1));
+  HIP_TRY(h, spin_event(h->ev1));
   HIP_TRY(h, hipEventElapsedTime(ms, h->ev0, h->ev1));
   return psmf_sync(h);
 }
