@@ -728,6 +728,7 @@ __global__ __launch_bounds__(F3_NT) void psmf_blk_filter3(BlockParams b) {
   L.gp = L.hv + 2;
   L.tr = L.gp + 2;
 
+  if (!blk_handoff_begin(b)) return;
   if (!b.assemble) {
     for (int idx = tid; idx < RB * RB; idx += F3_NT) L.sK[idx] = b.K[idx];
   } else {

@@ -55,7 +55,60 @@ struct BlockParams {
   double* XGpart;         // BLK_GRAM_WG x (RB + XGB) * XGB
   long long k1;           // xgram: first row of the NEXT block in the series
   int nb1;                // xgram: steps of the next block
+  // device-flag hand-off of the pipelined blocks (nullptr: the host orders the kernels with events):
+  //   flags[0] = xg_seq   highest block sequence number whose K / cross-Gram is complete      (set on the bulk stream)
+  //   flags[1] = filt_seq number of blocks whose filter kernel has finished                   (set by the NEXT filter kernel)
+  //   flags[2] = abort    a wait timed out
+  long long* flags;
+  long long seq;          // this block's sequence number
 };
+
+// ---- hand-off through device flags -------------------------------------------------------------------------------
+// An event wait or an event record between two kernels of one stream costs 5-8 us on this stack (measured gap between
+// consecutive filter kernels: 4 us bare, 9.4 with the record, 14.9 with both).  So the filter stream carries nothing
+// but filter kernels; each one, when it starts, (a) announces that its predecessor has finished -- the kernel boundary
+// made that kernel's stores visible -- which releases the bulk stream's apply, and (b) checks that its own K is there
+// (it practically always is: the cross-Gram runs one block ahead).  Every wait is bounded.
+constexpr long long HANDOFF_MAX_POLLS = 1LL << 21;     // x ~1 us: seconds, then the abort flag
+
+__device__ __forceinline__ long long flag_load(const long long* f) { return __hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void flag_store(long long* f, long long v) { __hip_atomic_store(f, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+
+// returns false (uniformly) if the run was aborted; ends with a workgroup barrier
+__device__ __forceinline__ bool blk_handoff_begin(const BlockParams& b) {
+  __shared__ int s_ok;            // a slot of its own: nothing else writes it
+  int* s_flag = &s_ok;
+  if (!b.flags) return true;
+  if (threadIdx.x == 0) {
+    int ok = 1;
+    if (flag_load(b.flags + 2) != 0) ok = 0;
+    if (ok) {
+      flag_store(b.flags + 1, b.seq);                    // blocks < seq are complete
+      long long polls = 0;
+      while (flag_load(b.flags + 0) < b.seq) {
+        __builtin_amdgcn_s_sleep(16);
+        if (++polls > HANDOFF_MAX_POLLS || flag_load(b.flags + 2) != 0) { ok = 0; break; }
+      }
+      if (polls > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // K was written after this kernel started
+      if (!ok) { flag_store(b.flags + 2, 1); if (b.sp.st->err == 0) b.sp.st->err = -7; }
+    }
+    *s_flag = ok;
+  }
+  __syncthreads();
+  return *s_flag != 0;
+}
+
+__global__ void psmf_flag_set_k(long long* f, long long v) { flag_store(f, v); }
+
+// bulk stream: hold the stream until flags[1] >= v (the filter kernel of block v - 1 has finished)
+__global__ void psmf_flag_wait_k(long long* flags, long long v, DevState* st) {
+  if (threadIdx.x != 0) return;
+  long long polls = 0;
+  while (flag_load(flags + 1) < v) {
+    __builtin_amdgcn_s_sleep(32);
+    if (++polls > HANDOFF_MAX_POLLS || flag_load(flags + 2) != 0) { flag_store(flags + 2, 1); if (st->err == 0) st->err = -7; break; }
+  }
+}
 
 // ------------------------------------------------------------------------------------------
 template <typename T>
@@ -388,6 +441,7 @@ __global__ __launch_bounds__(WG) void psmf_blk_filter(BlockParams b) {
   double* s4 = rowbuf + 4 * RM;       // 4 (+ errflag)
   int* errflag = reinterpret_cast<int*>(s4 + 4);
 
+  if (!blk_handoff_begin(b)) return;
   if (!b.assemble) {
     for (int idx = tid; idx < RB * RB; idx += WG) sK[idx] = b.K[idx];
   } else {
@@ -653,6 +707,7 @@ __global__ __launch_bounds__(2 * WG) void psmf_blk_filter2(BlockParams b) {
   const int nti = lw >> 1, ntj = lw & 1, lane = tid & 63;
   const bool ns_wave = (NT == 32) || lw == 0;
 
+  if (!blk_handoff_begin(b)) return;
   if (!b.assemble) {
     for (int idx = tid; idx < RB * RB; idx += 2 * WG) sK[idx] = b.K[idx];
   } else {

@@ -60,6 +60,8 @@ struct psmf_filter {
   double* Bcoef = nullptr;     // 2 x RB x RB
   double* XGpart = nullptr;    // BLK_GRAM_WG x (RB + XGB) x XGB
   double* XG = nullptr;        // 2 x (RB + XGB) x XGB
+  long long* flags = nullptr;  // device-flag hand-off of the pipelined blocks (psmf_block.hip): xg_seq, filt_seq, abort
+  long long seq_next = 1;      // sequence number of the next block to be enqueued
   hipStream_t bulk = nullptr;  // Gram / cross-Gram / apply of the pipelined blocked engine
   hipEvent_t evF[4] = {}, evA[4] = {}, evX[4] = {}, evS = nullptr;
   size_t scratch_bytes = 0;
@@ -335,12 +337,18 @@ int enqueue_blocks_pipelined(psmf_filter* h, int64_t k_begin, int64_t k_end) {
   hipStream_t fs = h->fstream ? h->fstream : h->stream;    // the filter chain (its own CUs when the mask streams exist)
   if (h->fstream) HIP_TRY(h, hipStreamWaitEvent(fs, h->evS, 0));
   psmf::BlockParams b;
+  // hand-off by device flags when the filter chain has a stream (hardware queue) of its own; by events otherwise
+  static const bool flags_off = getenv("PSMF_BLOCK_FLAGS") && atoi(getenv("PSMF_BLOCK_FLAGS")) == 0;
+  const bool use_flags = h->fstream != nullptr && h->flags != nullptr && !flags_off;
+  const long long s0 = h->seq_next;
+  h->seq_next += nblk;
   // first block: plain Gram of the stored C
   fill_block_params(h, b, k0_of(0), nb_of(0), 0);
   launch_blk_gram(h, b, h->bulk);
   if (h->use_coll)
     NCCL_TRY(h, ncclAllReduce(h->Kmat, h->Kmat, psmf::RB * psmf::RB, ncclDouble, ncclSum, h->comm, h->bulk));
-  HIP_TRY(h, hipEventRecord(h->evX[0], h->bulk));
+  if (use_flags) hipLaunchKernelGGL(psmf::psmf_flag_set_k, dim3(1), dim3(1), 0, h->bulk, h->flags + 0, s0);
+  else HIP_TRY(h, hipEventRecord(h->evX[0], h->bulk));
   for (int64_t bi = 0; bi < nblk; ++bi) {
     const int slot = (int)(bi & 1);
     // bulk: cross-Gram for block bi + 1 (needs C as of the start of block bi)
@@ -352,20 +360,29 @@ int enqueue_blocks_pipelined(psmf_filter* h, int64_t k_begin, int64_t k_end) {
       double* xg = h->XG + (size_t)((bi + 1) & 1) * xg_elems;
       launch_blk_xgram(h, x, xg, h->bulk);
       if (h->use_coll) NCCL_TRY(h, ncclAllReduce(xg, xg, xg_elems, ncclDouble, ncclSum, h->comm, h->bulk));
-      HIP_TRY(h, hipEventRecord(h->evX[(bi + 1) & 3], h->bulk));
+      if (use_flags) hipLaunchKernelGGL(psmf::psmf_flag_set_k, dim3(1), dim3(1), 0, h->bulk, h->flags + 0, s0 + bi + 1);
+      else HIP_TRY(h, hipEventRecord(h->evX[(bi + 1) & 3], h->bulk));
     }
-    // main: filter of block bi
+    // filter stream: filter of block bi
     fill_block_params(h, b, k0_of(bi), nb_of(bi), slot);
     if (bi > 0) {
       b.assemble = 1;
       b.XG = h->XG + (size_t)(bi & 1) * xg_elems;
       b.Aprev = h->Acoef + (size_t)(slot ^ 1) * psmf::RB * psmf::RM;
     }
-    HIP_TRY(h, hipStreamWaitEvent(fs, h->evX[bi & 3], 0));
-    launch_blk_filter(h, b, fs);
-    HIP_TRY(h, hipEventRecord(h->evF[bi & 3], fs));
+    if (use_flags) {
+      b.flags = h->flags;
+      b.seq = s0 + bi;
+      launch_blk_filter(h, b, fs);
+      if (bi + 1 == nblk) hipLaunchKernelGGL(psmf::psmf_flag_set_k, dim3(1), dim3(1), 0, fs, h->flags + 1, s0 + nblk);   // the last block has no successor to announce it
+      hipLaunchKernelGGL(psmf::psmf_flag_wait_k, dim3(1), dim3(64), 0, h->bulk, h->flags, s0 + bi + 1, h->st);
+    } else {
+      HIP_TRY(h, hipStreamWaitEvent(fs, h->evX[bi & 3], 0));
+      launch_blk_filter(h, b, fs);
+      HIP_TRY(h, hipEventRecord(h->evF[bi & 3], fs));
+      HIP_TRY(h, hipStreamWaitEvent(h->bulk, h->evF[bi & 3], 0));
+    }
     // bulk: apply of block bi
-    HIP_TRY(h, hipStreamWaitEvent(h->bulk, h->evF[bi & 3], 0));
     launch_blk_apply(h, b, h->bulk);
     HIP_TRY(h, hipEventRecord(h->evA[bi & 3], h->bulk));
     if (g_host_timing) { const double t = host_now_ms(); if (t - t_prev > t_worst) { t_worst = t - t_prev; worst_blk = bi; } t_prev = t; }
@@ -465,6 +482,7 @@ int prepare(psmf_filter* h, int64_t k_begin) {
   // step counter and error flag by a one-thread kernel (its arguments travel with the launch): no host buffer to keep
   // alive, so no synchronisation here -- consecutive passes over the series queue up back to back
   hipLaunchKernelGGL(psmf::psmf_prepare_k, dim3(1), dim3(1), 0, h->stream, h->st, (long long)k_begin);
+  if (h->flags) hipLaunchKernelGGL(psmf::psmf_flag_set_k, dim3(1), dim3(1), 0, h->stream, h->flags + 2, 0LL);
   if (h->mu_hist)
     HIP_TRY(h, hipMemcpyAsync(h->mu_hist + (size_t)(k_begin - h->sp.series_t0) * h->cfg.r, h->st->mu, h->cfg.r * sizeof(double),
                               hipMemcpyDeviceToDevice, h->stream));
@@ -550,6 +568,8 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
     CREATE_TRY(hipMemset(h->Bcoef, 0, (size_t)2 * psmf::RB * psmf::RB * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&h->XGpart, (size_t)psmf::BLK_GRAM_WG * (psmf::RB + psmf::XGB) * psmf::XGB * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&h->XG, (size_t)2 * (psmf::RB + psmf::XGB) * psmf::XGB * sizeof(double)));
+    CREATE_TRY(hipMalloc((void**)&h->flags, 8 * sizeof(long long)));
+    CREATE_TRY(hipMemset(h->flags, 0, 8 * sizeof(long long)));
     {
       // The filter chain is one workgroup on the critical path; the bulk kernels (cross-Gram, apply) run
       // beside it and would be co-scheduled onto its CU, stretching it by 10-17 % (measured).  Partition the
@@ -648,6 +668,7 @@ void psmf_destroy(psmf_handle h) {
   if (h->Bcoef) hipFree(h->Bcoef);
   if (h->XGpart) hipFree(h->XGpart);
   if (h->XG) hipFree(h->XG);
+  if (h->flags) hipFree(h->flags);
   for (int i = 0; i < 4; ++i) { if (h->evF[i]) hipEventDestroy(h->evF[i]); if (h->evA[i]) hipEventDestroy(h->evA[i]); if (h->evX[i]) hipEventDestroy(h->evX[i]); }
   if (h->evS) hipEventDestroy(h->evS);
   if (h->bulk) { hipStreamSynchronize(h->bulk); hipStreamDestroy(h->bulk); }
@@ -886,6 +907,7 @@ int psmf_sync(psmf_handle h) {
   HIP_TRY(h, spin_stream(h->stream));
   if (g_host_timing) { const double t = host_now_ms(); if (t_s1 - t_s0 > 5.0) fprintf(stderr, "[psmf host timing] memcpyAsync call %.1f ms\n", t_s1 - t_s0); if (t - t_s1 > 5.0) fprintf(stderr, "[psmf host timing] spin wait %.1f ms\n", t - t_s1); }
   const int err = *h->err_host;
+  if (err == -7) return fail(h, PSMF_ERR_HIP, "pipelined blocks: a device-flag hand-off timed out (PSMF_BLOCK_FLAGS=0 selects event hand-off)");
   if (err != 0) {
     char msg[128];
     snprintf(msg, sizeof(msg), "singular r x r system (I + kappa Pbar G) at step %d", err);
