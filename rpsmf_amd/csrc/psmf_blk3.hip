@@ -33,6 +33,7 @@
 namespace psmf {
 
 typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4s __attribute__((ext_vector_type(4)));
 
 constexpr int F3_NT = 512;
 constexpr int F3_S = 34;            // row stride of the row-major 32 x 32 LDS images
@@ -100,6 +101,7 @@ struct F3Lds {
   double* sA;       // RB x RS   scratch of assemble_K
   double* sKA;      // RB x RS
   double* dump;     // [2 parities][4 NS waves][8 registers][64 lanes]
+  float* dumpP;     // [2 parities][4 NS waves][2 tiles][64 lane slots][4]: the same columns, float32, P-layout
   double* img;      // [2 inversions][32 x F3_S]
   double* mub;      // RM
   double* w;        // RM
@@ -123,10 +125,16 @@ inline size_t blk_filter3_lds_bytes() {
 }
 
 // One Newton-Schulz iteration of tile column C:  R = I - M X_c,  Xn = X_c + X^T R  (see the header).
-// Mf: the step's matrix, T-layout, tile (kt, ti) at [(kt * 2 + ti) * 4 + kk]; Xc / Xo: own / partner's column.
+// Mf: the step's matrix, T-layout, tile (kt, ti) at [(kt * 2 + ti) * 4 + kk]; Xc: own column (T-layout, float64).
+// The correction X^T R is formed on the FLOAT32 matrix cores (v_mfma_f32_16x16x4_f32: 32 cycles against 64): R is small,
+// so rounding X and R to float32 perturbs the new iterate by ~1e-7 ||X|| ||R|| -- 2e-9 after the first iteration, 1e-11
+// or less after the last; the residual itself stays float64.  Xa: the A operands, float32, tile (kt, to) at
+// [to * 8 + kt * 4 + kk] for output row tile to, in "P-layout" = T-layout with the 16 lanes of a row permuted by
+// pi(4 a + v) = a + 4 v: the float32 MFMA returns row 4 (l >> 4) + v in register v where the float64 one returns
+// (l >> 4) + 4 v, and feeding it the rows in that order makes its output land in T-layout.
 // Returns this lane's share of ||R_c||_F^2.
 template <int C>
-__device__ __forceinline__ double f3_ns_iter(const double (&Mf)[16], const double (&Xc)[8], const double (&Xo)[8], double (&Xn)[8],
+__device__ __forceinline__ double f3_ns_iter(const double (&Mf)[16], const double (&Xc)[8], const float (&Xa)[16], double (&Xn)[8],
                                              const F3Mask& mk) {
   // the two 16 x 16 output tiles of a product are independent accumulator chains: alternate them, so that no MFMA
   // waits for the one before it
@@ -148,23 +156,20 @@ __device__ __forceinline__ double f3_ns_iter(const double (&Mf)[16], const doubl
       R[ti * 4 + q] = v;
       nrm += v * v;
     }
-  f64x4 a2[2];
+  f32x4s d2[2] = {f32x4s{0.f, 0.f, 0.f, 0.f}, f32x4s{0.f, 0.f, 0.f, 0.f}};
+  float Rf[8];
 #pragma unroll
-  for (int ti = 0; ti < 2; ++ti) a2[ti] = f64x4{Xc[ti * 4 + 0], Xc[ti * 4 + 1], Xc[ti * 4 + 2], Xc[ti * 4 + 3]};
+  for (int e = 0; e < 8; ++e) Rf[e] = (float)R[e];
 #pragma unroll
   for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-      for (int ti = 0; ti < 2; ++ti) {
-        // A operand = tile (kt, ti) of X in T-layout: column ti is this wave's own column iff ti == C
-        const double aop = (ti == C) ? Xc[kt * 4 + kk] : Xo[kt * 4 + kk];
-        a2[ti] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, R[kt * 4 + kk], a2[ti], 0, 0, 0);
-      }
+      for (int to = 0; to < 2; ++to) d2[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(Xa[to * 8 + kt * 4 + kk], Rf[kt * 4 + kk], d2[to], 0, 0, 0);
 #pragma unroll
-  for (int ti = 0; ti < 2; ++ti)
+  for (int to = 0; to < 2; ++to)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) Xn[ti * 4 + q] = a2[ti][q];
+    for (int q = 0; q < 4; ++q) Xn[to * 4 + q] = Xc[to * 4 + q] + (double)d2[to][q];
   return nrm;
 }
 
@@ -218,7 +223,9 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
   const bool isX = inv == 0, isY = inv == 1;
   double* imgX = L.img;
   double* imgY = L.img + 32 * F3_S;
-  double G[16], Wf[16], Xc[8], Xo[8];       // Wf: W of the last step (zero outside r x r): Lbar = (I / q - W / q^2) / omega
+  double G[16], Wf[16], Xc[8];
+  float Xa[16];                             // float32 A operands of the correction product (see f3_ns_iter)
+  const int pcol = (lcol >> 2) + 4 * (lcol & 3);     // pi(lcol)       // Wf: W of the last step (zero outside r x r): Lbar = (I / q - W / q^2) / omega
   const double q0 = st->Q[0];
   F3Mask mk;
   mk.full = (r == 32);
@@ -243,12 +250,18 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
   for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq) {
-      const int row = 16 * ti + lrow + 4 * qq, cc = 16 * C + lcol, co = 16 * (1 - C) + lcol;
+      const int row = 16 * ti + lrow + 4 * qq, cc = 16 * C + lcol;
       const double* src = isX ? st->XpX : st->XpY;
-      const bool ic = carried && row < r && cc < r, io = carried && row < r && co < r;
-      const double xc = src[ic ? row * r + cc : 0], xo = src[io ? row * r + co : 0];
+      const bool ic = carried && row < r && cc < r;
+      const double xc = src[ic ? row * r + cc : 0];
       Xc[ti * 4 + qq] = ic ? xc : (row == cc ? 1.0 : 0.0);
-      Xo[ti * 4 + qq] = io ? xo : (row == co ? 1.0 : 0.0);
+#pragma unroll
+      for (int to = 0; to < 2; ++to) {          // tile (kt = ti, to), register qq, P-layout
+        const int cp = 16 * to + pcol;
+        const bool ip = carried && row < r && cp < r;
+        const double xp = src[ip ? row * r + cp : 0];
+        Xa[to * 8 + ti * 4 + qq] = (float)(ip ? xp : (row == cp ? 1.0 : 0.0));
+      }
     }
   if (isX) {
     // <G_0, P> and tr G_0 of the own column, for eta of the first step (Pbar_1 = P + q I)
@@ -278,8 +291,8 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
     _Pragma("unroll") for (int ti_ = 0; ti_ < 2; ++ti_)                                                    \
       _Pragma("unroll") for (int tj_ = 0; tj_ < 2; ++tj_) {                                                \
         double wv_[4];                                                                                     \
-        if (isY) {                                                                                         \
-          _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) wv_[q_] = (tj_ == C) ? Xc[ti_ * 4 + q_] : Xo[ti_ * 4 + q_]; \
+        if (isY && tj_ == C) {                                                                             \
+          _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) wv_[q_] = Xc[ti_ * 4 + q_];                     \
         } else if (w_from_img) {                                                                           \
           _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) wv_[q_] = imgY[(16 * ti_ + lrow + 4 * q_) * F3_S + 16 * tj_ + lcol]; \
         } else {                                                                                           \
@@ -343,17 +356,28 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
     }
 #define F3_ITERATE(parity_out)                                                                             \
   do {                                                                                                     \
-    const double nr_ = f3_ns_iter<C>(Mf, Xc, Xo, Xn, mk);                                               \
+    const double nr_ = f3_ns_iter<C>(Mf, Xc, Xa, Xn, mk);                                               \
     const float nw_ = wave_sum_f32_dpp((float)nr_);                                                        \
     f64x2* dp_ = reinterpret_cast<f64x2*>(L.dump) + (size_t)(((parity_out) * 4 + role) * 4) * 64 + lane;   \
     _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) dp_[e_ * 64] = f64x2{Xn[2 * e_], Xn[2 * e_ + 1]};    \
+    f32x4s* pp_ = reinterpret_cast<f32x4s*>(L.dumpP) + (size_t)(((parity_out) * 4 + role) * 2) * 64 + 16 * lrow + pcol; \
+    _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_)                                                       \
+      pp_[t_ * 64] = f32x4s{(float)Xn[t_ * 4], (float)Xn[t_ * 4 + 1], (float)Xn[t_ * 4 + 2], (float)Xn[t_ * 4 + 3]}; \
     if (lane == 0) L.nrm[(parity_out) * 4 + role] = (double)nw_;                                           \
     _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) Xc[e_] = Xn[e_];                                      \
   } while (0)
 #define F3_FETCH_PARTNER(parity_in)                                                                        \
-  do {                                                                                                     \
-    const f64x2* dq_ = reinterpret_cast<const f64x2*>(L.dump) + (size_t)(((parity_in) * 4 + (role ^ 1)) * 4) * 64 + lane; \
-    _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) { const f64x2 v_ = dq_[e_ * 64]; Xo[2 * e_] = v_[0]; Xo[2 * e_ + 1] = v_[1]; } \
+  do {   /* both columns of the new iterate as float32 A operands: own tiles -> output tile C, partner's -> 1 - C */ \
+    _Pragma("unroll") for (int w_ = 0; w_ < 2; ++w_) {                                                     \
+      const int src_ = w_ == 0 ? role : (role ^ 1);                                                        \
+      const int to_ = w_ == 0 ? C : 1 - C;                                                                 \
+      const f32x4s* pq_ = reinterpret_cast<const f32x4s*>(L.dumpP) + (size_t)(((parity_in) * 4 + src_) * 2) * 64 + lane; \
+      _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_) {                                                   \
+        const f32x4s v_ = pq_[t_ * 64];                                                                    \
+        Xa[to_ * 8 + t_ * 4 + 0] = v_[0]; Xa[to_ * 8 + t_ * 4 + 1] = v_[1];                                 \
+        Xa[to_ * 8 + t_ * 4 + 2] = v_[2]; Xa[to_ * 8 + t_ * 4 + 3] = v_[3];                                 \
+      }                                                                                                    \
+    }                                                                                                      \
   } while (0)
     if (try_ns) F3_ITERATE(0);
     BLK_T(2);
@@ -419,7 +443,8 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
         for (int qq = 0; qq < 4; ++qq) {
           const int row = 16 * ti + lrow + 4 * qq;
           Xc[ti * 4 + qq] = im[row * F3_S + 16 * C + lcol];
-          Xo[ti * 4 + qq] = im[row * F3_S + 16 * (1 - C) + lcol];
+#pragma unroll
+          for (int to = 0; to < 2; ++to) Xa[to * 8 + ti * 4 + qq] = (float)im[row * F3_S + 16 * to + pcol];
         }
     } else {
       ++ctl.c_ns;
@@ -595,7 +620,9 @@ __device__ __forceinline__ void f3_v_program(const BlockParams& b, const F3Lds& 
       const double part = (a0 + a1) + (a2 + a3);
       const double hc = xor32_sum_f64(part);                            // h = A^T K a
       if (hf == 0) L.h[c] = hc;
-      const double e1 = wave_sum_f64_dpp(L.a[lane] * L.Ka[lane]);       // ee = a . K a
+    } else if (isV1) {
+      // ee = a . K a: wave 5 is idle in this phase, wave 7's product above is the one the barrier waits for
+      const double e1 = wave_sum_f64_dpp(cm * L.Ka[lane]);
       if (lane == 0) L.sc[F3_EE] = e1;
     } else if (isV0) {
       wj = xor32_sum_f64(wj);                                           // w = V mu_bar
@@ -708,6 +735,7 @@ __global__ __launch_bounds__(F3_NT) void psmf_blk_filter3(BlockParams b) {
   // instructions' immediate offsets.  (Off the dynamic-LDS base the compiler formed (lane part + constant) + base for
   // every row / column it reads and kept each sum in a VGPR of its own across the loop: 136 spilled registers.)
   __shared__ __attribute__((aligned(16))) double hot[2 * 4 * 8 * 64 + 3 * RM + 2 * RB + F3_NSC + 8 + 6];
+  __shared__ __attribute__((aligned(16))) float hotP[2 * 4 * 2 * 64 * 4];
   F3Lds L;
   L.sK = sm;
   L.sA = L.sK + RB * RB;
@@ -717,6 +745,7 @@ __global__ __launch_bounds__(F3_NT) void psmf_blk_filter3(BlockParams b) {
   L.rowbufY = L.rowbufX + 4 * RM;
   L.errflag = reinterpret_cast<int*>(L.rowbufY + 4 * RM);
   L.dump = hot;
+  L.dumpP = hotP;
   L.mub = L.dump + 2 * 4 * 8 * 64;
   L.w = L.mub + RM;
   L.h = L.w + RM;
