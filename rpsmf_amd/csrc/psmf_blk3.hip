@@ -98,8 +98,8 @@ enum { F3_KAPPA = 0, F3_N, F3_INVN, F3_EE, F3_IOM, F3_Q, F3_IQ, F3_PSCALE, F3_NS
 
 struct F3Lds {
   double* sK;       // RB x RB
-  double* sA;       // RB x RS   scratch of assemble_K
-  double* sKA;      // RB x RS
+  double* sA;       // RB x F3_AS  staging of the K assembly (Aprev)
+  double* sKA;      // RB x F3_AS  (upper part of XG)
   double* dump;     // [2 parities][4 NS waves][8 registers][64 lanes]
   float* dumpP;     // [2 parities][4 NS waves][2 tiles][64 lane slots][4]: the same columns, float32, P-layout
   double* img;      // [2 inversions][32 x F3_S]
@@ -116,12 +116,62 @@ struct F3Lds {
   double* rowbufX;  // 4 RM
   double* rowbufY;  // 4 RM
   int* errflag;
+  long long* tick;  // 2: loop start / loop end (s_memrealtime), diagnostics
 };
 
-// dynamic part (block Gram, assembly scratch, sweep images and row buffers); the per-step vectors are static LDS
+constexpr int F3_AS = 48;           // row stride of the K-assembly staging (16 mod 32: conflict-free MFMA operand reads)
+
+// dynamic part (block Gram, assembly staging, sweep images and row buffers); the per-step vectors are static LDS
 inline size_t blk_filter3_lds_bytes() {
-  const size_t doubles = (size_t)RB * RB + 2 * (size_t)RB * RS + 2 * 32 * F3_S + 8 * RM + 2;
+  const size_t doubles = (size_t)RB * RB + 2 * (size_t)RB * F3_AS + 2 * 32 * F3_S + 8 * RM + 2;
   return (doubles * 8 + 15) & ~(size_t)15;
+}
+
+// K of a pipelined block from the previous block's quantities (BlockParams; same result as assemble_K in
+// psmf_block.hip):  K[0:r,0:r] = G (tracked), K[r+q, r+q'] = Y^T Y (lower part of XG), and the cross block
+// K[i, r+q] = sum_m Aprev[m, i] XG[m, q] on the float64 matrix cores: Aprev (RB x r) and the upper part of XG
+// (RB x nb) staged once in LDS, one 16 x 16 output tile per wave (16 MFMAs).  Ends with a barrier.
+__device__ __forceinline__ void f3_assemble_K(const BlockParams& b, const F3Lds& L, const int r, const int tid) {
+  const int nb = b.nb, lane = tid & 63, w = tid >> 6, lrow = lane >> 4, lcol = lane & 15;
+  double* sK = L.sK;
+  double* sA = L.sA;
+  double* sX = L.sA + RB * F3_AS;
+  const DevState* st = b.sp.st;
+  for (int idx = tid; idx < RB * RB; idx += F3_NT) sK[idx] = 0.0;
+  for (int idx = tid; idx < RB * 32; idx += F3_NT) {
+    const int m = idx >> 5, c = idx & 31;
+    const double v = b.Aprev[m * r + min(c, r - 1)];
+    sA[m * F3_AS + c] = c < r ? v : 0.0;
+  }
+  for (int idx = tid; idx < RB * F3_AS; idx += F3_NT) {
+    const int m = idx / F3_AS, q = idx - m * F3_AS;
+    const double v = b.XG[(size_t)m * XGB + min(q, nb - 1)];
+    sX[m * F3_AS + q] = q < nb ? v : 0.0;
+  }
+  __syncthreads();
+  // tracked G of the previous block, T-layout dump (an assembled block always follows a filter3 block): wave w takes
+  // registers w and w + 8
+#pragma unroll
+  for (int e = w; e < 16; e += 8) {
+    const int row = 16 * (e >> 3) + lrow + 4 * (e & 3), col = 16 * ((e >> 2) & 1) + lcol;
+    const double g = st->f3_G[e * 64 + lane];
+    if (row < r && col < r) sK[row * RB + col] = g;
+  }
+  for (int idx = tid; idx < nb * nb; idx += F3_NT) { const int q = idx / nb, q2 = idx - q * nb; sK[(r + q) * RB + r + q2] = b.XG[(size_t)(RB + q) * XGB + q2]; }
+  const int nct = (nb + 15) >> 4;
+  if (w < 2 * nct) {
+    const int ti = w & 1, ct = w >> 1;
+    f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kk = 0; kk < RB / 4; ++kk)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sA[(4 * kk + lrow) * F3_AS + 16 * ti + lcol], sX[(4 * kk + lrow) * F3_AS + 16 * ct + lcol], acc, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = 16 * ti + lrow + 4 * q, c = 16 * ct + lcol;
+      if (i < r && c < nb) { sK[i * RB + r + c] = acc[q]; sK[(r + c) * RB + i] = acc[q]; }
+    }
+  }
+  __syncthreads();
 }
 
 // One Newton-Schulz iteration of tile column C:  R = I - M X_c,  Xn = X_c + X^T R  (see the header).
@@ -241,30 +291,27 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
         const int row = 16 * ti + lrow + 4 * qq, col = 16 * tj + lcol;
         const bool in = row < r && col < r;
         const int e = (ti * 2 + tj) * 4 + qq;
-        G[e] = in ? L.sK[row * RB + col] : 0.0;                              // G_0: exact Gram of the stored C
-        // the block starts from Lbar itself (carried over, or just formed by the sweep): as a W, q I - q^2 Lbar
-        const double l0 = carried ? st->Lbar[in ? row * r + col : 0] : imgX[row * F3_S + col];
-        Wf[e] = in ? ((row == col ? q0 : 0.0) - q0 * q0 * l0) : 0.0;
+        G[e] = in ? L.sK[row * RB + col] : 0.0;                              // G_0: exact Gram of the stored C / tracked G
+        if (carried) {
+          Wf[e] = st->f3_W[e * 64 + lane];
+        } else {
+          // the block starts from Lbar itself (just formed by the sweep): as a W, q I - q^2 Lbar
+          const double l0 = imgX[row * F3_S + col];
+          Wf[e] = in ? ((row == col ? q0 : 0.0) - q0 * q0 * l0) : 0.0;
+        }
       }
 #pragma unroll
-  for (int ti = 0; ti < 2; ++ti)
+  for (int e = 0; e < 8; ++e) {
+    const int row = 16 * (e >> 2) + lrow + 4 * (e & 3);
+    Xc[e] = carried ? st->f3_Xc[role][e * 64 + lane] : (row == 16 * C + lcol ? 1.0 : 0.0);
+  }
 #pragma unroll
-    for (int qq = 0; qq < 4; ++qq) {
-      const int row = 16 * ti + lrow + 4 * qq, cc = 16 * C + lcol;
-      const double* src = isX ? st->XpX : st->XpY;
-      const bool ic = carried && row < r && cc < r;
-      const double xc = src[ic ? row * r + cc : 0];
-      Xc[ti * 4 + qq] = ic ? xc : (row == cc ? 1.0 : 0.0);
-#pragma unroll
-      for (int to = 0; to < 2; ++to) {          // tile (kt = ti, to), register qq, P-layout
-        const int cp = 16 * to + pcol;
-        const bool ip = carried && row < r && cp < r;
-        const double xp = src[ip ? row * r + cp : 0];
-        Xa[to * 8 + ti * 4 + qq] = (float)(ip ? xp : (row == cp ? 1.0 : 0.0));
-      }
-    }
+  for (int e = 0; e < 16; ++e) {
+    const int row = 16 * ((e >> 2) & 1) + lrow + 4 * (e & 3), cp = 16 * (e >> 3) + pcol;
+    Xa[e] = carried ? st->f3_Xa[role][e * 64 + lane] : (row == cp ? 1.f : 0.f);
+  }
   if (isX) {
-    // <G_0, P> and tr G_0 of the own column, for eta of the first step (Pbar_1 = P + q I)
+    // <G_0, P> and tr G_0 of the own column, for eta of the first step (Pbar_1 = P + q I); carried: P = beta omega P+
     double g1 = 0.0, t1 = 0.0;
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti)
@@ -272,8 +319,10 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
       for (int qq = 0; qq < 4; ++qq) {
         const int row = 16 * ti + lrow + 4 * qq, col = 16 * C + lcol;
         const bool in = row < r && col < r;
-        const double pv = st->P[in ? row * r + col : 0];
         const double g = G[(ti * 2 + C) * 4 + qq];
+        double pv;
+        if (carried) pv = Xc[ti * 4 + qq];            // wave 4 applies beta omega
+        else pv = st->P[in ? row * r + col : 0];
         g1 += in ? g * pv : 0.0;
         t1 += (row == col) ? g : 0.0;
       }
@@ -320,7 +369,7 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
   F3Ctl ctl = {carried, 0, 0, 0, 0, 0};
   int w_par = 0;
   bool w_from_img = false;
-  double iq_w = 1.0 / q0;          // 1 / q that Wf was formed with
+  double iq_w = carried ? st->f3_sc[0] : 1.0 / q0;          // 1 / q that Wf was formed with
   BLK_T0();
   for (int jb = 0; jb < b.nb; ++jb) {
     // phase 0 (wave 4 forms w, s, kappa meanwhile): what the step that just ended left to do off the critical path
@@ -479,23 +528,39 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
   if (b.nb > 0) F3_W_AND_TRACES();
   f3_barrier();                       // wave 4 has published pscale and 1 / omega of the last step
   const double ps = L.sc[F3_PSCALE], iom = L.sc[F3_IOM];
+  // the state for the next block, as held: coalesced rows
 #pragma unroll
-  for (int ti = 0; ti < 2; ++ti)
+  for (int e = 0; e < 8; ++e) st->f3_Xc[role][e * 64 + lane] = Xc[e];
 #pragma unroll
-    for (int qq = 0; qq < 4; ++qq) {
-      const int row = 16 * ti + lrow + 4 * qq, col = 16 * C + lcol;
-      if (row < r && col < r) {
-        const int idx = row * r + col;
-        if (isX) {
-          st->XpX[idx] = Xc[ti * 4 + qq];
-          st->P[idx] = ps * Xc[ti * 4 + qq];
-          st->G[idx] = G[(ti * 2 + C) * 4 + qq];
-        } else {
-          st->XpY[idx] = Xc[ti * 4 + qq];
-          st->Lbar[idx] = ((row == col ? iq_w : 0.0) - Wf[(ti * 2 + C) * 4 + qq] * iq_w * iq_w) * iom;
+  for (int e = 0; e < 16; ++e) st->f3_Xa[role][e * 64 + lane] = Xa[e];
+  if (role == 0) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) st->f3_G[e * 64 + lane] = G[e];
+    if (lane == 0) st->f3_sc[0] = iq_w;
+  }
+  if (role == 2) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) st->f3_W[e * 64 + lane] = Wf[e];
+  }
+  if (b.last) {
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        const int row = 16 * ti + lrow + 4 * qq, col = 16 * C + lcol;
+        if (row < r && col < r) {
+          const int idx = row * r + col;
+          if (isX) {
+            st->XpX[idx] = Xc[ti * 4 + qq];
+            st->P[idx] = ps * Xc[ti * 4 + qq];
+            st->G[idx] = G[(ti * 2 + C) * 4 + qq];
+          } else {
+            st->XpY[idx] = Xc[ti * 4 + qq];
+            st->Lbar[idx] = ((row == col ? iq_w : 0.0) - Wf[(ti * 2 + C) * 4 + qq] * iq_w * iq_w) * iom;
+          }
         }
       }
-    }
+  }
   if (role == 0 && lane == 0) { st->cnt[0] += ctl.c_ns; st->cnt[1] += ctl.c_sw; st->cnt[2] += ctl.c_it; st->cnt[3] += ctl.c_fail; }
 #undef F3_ITERATE
 #undef F3_FETCH_PARTNER
@@ -523,14 +588,22 @@ __device__ __forceinline__ void f3_v_program(const BlockParams& b, const F3Lds& 
   double kappa = 0.0, Nk = 0.0, invN = 0.0, s_k = 0.0, eta_k = 0.0, ee_k = 0.0, phi = 1.0, omega = 1.0, pscale = 1.0, wj = 0.0;
   double q = st->Q[0];                  // Q = q I (checked by the host)
   double rho = st->rho, lam = st->lam;
+  double iom0 = 1.0;                    // 1 / omega of the last step of the previous block (carried W is not yet divided by it)
   if (isV0) {
     const int j = lane & 31, hf = lane >> 5;
+    if (carried) {
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const int i = 16 * hf + t;
-      const bool in = i < r && j < r;
-      const double v = st->V[in ? i * r + j : 0];
-      pr[t] = in ? v : 0.0;
+      for (int t = 0; t < 16; ++t) pr[t] = st->f3_V[t * 64 + lane];
+      iom0 = st->f3_sc[1];
+      pscale = st->f3_sc[2];
+    } else {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int i = 16 * hf + t;
+        const bool in = i < r && j < r;
+        const double v = st->V[in ? i * r + j : 0];
+        pr[t] = in ? v : 0.0;
+      }
     }
   } else if (isV1) {
 #pragma unroll
@@ -562,13 +635,14 @@ __device__ __forceinline__ void f3_v_program(const BlockParams& b, const F3Lds& 
   } while (0)
 
   F3Ctl ctl = {carried, 0, 0, 0, 0, 0};
+  if (role == 4 && lane == 0) L.tick[0] = (long long)__builtin_amdgcn_s_memrealtime();
   BLK_T0();
   for (int jb = 0; jb < b.nb; ++jb) {
     // =============================== phase 0 ===============================
     double cm = 0.0;                       // V1: a_m, V2: (K a)_m  (kept for the rank-1 update of phase 2)
     if (isV0) {
       const int j = lane & 31, hf = lane >> 5;
-      double iom = 1.0;
+      double iom = iom0;
       if (jb > 0) { F3_V0_FINISH_PREV(); iom = fast_rcp(omega); }
       double part0 = 0.0, part1 = 0.0;
 #pragma unroll
@@ -688,6 +762,7 @@ __device__ __forceinline__ void f3_v_program(const BlockParams& b, const F3Lds& 
     BLK_T(1);
   }
   BLK_TOUT();
+  if (role == 4 && lane == 0) L.tick[1] = (long long)__builtin_amdgcn_s_memrealtime();
 
   // ---- block end ----
   if (isV0) {
@@ -698,20 +773,27 @@ __device__ __forceinline__ void f3_v_program(const BlockParams& b, const F3Lds& 
   if (isV0) {
     const int j = lane & 31, hf = lane >> 5;
 #pragma unroll
-    for (int t = 0; t < 16; ++t) {
-      const int i = 16 * hf + t;
-      if (i < r && j < r) {
-        st->V[i * r + j] = pr[t];
-        st->Q[i * r + j] = (i == j) ? q : 0.0;
+    for (int t = 0; t < 16; ++t) st->f3_V[t * 64 + lane] = pr[t];
+    if (b.last) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int i = 16 * hf + t;
+        if (i < r && j < r) {
+          st->V[i * r + j] = pr[t];
+          st->Q[i * r + j] = (i == j) ? q : 0.0;
+        }
       }
+    } else if (hf == 0 && j < r) {
+      st->Q[j * r + j] = q;             // Q = q I: the diagonal is what the next block reads (Q[0])
     }
     if (lane < r) st->mu[lane] = L.mub[lane];
     if (lane == 0) {
+      st->f3_sc[1] = L.sc[F3_IOM]; st->f3_sc[2] = pscale;
       st->k = b.k0 + b.nb;
       st->rho = rho; st->lam = lam; st->phi = phi; st->omega = omega; st->ee = ee_k;
       st->s_done = s_k; st->eta_done = eta_k; st->N_done = Nk;
       if (*L.errflag && st->err == 0) st->err = (int)(b.k0 + 1);
-      st->ns_valid = 1;
+      st->ns_valid = 3;
     }
   } else if (isV1) {
 #pragma unroll
@@ -739,8 +821,8 @@ __global__ __launch_bounds__(F3_NT) void psmf_blk_filter3(BlockParams b) {
   F3Lds L;
   L.sK = sm;
   L.sA = L.sK + RB * RB;
-  L.sKA = L.sA + RB * RS;
-  L.img = L.sKA + RB * RS;
+  L.sKA = L.sA + RB * F3_AS;
+  L.img = L.sKA + RB * F3_AS;
   L.rowbufX = L.img + 2 * 32 * F3_S;
   L.rowbufY = L.rowbufX + 4 * RM;
   L.errflag = reinterpret_cast<int*>(L.rowbufY + 4 * RM);
@@ -756,18 +838,22 @@ __global__ __launch_bounds__(F3_NT) void psmf_blk_filter3(BlockParams b) {
   L.hv = L.nrm + 8;
   L.gp = L.hv + 2;
   L.tr = L.gp + 2;
+  __shared__ long long s_tick[2];
+  L.tick = s_tick;
 
   if (!blk_handoff_begin(b)) return;
+  const long long t_h = (long long)__builtin_amdgcn_s_memrealtime();
   if (!b.assemble) {
     for (int idx = tid; idx < RB * RB; idx += F3_NT) L.sK[idx] = b.K[idx];
   } else {
-    assemble_K<F3_NT>(b, L.sK, L.sA, L.sKA, r, tid);
+    f3_assemble_K(b, L, r, tid);
   }
   if (tid == 0) *L.errflag = 0;
   if (tid < RM) { L.mub[tid] = (tid < r) ? st->mu[tid] : 0.0; L.w[tid] = 0.0; L.h[tid] = 0.0; }
   if (tid < F3_NSC) L.sc[tid] = 0.0;
-  const bool carried = st->ns_valid != 0;
+  const bool carried = st->ns_valid == 3;       // the previous block (or run) left the f3_* register dump behind
   __syncthreads();
+  const long long t_a = (long long)__builtin_amdgcn_s_memrealtime();
   if (!carried) {
     // Lbar_1 = (P + q I)^-1 by the direct sweep: both halves run it in lockstep on their own image
     const int lt = tid & (WG - 1), c32 = lt & 31, rg = lt >> 5;
@@ -793,6 +879,7 @@ __global__ __launch_bounds__(F3_NT) void psmf_blk_filter3(BlockParams b) {
   if (tid == 0) {
     // cnt[4]: sum of in-kernel durations, cnt[5]: sum of the gaps to the previous filter kernel, cnt[7]: launches (10 ns ticks)
     const long long t_end = (long long)__builtin_amdgcn_s_memrealtime();
+    st->dbg[0] += t_h - t_begin; st->dbg[1] += t_a - t_h; st->dbg[2] += L.tick[0] - t_a; st->dbg[3] += L.tick[1] - L.tick[0]; st->dbg[4] += t_end - L.tick[1];
     st->cnt[4] += t_end - t_begin;
     if (st->cnt[6] != 0) st->cnt[5] += t_begin - st->cnt[6];
     st->cnt[6] = t_end;

@@ -61,6 +61,7 @@ struct BlockParams {
   //   flags[2] = abort    a wait timed out
   long long* flags;
   long long seq;          // this block's sequence number
+  int last;               // filter3: last block of the run -> also write the row-major r x r state (DevState)
 };
 
 // ---- hand-off through device flags -------------------------------------------------------------------------------

@@ -181,6 +181,7 @@ int enqueue_step(psmf_filter* h) {
 // one block of nb steps of the blocked engine: Gram, reduction, (all-reduce), coefficient-space filter, apply
 void fill_block_params(psmf_filter* h, psmf::BlockParams& b, int64_t k0, int nb, int slot = 0) {
   memset(&b, 0, sizeof(b));
+  b.last = 1;            // standalone block; the pipelined loop clears it for all but a run's last block
   b.sp = h->sp;
   b.Kpart = h->Kpart; b.K = h->Kmat;
   b.Acoef = h->Acoef + (size_t)slot * psmf::RB * psmf::RM;
@@ -370,6 +371,7 @@ int enqueue_blocks_pipelined(psmf_filter* h, int64_t k_begin, int64_t k_end) {
       b.XG = h->XG + (size_t)(bi & 1) * xg_elems;
       b.Aprev = h->Acoef + (size_t)(slot ^ 1) * psmf::RB * psmf::RM;
     }
+    b.last = (bi + 1 == nblk) ? 1 : 0;
     if (use_flags) {
       b.flags = h->flags;
       b.seq = s0 + bi;
@@ -1022,10 +1024,14 @@ int psmf_counters(psmf_handle h, int64_t* out8, int reset) {
   if (!h || !out8) return PSMF_ERR_ARG;
   if (set_device(h) != PSMF_OK) return PSMF_ERR_HIP;
   HIP_TRY(h, hipStreamSynchronize(h->stream));
-  long long c[8];
+  long long c[8], g[8];
   HIP_TRY(h, hipMemcpy(c, h->st->cnt, sizeof(c), hipMemcpyDeviceToHost));
+  HIP_TRY(h, hipMemcpy(g, h->st->dbg, sizeof(g), hipMemcpyDeviceToHost));
   for (int i = 0; i < 8; ++i) out8[i] = c[i];
-  if (reset) HIP_TRY(h, hipMemset(h->st->cnt, 0, sizeof(c)));
+  if (getenv("PSMF_DBG_BREAKDOWN") && c[7] > 0)
+    fprintf(stderr, "[psmf] filter3 per launch: hand-off %.2f us, K %.2f, init %.2f, steps %.2f, end %.2f\n", 0.01 * g[0] / c[7], 0.01 * g[1] / c[7],
+            0.01 * g[2] / c[7], 0.01 * g[3] / c[7], 0.01 * g[4] / c[7]);
+  if (reset) { HIP_TRY(h, hipMemset(h->st->cnt, 0, sizeof(c))); HIP_TRY(h, hipMemset(h->st->dbg, 0, sizeof(g))); }
   return PSMF_OK;
 }
 

@@ -34,7 +34,14 @@ struct DevState {
   double s_done, eta_done, N_done;  // s, eta, N of the last finished step
   long long k;            // number of finished steps = 0-based series index of the current step
   int err;                // != 0: numeric failure (singular system) at step err
-  int ns_valid;           // Lbar / XpX / XpY describe the current state (cleared by every host state upload)
+  int ns_valid;           // != 0: Lbar / XpX / XpY describe the current state; 3: so does the f3_* dump (cleared by every host state upload)
+  // filter3 (psmf_blk3.hip): the r x r state between the blocks of a run, exactly as the waves hold it in registers
+  // ([register][lane]: coalesced 512-byte rows), valid while ns_valid == 3.  The row-major V / P / G / Lbar / XpX / XpY
+  // above are written by the LAST block of a run only (BlockParams.last).
+  double f3_G[16 * 64], f3_W[16 * 64], f3_Xc[4][8 * 64], f3_V[16 * 64];
+  float f3_Xa[4][16 * 64];
+  double f3_sc[8];        // [0] 1 / q that f3_W was formed with, [1] 1 / omega and [2] beta omega of the last step
+  long long dbg[8];       // filter3 in-situ breakdown (10 ns ticks): [0] hand-off, [1] K load / assembly, [2] state init, [3] step loop, [4] block end
   long long cnt[8];       // diagnostics of the blocked filter: [0] steps inverted by Newton-Schulz, [1] by the sweep,
                           // [2] Newton-Schulz iterations in total, [3] failed Newton-Schulz attempts (psmf_counters)
 };
