@@ -137,6 +137,16 @@ __device__ __forceinline__ void f3_assemble_K(const BlockParams& b, const F3Lds&
   double* sA = L.sA;
   double* sX = L.sA + RB * F3_AS;
   const DevState* st = b.sp.st;
+  // every global load of the assembly is issued before the first barrier (one L2 round trip, not two)
+  double gv[2], yy[5];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) gv[u] = st->f3_G[(w + 8 * u) * 64 + lane];     // tracked G of the previous block (T-layout dump:
+                                                                               // an assembled block always follows a filter3 block)
+#pragma unroll
+  for (int u = 0; u < 5; ++u) {
+    const int idx = min(tid + u * F3_NT, nb * nb - 1), q = idx / nb, q2 = idx - q * nb;
+    yy[u] = b.XG[(size_t)(RB + q) * XGB + q2];
+  }
   for (int idx = tid; idx < RB * RB; idx += F3_NT) sK[idx] = 0.0;
   for (int idx = tid; idx < RB * 32; idx += F3_NT) {
     const int m = idx >> 5, c = idx & 31;
@@ -149,15 +159,17 @@ __device__ __forceinline__ void f3_assemble_K(const BlockParams& b, const F3Lds&
     sX[m * F3_AS + q] = q < nb ? v : 0.0;
   }
   __syncthreads();
-  // tracked G of the previous block, T-layout dump (an assembled block always follows a filter3 block): wave w takes
-  // registers w and w + 8
 #pragma unroll
-  for (int e = w; e < 16; e += 8) {
+  for (int u = 0; u < 2; ++u) {
+    const int e = w + 8 * u;
     const int row = 16 * (e >> 3) + lrow + 4 * (e & 3), col = 16 * ((e >> 2) & 1) + lcol;
-    const double g = st->f3_G[e * 64 + lane];
-    if (row < r && col < r) sK[row * RB + col] = g;
+    if (row < r && col < r) sK[row * RB + col] = gv[u];
   }
-  for (int idx = tid; idx < nb * nb; idx += F3_NT) { const int q = idx / nb, q2 = idx - q * nb; sK[(r + q) * RB + r + q2] = b.XG[(size_t)(RB + q) * XGB + q2]; }
+#pragma unroll
+  for (int u = 0; u < 5; ++u) {
+    const int idx = tid + u * F3_NT;
+    if (idx < nb * nb) { const int q = idx / nb, q2 = idx - q * nb; sK[(r + q) * RB + r + q2] = yy[u]; }
+  }
   const int nct = (nb + 15) >> 4;
   if (w < 2 * nct) {
     const int ti = w & 1, ct = w >> 1;
@@ -768,6 +780,9 @@ __device__ __forceinline__ void f3_v_program(const BlockParams& b, const F3Lds& 
   if (isV0) {
     if (b.nb > 0) F3_V0_FINISH_PREV();
     if (lane == 0) { L.sc[F3_PSCALE] = pscale; L.sc[F3_IOM] = fast_rcp(omega); L.sc[F3_Q] = q; }
+  } else if (isV1) {
+#pragma unroll
+    for (int c = 0; c < 32; ++c) L.sA[lane * F3_AS + c] = pr[c];       // (a strided global store per column took ~4 us)
   }
   f3_barrier();
   if (isV0) {
@@ -795,11 +810,9 @@ __device__ __forceinline__ void f3_v_program(const BlockParams& b, const F3Lds& 
       if (*L.errflag && st->err == 0) st->err = (int)(b.k0 + 1);
       st->ns_valid = 3;
     }
-  } else if (isV1) {
-#pragma unroll
-    for (int c = 0; c < 32; ++c)
-      if (c < r) b.Acoef[lane * r + c] = pr[c];
   }
+  // A_B (wave 5's rows) left through LDS before the barrier above: all four vector waves store it, coalesced
+  for (int idx = tid - 256; idx < RB * r; idx += 256) { const int m = idx / r, c = idx - m * r; b.Acoef[idx] = L.sA[m * F3_AS + c]; }
 #undef F3_V0_FINISH_PREV
 }
 

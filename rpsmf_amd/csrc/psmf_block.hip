@@ -82,9 +82,10 @@ __device__ __forceinline__ bool blk_handoff_begin(const BlockParams& b) {
   if (!b.flags) return true;
   if (threadIdx.x == 0) {
     int ok = 1;
-    if (flag_load(b.flags + 2) != 0) ok = 0;
-    if (ok) {
-      flag_store(b.flags + 1, b.seq);                    // blocks < seq are complete
+    flag_store(b.flags + 1, b.seq);                      // blocks < seq are complete
+    const long long xg0 = flag_load(b.flags + 0), ab0 = flag_load(b.flags + 2);   // both loads in flight together
+    if (ab0 != 0) ok = 0;
+    if (ok && xg0 < b.seq) {
       long long polls = 0;
       while (flag_load(b.flags + 0) < b.seq) {
         __builtin_amdgcn_s_sleep(16);
