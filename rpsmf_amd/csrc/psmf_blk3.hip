@@ -448,9 +448,10 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
     bool done = false, failed = !try_ns;
     int it = 0;
     if (try_ns) F3_DECIDE();
+    bool fetch_late = false;         // converged: the partner's final column is only needed by the NEXT step -> after phase F
     if (try_ns && !failed) {
-      F3_FETCH_PARTNER(0);
-      if (!done) F3_ITERATE(1);
+      if (!done) { F3_FETCH_PARTNER(0); F3_ITERATE(1); }
+      else fetch_late = true;
     }
     {
       // G_k = G_{k-1} + (h w^T + w h^T) / N + ee w w^T / N^2   (tracked Gram)
@@ -478,8 +479,9 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
     if (try_ns && !done && !failed) { par = 1; it = 1; }
     while (try_ns && !done && !failed) {
       F3_DECIDE();
-      if (!failed) F3_FETCH_PARTNER(par);
+      if (done) fetch_late = true;
       if (done || failed) break;
+      F3_FETCH_PARTNER(par);
       F3_ITERATE(par ^ 1);
       par ^= 1;
       ++it;
@@ -531,6 +533,7 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
         if (lane == 0) L.hv[C] = hvp;
       }
     }
+    if (fetch_late) F3_FETCH_PARTNER(par);
     BLK_T(5);
     f3_barrier();                                                     // ---- BF
     BLK_T(1);
