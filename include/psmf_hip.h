@@ -158,7 +158,8 @@ typedef struct {
   int32_t abi_version;
   int32_t d, n, r;       /* Y is d x n, C d x r, X r x n (reference layout)                  */
   int32_t batch;         /* independent replicas (seeds): own mask, C0, X0                    */
-  int32_t robust;        /* 0: PSMF.py:40-95   1: rPSMF.py:40-148                              */
+  int32_t method;        /* 0: PSMF.py:40-95   1: rPSMF.py:40-148   2: MLE-SMF, MLESMF.py:40-92 (V unused)
+                          * 3: TMF, TMF.py:30-73 (V, P, Q, rho unused; nu = 2; no bands, inside = 0)        */
   int32_t n_iter;        /* passes over the n columns (Iter)                                  */
   int32_t device;
   int32_t want_bands;    /* also return Yrec, YrecL, YrecH                                    */
@@ -176,7 +177,8 @@ typedef struct {
  *   Epred, Efull  batch x n_iter  (RMSE after each pass, PSMF.py:88-89)
  *   inside        batch           (coverage, common.py:87-94)
  *   Yrec, YrecL, YrecH  batch x n x d float64 or NULL
- * replaces ProbabilisticSequentialMatrixFactorizer / robust_PSMF and the RMSEM /
+ * replaces ProbabilisticSequentialMatrixFactorizer / robust_PSMF (and, method 2 / 3, the baseline filters
+ * stochasticGradientStateSpaceMF / temporalRegularizedMF that share their masked contractions) and the RMSEM /
  * compute_number_inside_bars calls made on their outputs. */
 int psmf_impute_run(const psmf_impute_config* cfg, const double* YorgInt, const uint8_t* M,
                     const uint8_t* Mmiss, double* C, double* X, const double* V,

@@ -35,7 +35,7 @@ class PsmfConfig(C.Structure):
 
 class PsmfImputeConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
-        "abi_version", "d", "n", "r", "batch", "robust", "n_iter", "device", "want_bands")] + [
+        "abi_version", "d", "n", "r", "batch", "method", "n_iter", "device", "want_bands")] + [
         ("sig", C.c_double), ("lambda0", C.c_double)]
 
 

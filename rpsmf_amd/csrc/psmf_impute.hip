@@ -1,6 +1,9 @@
 // Masked, batched small-d engine: the filter loops of ExperimentImpute
 //   ProbabilisticSequentialMatrixFactorizer   ExperimentImpute/PSMF.py:40-95
 //   robust_PSMF                               ExperimentImpute/rPSMF.py:40-148
+// and the two baseline filters of the imputation tables that share their masked contractions
+//   stochasticGradientStateSpaceMF (MLE-SMF)  ExperimentImpute/MLESMF.py:40-92   weights m_i / rho_i, C += gam / eta (m o e) x_p^T
+//   temporalRegularizedMF (TMF)               ExperimentImpute/TMF.py:30-73      x_t = x_p + (nu I + G)^-1 C^T e, C += gam (m o e) x_p^T
 // plus the RMSEM / compute_number_inside_bars reductions made on their outputs
 // (ExperimentImpute/common.py:79-94), for a whole batch of independent replicas (seeds).
 //
@@ -25,6 +28,7 @@ constexpr int IR = 16;   // largest rank of the masked engine (experiments use r
 
 struct ImputeParams {
   int d, n, r, n_iter, robust, want_bands;
+  int method;              // 0 PSMF, 1 rPSMF (robust = 1), 2 MLE-SMF, 3 TMF
   double sig, lambda0, rho0;
   const double* Yorg;      // n x d (shared)
   const uint8_t* M;        // batch x n x d
@@ -104,7 +108,10 @@ __global__ __launch_bounds__(WG) void psmf_impute_kernel(ImputeParams p) {
   const bool ein = ei < r && ec < r;
 
   unsigned long long nmiss_l = 0;   // per-thread counts, rows tid, tid + 256, ...
+  const bool sgd = p.method >= 2;     // MLE-SMF / TMF: gradient step on C along x_p, no V
+  const bool tmf = p.method == 3;
   for (int it = 0; it < p.n_iter; ++it) {
+    const double gam = 1e-6 / pow((double)(it + 1), 0.7);     // MLESMF.py:59-60, TMF.py:46-48
     if (p.robust) {                 // rPSMF.py:77-79: Q, R, lambda restart every pass; V, P, C carry over
       for (int idx = tid; idx < r * r; idx += WG) sQ[idx] = p.Q0[idx];
       rho = p.rho0;
@@ -165,7 +172,8 @@ __global__ __launch_bounds__(WG) void psmf_impute_kernel(ImputeParams p) {
       __syncthreads();
       double s = 0.0;
       for (int l = 0; l < r; ++l) s += sx[l] * sw[l];
-      const double kappa = 1.0 / (rho + s);
+      // weights of the observed rows: PSMF / rPSMF 1 / (rho + s) (PSMF.py:71-72), MLE-SMF 1 / rho (MLESMF.py:70), TMF 1
+      const double kappa = tmf ? 1.0 : (sgd ? 1.0 / rho : 1.0 / (rho + s));
       // ---- B: augmented masked Gram  [C | e]^T diag(m) [C | e]  + sum(m) ----
 #pragma unroll
       for (int rd = 0; rd < 3; ++rd) {
@@ -195,7 +203,8 @@ __global__ __launch_bounds__(WG) void psmf_impute_kernel(ImputeParams p) {
       const double msum = sred[0], ee = sred[1];
       // ---- C: PP = P + Q, <G, PP>, P+ = (PP^-1 + kappa G)^-1 ----
       double A1[1], G1[1];
-      const double ppv = ein ? 0.5 * ((sP[ei * r + ec] + sQ[ei * r + ec]) + (sP[ec * r + ei] + sQ[ec * r + ei])) : 0.0;
+      // TMF: (nu I + G)^-1 is the same solve with PP = I / nu, nu = 2 (TMF.py:47,60)
+      const double ppv = ein ? (tmf ? (ei == ec ? 0.5 : 0.0) : 0.5 * ((sP[ei * r + ec] + sQ[ei * r + ec]) + (sP[ec * r + ei] + sQ[ec * r + ei]))) : 0.0;
       const double gv = ein ? sG[ei * r + ec] : 0.0;
       A1[0] = ein ? ppv : ((ei == ec && ei < r2) ? 1.0 : 0.0);
       G1[0] = kappa * gv;
@@ -229,21 +238,22 @@ __global__ __launch_bounds__(WG) void psmf_impute_kernel(ImputeParams p) {
       }
       const double wsc = 1.0 / N;
       // ---- E: C, V, P, bands, metrics ----
+      const double csc = tmf ? gam : gam / eta;        // MLESMF.py:79, TMF.py:63
       for (int idx = tid; idx < d * r; idx += WG) {
         const int i = idx / r, l = idx - i * r;
-        sC[idx] += se[i] * sw[l] * wsc;
+        sC[idx] += sgd ? se[i] * sx[l] * csc : se[i] * sw[l] * wsc;
       }
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int i = tid + u * WG;
         if (i < d) {
-          const double band = p.sig * sqrt(p.robust ? (s * (mv[u] ? 1.0 : 0.0) + eta) : N);   // rPSMF.py:121-123 / PSMF.py:83-84
+          const double band = p.sig * sqrt(p.robust ? (s * (mv[u] ? 1.0 : 0.0) + eta) : (sgd ? eta : N));   // rPSMF.py:121-123 / PSMF.py:83-84 / MLESMF.py:81-82
           const double lo = yh[u] - band, hi = yh[u] + band;
           if (mmv[u]) {
             const double dl = yh[u] - yv[u];
             sse_pred += dl * dl;
             nmiss_l += 1;
-            if (it == p.n_iter - 1 && yv[u] < hi && lo < yv[u]) inside_l += 1;
+            if (it == p.n_iter - 1 && !tmf && yv[u] < hi && lo < yv[u]) inside_l += 1;
           }
           if (p.want_bands) {
             const size_t off = ((size_t)rep * n + t) * d + i;
@@ -255,8 +265,7 @@ __global__ __launch_bounds__(WG) void psmf_impute_kernel(ImputeParams p) {
       }
       __syncthreads();   // all reads of sV, sx, sP, sQ, sPp of this column are done
       if (ein) {
-        const double vv = phi * (sV[ei * r + ec] - sw[ei] * sw[ec] * wsc);
-        sV[ei * r + ec] = vv;
+        if (!sgd) sV[ei * r + ec] = phi * (sV[ei * r + ec] - sw[ei] * sw[ec] * wsc);
         sP[ei * r + ec] = omega * 0.5 * (sPp[ei * r + ec] + sPp[ec * r + ei]);
         if (p.robust) sQ[ei * r + ec] *= omega;
       }
@@ -320,6 +329,7 @@ extern "C" int psmf_impute_run(const psmf_impute_config* cfg, const double* Yorg
   if (r < 1 || r > IR) return fail(PSMF_ERR_ARG, "need 1 <= r <= 16");
   if (d < 1 || d > 2 * WG) return fail(PSMF_ERR_ARG, "need 1 <= d <= 512 (one workgroup per replica)");
   if (n < 2 || B < 1 || cfg->n_iter < 1) return fail(PSMF_ERR_ARG, "bad n / batch / n_iter");
+  if (cfg->method < 0 || cfg->method > 3) return fail(PSMF_ERR_ARG, "method must be 0 (PSMF), 1 (rPSMF), 2 (MLE-SMF) or 3 (TMF)");
   if (cfg->want_bands && (!Yrec || !YrecL || !YrecH)) return fail(PSMF_ERR_ARG, "want_bands needs Yrec, YrecL, YrecH");
   const size_t lds = impute_lds_bytes(d, r);
   if (lds > 160 * 1024) return fail(PSMF_ERR_ARG, "d * r does not fit one workgroup's LDS");
@@ -368,7 +378,7 @@ extern "C" int psmf_impute_run(const psmf_impute_config* cfg, const double* Yorg
   I_TRY(hipMemcpy(dV, V, r * r * 8, hipMemcpyHostToDevice));
   I_TRY(hipMemcpy(dP, P, r * r * 8, hipMemcpyHostToDevice));
   I_TRY(hipMemcpy(dQ, Q, r * r * 8, hipMemcpyHostToDevice));
-  ip.d = d; ip.n = n; ip.r = r; ip.n_iter = cfg->n_iter; ip.robust = cfg->robust; ip.want_bands = cfg->want_bands;
+  ip.d = d; ip.n = n; ip.r = r; ip.n_iter = cfg->n_iter; ip.robust = cfg->method == 1; ip.method = cfg->method; ip.want_bands = cfg->want_bands;
   ip.sig = cfg->sig; ip.lambda0 = cfg->lambda0; ip.rho0 = rho;
   ip.Yorg = dY; ip.M = dM; ip.Mmiss = dMm; ip.C = dC; ip.X = dX; ip.V0 = dV; ip.P0 = dP; ip.Q0 = dQ;
   ip.Epred = dEp; ip.Efull = dEf; ip.inside = dIn; ip.Yrec = dYr; ip.YrecL = dYl; ip.YrecH = dYh; ip.err = dErr;

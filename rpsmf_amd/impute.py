@@ -16,7 +16,10 @@ import numpy as np
 
 from . import _capi
 
-__all__ = ["ProbabilisticSequentialMatrixFactorizer", "robust_PSMF", "impute_batch"]
+__all__ = ["ProbabilisticSequentialMatrixFactorizer", "robust_PSMF", "stochasticGradientStateSpaceMF", "temporalRegularizedMF",
+           "impute_batch"]
+
+METHODS = {"psmf": 0, "rpsmf": 1, "mle_smf": 2, "tmf": 3}
 
 
 def _uniform_rho(R, d):
@@ -32,12 +35,13 @@ def _uniform_rho(R, d):
 
 
 def impute_batch(YorgInt, M, Mmiss, C0, X0, V, Q, R, P, sig, Iter, robust=False, lambda0=0.0, device=0,
-                 want_bands=False):
+                 want_bands=False, method=None):
     """Run `batch` replicas.  Reference layouts: YorgInt (d, n); M, Mmiss (batch, d, n);
     C0 (batch, d, r); X0 (batch, r, n).  Returns a dict with Epred, Efull (batch, Iter),
     inside (batch,), C (batch, d, r), X (batch, r, n), elapsed_ms and, if requested,
     Yrec / YrecL / YrecH (batch, d, n)."""
     lib = _capi.load_library()
+    meth = METHODS[method] if method is not None else int(bool(robust))     # "mle_smf" / "tmf": the baseline filters
     YorgInt = np.asarray(YorgInt, dtype=np.float64)
     d, n = YorgInt.shape
     M = np.asarray(M)
@@ -61,7 +65,7 @@ def impute_batch(YorgInt, M, Mmiss, C0, X0, V, Q, R, P, sig, Iter, robust=False,
     Efull = np.zeros((B, Iter))
     inside = np.zeros(B)
     bands = [np.zeros((B, n, d)) for _ in range(3)] if want_bands else [None, None, None]
-    cfg = _capi.PsmfImputeConfig(abi_version=_capi.ABI_VERSION, d=d, n=n, r=r, batch=B, robust=int(robust),
+    cfg = _capi.PsmfImputeConfig(abi_version=_capi.ABI_VERSION, d=d, n=n, r=r, batch=B, method=meth,
                                  n_iter=int(Iter), device=int(device), want_bands=int(want_bands),
                                  sig=float(sig), lambda0=float(lambda0))
     ms = C.c_float()
@@ -84,14 +88,14 @@ def impute_batch(YorgInt, M, Mmiss, C0, X0, V, Q, R, P, sig, Iter, robust=False,
     return out
 
 
-def _single(Y, C, X, d, n, r, M, Mmiss, V, Q, R, P, sig, Iter, YorgInt, Einit, robust, lambda0):
+def _single(Y, C, X, d, n, r, M, Mmiss, V, Q, R, P, sig, Iter, YorgInt, Einit, robust, lambda0, method=None):
     Y = np.asarray(Y, dtype=float)
     YorgInt = np.asarray(YorgInt, dtype=float)
     if Y.shape != (d, n) or C.shape != (d, r) or X.shape != (r, n):
         raise ValueError("shape mismatch with d, n, r")
     if not np.array_equal(Y, YorgInt * (np.asarray(M) != 0)):
         raise ValueError("the device path requires Y == YorgInt * M (as the experiment constructs it)")
-    res = impute_batch(YorgInt, M, Mmiss, C, X, V, Q, R, P, sig, Iter, robust=robust, lambda0=lambda0)
+    res = impute_batch(YorgInt, M, Mmiss, C, X, V, Q, R, P, sig, Iter, robust=robust, lambda0=lambda0, method=method)
     X[...] = res["X"][0]  # the reference updates the caller's X in place (PSMF.py:74)
     Epred = np.zeros((1, Iter + 1))
     Efull = np.zeros((1, Iter + 1))
@@ -112,3 +116,16 @@ def ProbabilisticSequentialMatrixFactorizer(Y, C, X, d, n, r, M, Mmiss, lam, V, 
 def robust_PSMF(Y, C, X, d, n, r, M, Mmiss, V, Q0, R0, P, lambda0, sig, Iter, YorigInt, Einit):
     """ExperimentImpute/rPSMF.py:40-148 on the device."""
     return _single(Y, C, X, d, n, r, M, Mmiss, V, Q0, R0, P, sig, Iter, YorigInt, Einit, True, lambda0)
+
+
+def stochasticGradientStateSpaceMF(Y, C, X, d, n, r, M, Mmiss, lam, Q, R, P, sig, Iter, YorgInt, Einit):
+    """MLE-SMF, ExperimentImpute/MLESMF.py:40-92, on the device (same arguments and return tuple; `lam` is unused there)."""
+    return _single(Y, C, X, d, n, r, M, Mmiss, np.eye(r), Q, R, P, sig, Iter, YorgInt, Einit, False, 0.0, method="mle_smf")
+
+
+def temporalRegularizedMF(Y, C, X, d, n, r, M, Mmiss, lam, R, Iter, YorgInt, Einit):
+    """TMF, ExperimentImpute/TMF.py:30-73, on the device.  Returns (Epred, Efull, RunTime) like the reference
+    (`lam` and `R` are unused there)."""
+    I = np.eye(r)
+    ep, ef, rt, _ = _single(Y, C, X, d, n, r, M, Mmiss, I, I, 1.0, I, 0.0, Iter, YorgInt, Einit, False, 0.0, method="tmf")
+    return ep, ef, rt

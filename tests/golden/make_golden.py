@@ -346,6 +346,32 @@ def case_impute_synth(seed=7, d=19, n=400, r=10):
     return out
 
 
+def case_impute_baselines():
+    """MLE-SMF and TMF (the two baseline filters that share the masked contractions) run by the reference
+    on the inputs of the impute_synth fixture (which must exist)."""
+    sys.path.insert(0, os.path.join(REF, "ExperimentImpute"))
+    cwd = os.getcwd()
+    os.chdir("/tmp")
+    import MLESMF as ref_mle
+    import TMF as ref_tmf
+
+    os.chdir(cwd)
+    g = np.load(os.path.join(OUT, "impute_synth.npz"))
+    Yorig, Mmiss, M, Y, C, X, Einit = g["Yorig"], g["Mmiss"], g["M"], g["Y"], g["C0"], g["X0"], float(g["Einit"])
+    d, n = Y.shape
+    r = C.shape[1]
+    YorigInt = np.nan_to_num(Yorig, nan=0.0)
+    Q, P, R = 0.1 * np.eye(r), 1.0 * np.eye(r), 10 * np.eye(d)     # MLESMF.py:116-124, TMF.py:98-99
+    out = dict(Iter=2)
+    Xa = X.copy()
+    ep, ef, _, ib = ref_mle.stochasticGradientStateSpaceMF.func(Y, C.copy(), Xa, d, n, r, M, Mmiss, 10, Q, R, P, 2, 2, YorigInt, Einit)
+    out.update(mle_Epred=ep, mle_Efull=ef, mle_inside=ib, mle_X=Xa)
+    Xb = X.copy()
+    ep, ef, _ = ref_tmf.temporalRegularizedMF.func(Y, C.copy(), Xb, d, n, r, M, Mmiss, 10, R, 2, YorigInt, Einit)
+    out.update(tmf_Epred=ep, tmf_Efull=ef, tmf_X=Xb)
+    return out
+
+
 def case_impute_kat(dataset="LondonAir_PM25", n_rep=2):
     """The reference's stored known answers + the data file they were computed on."""
     Yorig = np.genfromtxt(os.path.join(REF, "ExperimentImpute/data", dataset + ".csv"), delimiter=",")
@@ -376,6 +402,7 @@ def main():
         "rpsmf_recursive": lambda: case_recursive(True, 15),
         "impute_synth": case_impute_synth,
         "impute_kat_pm25": case_impute_kat,
+        "impute_baselines": case_impute_baselines,
     }
     only = sys.argv[1:]
     for name, fn in cases.items():

@@ -129,6 +129,37 @@ def test_impute_reference_functions_synthetic():
     assert relerr(X, g["rpsmf_X"]) < 1e-8
 
 
+def test_impute_baseline_filters_vs_reference_outputs():
+    """MLE-SMF and TMF (the baseline filters that share the masked contractions) through the drop-in functions,
+    against the reference functions' own outputs on the impute_synth inputs; MLE-SMF bands and final C against the oracle."""
+    from oracle.impute_oracle import mle_smf_filter
+
+    g, b = load_golden("impute_synth"), load_golden("impute_baselines")
+    Yint = np.nan_to_num(g["Yorig"], nan=0.0)
+    d, n = Yint.shape
+    r = g["C0"].shape[1]
+    Q, P, R = 0.1 * np.eye(r), np.eye(r), 10 * np.eye(d)
+    X = g["X0"].copy()
+    ep, ef, rt, ib = impute.stochasticGradientStateSpaceMF(
+        g["Y"], g["C0"].copy(), X, d, n, r, g["M"], g["Mmiss"], 10, Q, R, P, 2, 2, Yint, float(g["Einit"]))
+    assert relerr(ep, b["mle_Epred"]) < 1e-9 and relerr(ef, b["mle_Efull"]) < 1e-9
+    assert abs(ib - float(b["mle_inside"])) < 1e-12
+    assert relerr(X, b["mle_X"]) < 1e-8
+    X = g["X0"].copy()
+    ep, ef, rt = impute.temporalRegularizedMF(
+        g["Y"], g["C0"].copy(), X, d, n, r, g["M"], g["Mmiss"], 10, R, 2, Yint, float(g["Einit"]))
+    assert relerr(ep, b["tmf_Epred"]) < 1e-9 and relerr(ef, b["tmf_Efull"]) < 1e-9
+    assert relerr(X, b["tmf_X"]) < 1e-8
+    # batch of 2 identical replicas with bands: final C, bands vs the oracle
+    Xo = g["X0"].copy()
+    _, _, _, st = mle_smf_filter(g["Y"], g["C0"], Xo, g["M"], g["Mmiss"], Q, 10.0, P, 2, 2, Yint, float(g["Einit"]), return_state=True)
+    res = impute.impute_batch(Yint, np.stack([g["M"]] * 2), np.stack([g["Mmiss"]] * 2), np.stack([g["C0"]] * 2), np.stack([g["X0"]] * 2),
+                              np.eye(r), Q, 10.0, P, 2, 2, method="mle_smf", want_bands=True)
+    for rep in range(2):
+        assert relerr(res["C"][rep], st["C"]) < 1e-10
+        assert relerr(res["YrecL"][rep], st["YrecL"]) < 1e-9 and relerr(res["YrecH"][rep], st["YrecH"]) < 1e-9
+
+
 @pytest.mark.parametrize("method", ["PSMF", "rPSMF"])
 def test_impute_stored_known_answers_batched(method):
     """The reference's stored results for LondonAir_PM25 (40 %, seed 123), first two repeats as ONE batch."""

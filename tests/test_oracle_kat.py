@@ -70,3 +70,22 @@ def test_reference_functions_on_synthetic():
         assert relerr(ef, g[key + "_Efull"]) < 1e-10
         assert abs(ib - float(g[key + "_inside"])) < 1e-12
         assert relerr(X, g[key + "_X"]) < 1e-9
+
+
+def test_baseline_filters_on_synthetic():
+    """MLE-SMF (MLESMF.py:40-92) and TMF (TMF.py:30-73) restatements vs the reference functions run in the build
+    container on the impute_synth inputs (fixture tests/golden/impute_baselines.npz, make_golden.py)."""
+    from oracle.impute_oracle import mle_smf_filter, tmf_filter
+
+    g, b = load_golden("impute_synth"), load_golden("impute_baselines")
+    Yint = np.nan_to_num(g["Yorig"], nan=0.0)
+    r = g["C0"].shape[1]
+    X = g["X0"].copy()
+    ep, ef, ib = mle_smf_filter(g["Y"], g["C0"], X, g["M"], g["Mmiss"], 0.1 * np.eye(r), 10.0, np.eye(r), 2, 2, Yint, float(g["Einit"]))
+    assert relerr(ep, b["mle_Epred"]) < 1e-12 and relerr(ef, b["mle_Efull"]) < 1e-12
+    assert abs(ib - float(b["mle_inside"])) < 1e-12
+    assert relerr(X, b["mle_X"]) < 1e-12
+    X = g["X0"].copy()
+    ep, ef = tmf_filter(g["Y"], g["C0"], X, g["M"], g["Mmiss"], 2, Yint, float(g["Einit"]))
+    assert relerr(ep, b["tmf_Epred"]) < 1e-12 and relerr(ef, b["tmf_Efull"]) < 1e-12
+    assert relerr(X, b["tmf_X"]) < 1e-12
