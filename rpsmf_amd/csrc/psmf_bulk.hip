@@ -19,6 +19,13 @@
 
 namespace psmf {
 
+// per-wave time stamps for tools/bulk_prof.hip (BK_STAMPS); no-ops in the product
+#ifdef BK_STAMPS
+#define BK_STAMP(i) do { if ((threadIdx.x & 63) == 0) reinterpret_cast<long long*>(b.Kpart)[(blockIdx.x * BK_WAVES + (threadIdx.x >> 6)) * 8 + (i)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define BK_STAMP(i) do { } while (0)
+#endif
+
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK_TR = 16;      // rows per wave tile
@@ -58,6 +65,7 @@ __global__ __launch_bounds__(BK_NT) void psmf_blk_xgram2(BlockParams b) {
   const float* __restrict__ Y = reinterpret_cast<const float*>(p.Y) + (size_t)(b.k0 - p.series_t0) * dl;
   const float* __restrict__ Y1 = reinterpret_cast<const float*>(p.Y) + (size_t)(b.k1 - p.series_t0) * dl;
   double* img = smem + (size_t)w * BK_TR * BK_S;
+  BK_STAMP(0);
   for (int i = lane; i < BK_TR * BK_S; i += 64) img[i] = 0.0;
   f64x4 acc[NRT * NCT];
 #pragma unroll
@@ -94,6 +102,7 @@ __global__ __launch_bounds__(BK_NT) void psmf_blk_xgram2(BlockParams b) {
   };
   int t = blockIdx.x * BK_WAVES + w;
   if (t < ntile) load_tile(t);
+  BK_STAMP(1);
   while (t < ntile) {
     // registers -> float64 image
 #pragma unroll
@@ -132,6 +141,7 @@ __global__ __launch_bounds__(BK_NT) void psmf_blk_xgram2(BlockParams b) {
     }
     t = tn;
   }
+  BK_STAMP(2);
   // ---- fixed-order tree over the 8 waves (two buffers at a time), then one partial per workgroup ----
   constexpr int PSZ = NRT * NCT * 256;          // doubles per partial
   __syncthreads();
@@ -219,6 +229,7 @@ __global__ __launch_bounds__(BK_NT) void psmf_blk_apply2(BlockParams b) {
   double* sZ = reinterpret_cast<double*>(wbase);                         // 16 x AP_S
   float* sC = reinterpret_cast<float*>(wbase + BK_TR * AP_S * 8);        // 16 x AP2_SC
   float* sY = sC + BK_TR * AP2_SC;                                       // AP2_NY x AP2_SY  (index = output column - r)
+  BK_STAMP(0);
   for (int idx = tid; idx < RB * RB; idx += BK_NT) {
     const int m = idx / RB, c = idx - m * RB;
     double v = 0.0;
@@ -261,6 +272,7 @@ __global__ __launch_bounds__(BK_NT) void psmf_blk_apply2(BlockParams b) {
   };
   int t = blockIdx.x * BK_WAVES + w;
   if (t < nslab) load_slab(t);
+  BK_STAMP(1);
   while (t < nslab) {
     const int row0 = t * BK_TR;
     const bool full = row0 + BK_TR <= dl;
@@ -338,6 +350,8 @@ __global__ __launch_bounds__(BK_NT) void psmf_blk_apply2(BlockParams b) {
     }
     t = tn;
   }
+  BK_STAMP(2);
+  BK_STAMP(3);
 }
 
 }  // namespace psmf
