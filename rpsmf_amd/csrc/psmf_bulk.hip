@@ -66,7 +66,6 @@ __global__ __launch_bounds__(BK_NT) void psmf_blk_xgram2(BlockParams b) {
   const float* __restrict__ Y1 = reinterpret_cast<const float*>(p.Y) + (size_t)(b.k1 - p.series_t0) * dl;
   double* img = smem + (size_t)w * BK_TR * BK_S;
   BK_STAMP(0);
-  for (int i = lane; i < BK_TR * BK_S; i += 64) img[i] = 0.0;
   f64x4 acc[NRT * NCT];
 #pragma unroll
   for (int t = 0; t < NRT * NCT; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
@@ -100,8 +99,18 @@ __global__ __launch_bounds__(BK_NT) void psmf_blk_xgram2(BlockParams b) {
       nv[i] = (q < nb1) ? bk_load4(Y1 + (size_t)q * dl + min(rs, dl - 1), full, n_ok) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
-  int t = blockIdx.x * BK_WAVES + w;
+  // tile k of this wave: whole rounds over all waves, then the remainder spread over the workgroups, one wave (= one
+  // SIMD) at a time: the two waves that share a SIMD never both get an extra tile (the loop is matrix-core bound)
+  const int gw = blockIdx.x * BK_WAVES + w, nfull = ntile / nwave, rem = ntile - nfull * nwave;
+  auto tile_of = [&](const int k) -> int {
+    if (k < nfull) return k * nwave + gw;
+    const int j = w * (int)gridDim.x + (int)blockIdx.x;
+    return (k == nfull && j < rem) ? nfull * nwave + j : ntile;
+  };
+  int kt = 0;
+  int t = tile_of(0);
   if (t < ntile) load_tile(t);
+  for (int i = lane; i < BK_TR * BK_S; i += 64) img[i] = 0.0;       // (behind the first tile's loads)
   BK_STAMP(1);
   while (t < ntile) {
     // registers -> float64 image
@@ -123,7 +132,7 @@ __global__ __launch_bounds__(BK_NT) void psmf_blk_xgram2(BlockParams b) {
         if (q < nb1) img[(4 * lrow + j) * BK_S + 64 + q] = (double)nv[i][j];
       }
     }
-    const int tn = t + nwave;
+    const int tn = tile_of(++kt);
     if (tn < ntile) load_tile(tn);                 // in flight during the MFMAs below
 #pragma unroll
     for (int kk = 0; kk < BK_TR / 4; ++kk) {
@@ -173,6 +182,7 @@ __global__ __launch_bounds__(BK_NT) void psmf_blk_xgram2(BlockParams b) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) out[(tI * 4 + q) * 64 + lane] = acc[tI][q];
   }
+  BK_STAMP(3);
 }
 
 // XG[(rowbase + (l >> 4) + 4 q) * XGB + 16 ct + (l & 15)] = sum over partials, fixed order.
@@ -230,16 +240,6 @@ __global__ __launch_bounds__(BK_NT) void psmf_blk_apply2(BlockParams b) {
   float* sC = reinterpret_cast<float*>(wbase + BK_TR * AP_S * 8);        // 16 x AP2_SC
   float* sY = sC + BK_TR * AP2_SC;                                       // AP2_NY x AP2_SY  (index = output column - r)
   BK_STAMP(0);
-  for (int idx = tid; idx < RB * RB; idx += BK_NT) {
-    const int m = idx / RB, c = idx - m * RB;
-    double v = 0.0;
-    if (c < r) v = b.Acoef[m * r + c];
-    else if (c < r + nb) v = b.Bcoef[(size_t)(c - r) * RB + m];
-    sW[m * GZ_S + c] = v;
-  }
-  for (int i = lane; i < BK_TR * AP_S; i += 64) sZ[i] = 0.0;
-  for (int i = lane; i < BK_TR * AP2_SC; i += 64) sC[i] = 0.f;
-  __syncthreads();
   float* __restrict__ C = reinterpret_cast<float*>(p.C);
   const float* __restrict__ Y = reinterpret_cast<const float*>(p.Y) + (size_t)(b.k0 - p.series_t0) * dl;
   float* __restrict__ YP = p.store_yp ? reinterpret_cast<float*>(p.YP) + (size_t)(b.k0 - p.series_t0) * dl : nullptr;
@@ -270,8 +270,26 @@ __global__ __launch_bounds__(BK_NT) void psmf_blk_apply2(BlockParams b) {
       yv[i] = (q < nb) ? bk_load4(Y + (size_t)q * dl + min(rs, dl - 1), full, dl - rs) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
-  int t = blockIdx.x * BK_WAVES + w;
+  const int gw = blockIdx.x * BK_WAVES + w, nfull = nslab / nwave, rem = nslab - nfull * nwave;
+  auto slab_of = [&](const int k) -> int {      // as tile_of in psmf_blk_xgram2
+    if (k < nfull) return k * nwave + gw;
+    const int j = w * (int)gridDim.x + (int)blockIdx.x;
+    return (k == nfull && j < rem) ? nfull * nwave + j : nslab;
+  };
+  int kt = 0;
+  int t = slab_of(0);
   if (t < nslab) load_slab(t);
+  // the coefficient matrix and the LDS images, behind the first slab's loads
+  for (int idx = tid; idx < RB * RB; idx += BK_NT) {
+    const int m = idx / RB, c = idx - m * RB;
+    double v = 0.0;
+    if (c < r) v = b.Acoef[m * r + c];
+    else if (c < r + nb) v = b.Bcoef[(size_t)(c - r) * RB + m];
+    sW[m * GZ_S + c] = v;
+  }
+  for (int i = lane; i < BK_TR * AP_S; i += 64) sZ[i] = 0.0;
+  for (int i = lane; i < BK_TR * AP2_SC; i += 64) sC[i] = 0.f;
+  __syncthreads();
   BK_STAMP(1);
   while (t < nslab) {
     const int row0 = t * BK_TR;
@@ -293,7 +311,7 @@ __global__ __launch_bounds__(BK_NT) void psmf_blk_apply2(BlockParams b) {
         for (int j = 0; j < 4; ++j) sZ[(4 * lrow + j) * AP_S + r + q] = (double)yv[i][j];
       }
     }
-    const int tn = t + nwave;
+    const int tn = slab_of(++kt);
     if (tn < nslab) load_slab(tn);                 // in flight during the MFMAs below
     f64x4 acc[4];
 #pragma unroll
