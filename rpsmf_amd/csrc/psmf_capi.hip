@@ -570,6 +570,7 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
     CREATE_TRY(hipMemset(h->Bcoef, 0, (size_t)2 * psmf::RB * psmf::RB * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&h->XGpart, (size_t)psmf::BLK_GRAM_WG * (psmf::RB + psmf::XGB) * psmf::XGB * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&h->XG, (size_t)2 * (psmf::RB + psmf::XGB) * psmf::XGB * sizeof(double)));
+    CREATE_TRY(hipMemset(h->XG, 0, (size_t)2 * (psmf::RB + psmf::XGB) * psmf::XGB * sizeof(double)));   // the all-reduce covers entries no kernel writes
     CREATE_TRY(hipMalloc((void**)&h->flags, 8 * sizeof(long long)));
     CREATE_TRY(hipMemset(h->flags, 0, 8 * sizeof(long long)));
     {
