@@ -364,6 +364,7 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
         _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                                                   \
           Wf[(ti_ * 2 + tj_) * 4 + q_] = F3_VALID(mk, ti_, tj_, q_) ? wv_[q_] : 0.0;                       \
       }                                                                                                    \
+    BLK_T(6);                                                                                              \
     if (isX) {                                                                                             \
       double g1_ = 0.0, t1_ = 0.0;                                                                         \
       _Pragma("unroll") for (int ti_ = 0; ti_ < 2; ++ti_)                                                  \
@@ -386,7 +387,7 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
   for (int jb = 0; jb < b.nb; ++jb) {
     // phase 0 (wave 4 forms w, s, kappa meanwhile): what the step that just ended left to do off the critical path
     if (jb > 0) F3_W_AND_TRACES();
-    BLK_T(0);
+    BLK_T(7);
     f3_barrier();                                                     // ---- B1
     BLK_T(1);
     // =============================== phase 1: M, first iteration ===============================

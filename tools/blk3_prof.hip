@@ -39,7 +39,7 @@ int main() {
   hipMemset(dKp, 0, 4096); psmf_blk_filter3<<<1, F3_NT, lds>>>(b); hipDeviceSynchronize();
   unsigned long long h[8 * 12], cnt[16]; hipMemcpy(h, dKp, sizeof(h), hipMemcpyDeviceToHost); hipMemcpy(cnt, reinterpret_cast<unsigned long long*>(dKp) + 200, sizeof(cnt), hipMemcpyDeviceToHost);
   printf("NS converged on %llu steps, sweep on %llu; residual evaluations by iteration:", cnt[0], cnt[1]); for (int q = 2; q < 10; ++q) printf(" %llu", cnt[q]); printf("; mean initial ||R|| = %.3f\n", 1e-6 * cnt[12] / (double)(cnt[2] ? cnt[2] : 1));
-  const char* nm[10] = {"phase 0 (idle)", "barrier waits", "phase 1 (M, it 0)", "phase 2 (it 1, G)", "further iterations", "phase F", "-", "-", "-", "-"};
+  const char* nm[10] = {"phase 0 (idle)", "barrier waits", "phase 1 (M, it 0)", "phase 2 (it 1, G)", "further iterations", "phase F", "phase 0: W fill", "phase 0: traces", "-", "-"};
   printf("block of %d steps: %.1f us = %.2f us/step; err flag field k=%d\n", nb, ms * 1e3, ms * 1e3 / nb, 0);
   for (int w : {0, 2, 4, 5, 7}) { printf("wave %d (%s):\n", w, w < 2 ? "X" : (w < 4 ? "Y" : "V: phase 0 | barrier waits | phase 1 | phase 2 | to BF")); for (int q = 0; q < 10; ++q) printf("   %-22s %7.0f cycles/step\n", nm[q], (double)h[w * 12 + q] / nb); }
   return 0;
