@@ -14,7 +14,8 @@
 // Per column: masked residual, augmented Gram [C | e]^T diag(m) [C | e] (gives G, b = C^T e, e^T e in
 // one pass), the two symmetric sweep inversions of the reference's Woodbury form
 // (PSMF.py:30-36), the Kalman update of x, the rank-1 updates of C and V, error bands.
-// Everything is latency-bound; inputs of column t+1 are prefetched while column t is processed.
+// Everything is latency-bound; inputs of column t+1 are prefetched while column t is processed, and the barriers inside the
+// column loop order LDS only (solve_barrier<true>): the prefetch and the per-column stores (X, bands) stay in flight across them.
 #include "../../include/psmf_hip.h"
 #include "psmf_kernels.hip"
 
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(WG) void psmf_impute_kernel(ImputeParams p) {
         for (int l = 0; l < r; ++l) a += sV[i * r + l] * sx[l];
         sw[i] = a;
       }
-      __syncthreads();
+      solve_barrier<true>();
       double s = 0.0;
       for (int l = 0; l < r; ++l) s += sx[l] * sw[l];
       // weights of the observed rows: PSMF / rPSMF 1 / (rho + s) (PSMF.py:71-72), MLE-SMF 1 / rho (MLESMF.py:70), TMF 1
@@ -192,14 +193,14 @@ __global__ __launch_bounds__(WG) void psmf_impute_kernel(ImputeParams p) {
       if (tid < 64) for (int i = tid; i < d; i += 64) msum_l += smk[i];
       msum_l = wave_sum(msum_l);
       if (tid == 0) sred[0] = msum_l;
-      __syncthreads();
+      solve_barrier<true>();
       if (tid < npair) {
         const double g = (sgp[tid] + sgp[160 + tid]) + (sgp[320 + tid] + sgp[480 + tid]);
         if (tb < r) { sG[ta * r + tb] = g; sG[tb * r + ta] = g; }
         else if (ta < r) sb[ta] = g;         // C^T e   (e is already masked)
         else sred[1] = g;                    // e^T e
       }
-      __syncthreads();
+      solve_barrier<true>();
       const double msum = sred[0], ee = sred[1];
       // ---- C: PP = P + Q, <G, PP>, P+ = (PP^-1 + kappa G)^-1 ----
       double A1[1], G1[1];
@@ -210,9 +211,9 @@ __global__ __launch_bounds__(WG) void psmf_impute_kernel(ImputeParams p) {
       G1[0] = kappa * gv;
       double gpp = wave_sum(ppv * gv);
       if ((tid & 63) == 0) sred[4 + (tid >> 6)] = gpp;
-      spd_update_solve<16>(A1, G1, r2, ec, ei, rowbuf, errflag);   // contains barriers
+      spd_update_solve<16, true>(A1, G1, r2, ec, ei, rowbuf, errflag);   // contains barriers
       if (ein) sPp[ei * r + ec] = A1[0];
-      __syncthreads();
+      solve_barrier<true>();
       const double trGP = (sred[4] + sred[5]) + (sred[6] + sred[7]);
       const double eta = (rho * msum + trGP) / dd;      // divide by d, not by #observed (PSMF.py:77)
       const double N = s + eta;
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(WG) void psmf_impute_kernel(ImputeParams p) {
       }
       double bPb = 0.0;
       if (p.robust) {
-        __syncthreads();
+        solve_barrier<true>();
         for (int l = 0; l < r; ++l) bPb += sb[l] * sz[l];
         bPb *= kappa * kappa;
       }
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(WG) void psmf_impute_kernel(ImputeParams p) {
           }
         }
       }
-      __syncthreads();   // all reads of sV, sx, sP, sQ, sPp of this column are done
+      solve_barrier<true>();   // all reads of sV, sx, sP, sQ, sPp of this column are done
       if (ein) {
         if (!sgd) sV[ei * r + ec] = phi * (sV[ei * r + ec] - sw[ei] * sw[ec] * wsc);
         sP[ei * r + ec] = omega * 0.5 * (sPp[ei * r + ec] + sPp[ec * r + ei]);
@@ -271,7 +272,7 @@ __global__ __launch_bounds__(WG) void psmf_impute_kernel(ImputeParams p) {
       }
       if (tid < r) sx[tid] = xnew;
       if (p.robust) { rho *= omega; lam += dd; }
-      __syncthreads();
+      solve_barrier<true>();
     }
     // ---- end of pass: RMSE of the one-step predictions, RMSE of C @ X, coverage ----
     double nm_d = (double)nmiss_l;

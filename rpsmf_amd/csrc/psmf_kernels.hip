@@ -86,7 +86,15 @@ __device__ __forceinline__ double fast_rcp(double d) {
   return x;
 }
 
-template <int RPAD>
+// LDS_ONLY: the barriers order LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier) instead of __syncthreads(), which also
+// drains vmcnt -- for callers that keep global loads / stores in flight across the solve (psmf_impute.hip)
+template <bool LDS_ONLY>
+__device__ __forceinline__ void solve_barrier() {
+  if (LDS_ONLY) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  else __syncthreads();
+}
+
+template <int RPAD, bool LDS_ONLY = false>
 __device__ __forceinline__ void sweep_all(double (&A)[(RPAD * RPAD) / WG > 0 ? (RPAD * RPAD) / WG : 1], const int r2,
                                           const int c, const int rg, double* rowbuf, int* errflag) {
   // (a 512-thread workgroup may run two independent sweeps in lockstep, one per 256-thread half, each
@@ -109,7 +117,7 @@ __device__ __forceinline__ void sweep_all(double (&A)[(RPAD * RPAD) / WG > 0 ? (
   for (int m = 0; m < M; ++m) ic[m] = min(rg + m * RG, r2 - 1);
   // rows 0 and 1 live in slot m = 0 of row groups 0 and 1 (RG >= 4)
   if (rg < 2 && con) rowbuf[rg * RM + c] = A[0];
-  __syncthreads();
+  solve_barrier<LDS_ONLY>();
   bool bad = false;
   for (int k = 0; k < r2; k += 2) {
     const double* rb0 = rowbuf + ((k >> 1) & 1) * 2 * RM;
@@ -160,22 +168,22 @@ __device__ __forceinline__ void sweep_all(double (&A)[(RPAD * RPAD) / WG > 0 ? (
         if (con && ((k + 3) % RG) == rg) rn1[c] = nx;
       }
     }
-    __syncthreads();
+    solve_barrier<LDS_ONLY>();
   }
   if (bad && (threadIdx.x & (WG - 1)) == 0) *errflag = 1;
 }
 
 // A (in): symmetric Pbar elements of this thread, identity-padded to r2;  Gk (in): kappa * G elements
 // (0 in the padding).  A (out): elements of (Pbar^-1 + kappa G)^-1.  rowbuf: 4 * RM doubles of LDS.
-template <int RPAD>
+template <int RPAD, bool LDS_ONLY = false>
 __device__ __forceinline__ void spd_update_solve(double (&A)[(RPAD * RPAD) / WG > 0 ? (RPAD * RPAD) / WG : 1],
                                                  const double (&Gk)[(RPAD * RPAD) / WG > 0 ? (RPAD * RPAD) / WG : 1],
                                                  const int r2, const int c, const int rg, double* rowbuf, int* errflag) {
   constexpr int M = (RPAD * RPAD) / WG > 0 ? (RPAD * RPAD) / WG : 1;
-  sweep_all<RPAD>(A, r2, c, rg, rowbuf, errflag);       // A = -Pbar^-1
+  sweep_all<RPAD, LDS_ONLY>(A, r2, c, rg, rowbuf, errflag);       // A = -Pbar^-1
 #pragma unroll
   for (int m = 0; m < M; ++m) A[m] = Gk[m] - A[m];
-  sweep_all<RPAD>(A, r2, c, rg, rowbuf, errflag);       // A = -(Pbar^-1 + kappa G)^-1
+  sweep_all<RPAD, LDS_ONLY>(A, r2, c, rg, rowbuf, errflag);       // A = -(Pbar^-1 + kappa G)^-1
 #pragma unroll
   for (int m = 0; m < M; ++m) A[m] = -A[m];
 }
