@@ -81,6 +81,10 @@ class Series:
             yield a, Y
 
 
+def geo_engine_block(f):
+    return f.geometry()["engine"] == "block"
+
+
 def init_state(d, r, seed):
     rng = np.random.default_rng(seed + 7)
     C0 = (0.1 * rng.standard_normal((d, r))).astype(np.float32).astype(np.float64)
@@ -183,6 +187,8 @@ def main():
     for _ in range(args.warmup):
         f.run(0, T, sync=False)
     f.sync()
+    if geo_engine_block(f):
+        f.counters(reset=True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -190,6 +196,7 @@ def main():
     f.sync()
     barrier()
     elapsed = time.perf_counter() - t0
+    insitu = f.counters() if geo_engine_block(f) else None      # device-timer durations of the filter kernels of the timed region
     if dist is not None:
         import torch
 
@@ -209,12 +216,19 @@ def main():
         t_filter = f.time_kernel(0, 20)
         t_gram = f.time_kernel(1, 50)
         t_apply = f.time_kernel(2, 50)
-        kernel, kernel_us, steps_per_launch = "psmf_blk_filter3", t_filter, B
+        # duration of the dominant kernel: its average over the launches of the TIMED REGION, from the kernel's own
+        # s_memrealtime stamps (psmf_counters); HIP events cannot bracket single kernels of the pipelined streams without
+        # adding 5-8 us each.  The stand-alone HIP-event figure (psmf_time_kernel) is reported beside it.
+        full_blocks_only = (T % B == 0)
+        t_insitu = insitu["filter_us_mean"] if insitu and insitu["filter_launches"] > 0 else t_filter
+        kernel, kernel_us, steps_per_launch = "psmf_blk_filter3", t_insitu, (B if full_blocks_only else T / (insitu["filter_launches"] / args.steps))
         zbytes = (4.0 if args.storage == "f32" else 8.0) * d_local * 64
         pmc = os.path.join(ROOT, "profiles", "r1_pmc_traffic_block_engine.json")
         if (d, r, args.storage, world) == (100_000, 32, "f32", 1) and os.path.exists(pmc):
             traffic = json.load(open(pmc))["traffic_bytes_per_launch"]   # rocprofv3 --pmc passes of this workload (filter kernel)
-        extra = {"steps_per_launch": B,
+        extra = {"steps_per_launch": steps_per_launch,
+                 "kernel_us_hip_events_standalone": t_filter,
+                 "filter_gap_us_in_timed_region": insitu["filter_gap_us_mean"] if insitu else None,
                  "kernels_us": {"psmf_blk_filter3": t_filter, "psmf_blk_xgram2+xreduce2": t_gram, "psmf_blk_apply2": t_apply},
                  "bulk_kernels_GBps": {"cross-Gram (reads Z and the next series block)": 1.5 * zbytes / (t_gram * 1e-6) / 1e9,
                                        "apply (reads Z, writes C and y_hat)": 2 * zbytes / (t_apply * 1e-6) / 1e9},
