@@ -65,8 +65,9 @@ __device__ __forceinline__ double wave_sum_f64_dpp(double v) {
 // Which T-layout elements lie inside the r x r matrix / on the diagonal (16 < r <= 32): tile (0, 0) is always inside,
 // column tile 1 is inside iff (l & 15) < r - 16, row tile 1 iff (l >> 4) + 4 q < r - 16; only the tiles (t, t) hold
 // diagonal elements, where (l & 15) == (l >> 4) + 4 q.  Nine lane predicates (kept in SGPR pairs) in all.
+template <bool FULL>      // FULL: r == 32, nothing to mask (five predicates fewer to keep in SGPR pairs)
 struct F3Mask {
-  bool full;      // r == 32 (uniform): nothing to mask
+  static constexpr bool full = FULL;
   bool c1, r1[4], dg[4];
 };
 #define F3_VALID(mk, ti, tj, q) ((mk).full || (((ti) == 0 || (mk).r1[q]) && ((tj) == 0 || (mk).c1)))
@@ -195,9 +196,9 @@ __device__ __forceinline__ void f3_assemble_K(const BlockParams& b, const F3Lds&
 // pi(4 a + v) = a + 4 v: the float32 MFMA returns row 4 (l >> 4) + v in register v where the float64 one returns
 // (l >> 4) + 4 v, and feeding it the rows in that order makes its output land in T-layout.
 // Returns this lane's share of ||R_c||_F^2.
-template <int C>
+template <int C, bool FULL>
 __device__ __forceinline__ double f3_ns_iter(const double (&Mf)[16], const double (&Xc)[8], const float (&Xa)[16], double (&Xn)[8],
-                                             const F3Mask& mk) {
+                                             const F3Mask<FULL>& mk) {
   // the two 16 x 16 output tiles of a product are independent accumulator chains: alternate them, so that no MFMA
   // waits for the one before it
   f64x4 acc[2] = {f64x4{0.0, 0.0, 0.0, 0.0}, f64x4{0.0, 0.0, 0.0, 0.0}};
@@ -275,7 +276,7 @@ __device__ __forceinline__ void f3_sweep_images(const F3Lds& L, const int r2, co
 // ------------------------------------------------------------------------------------------------------------
 // Program of the four inversion waves.  INV 0 = X (P+ = M^-1), 1 = Y (W = (M / beta + I / q)^-1); C = own tile column.
 // ------------------------------------------------------------------------------------------------------------
-template <int C>
+template <int C, bool FULL>
 __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds& L, const int inv, const int role, const int lane,
                                               const bool carried) {
   const StepParams& p = b.sp;
@@ -289,8 +290,7 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
   float Xa[16];                             // float32 A operands of the correction product (see f3_ns_iter)
   const int pcol = (lcol >> 2) + 4 * (lcol & 3);     // pi(lcol)       // Wf: W of the last step (zero outside r x r): Lbar = (I / q - W / q^2) / omega
   const double q0 = st->Q[0];
-  F3Mask mk;
-  mk.full = (r == 32);
+  F3Mask<FULL> mk;
   mk.c1 = lcol < r - 16;
 #pragma unroll
   for (int qq = 0; qq < 4; ++qq) { mk.r1[qq] = lrow + 4 * qq < r - 16; mk.dg[qq] = lcol == lrow + 4 * qq; }
@@ -418,7 +418,7 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
     }
 #define F3_ITERATE(parity_out)                                                                             \
   do {                                                                                                     \
-    const double nr_ = f3_ns_iter<C>(Mf, Xc, Xa, Xn, mk);                                               \
+    const double nr_ = f3_ns_iter<C, FULL>(Mf, Xc, Xa, Xn, mk);                                               \
     const float nw_ = wave_sum_f32_dpp((float)nr_);                                                        \
     f64x2* dp_ = reinterpret_cast<f64x2*>(L.dump) + (size_t)(((parity_out) * 4 + role) * 4) * 64 + lane;   \
     _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) dp_[e_ * 64] = f64x2{Xn[2 * e_], Xn[2 * e_ + 1]};    \
@@ -888,8 +888,13 @@ __global__ __launch_bounds__(F3_NT) void psmf_blk_filter3(BlockParams b) {
   }
   if (role < 4) {
     const int inv = role >> 1;
-    if (role & 1) f3_ns_program<1>(b, L, inv, role, lane, carried);
-    else f3_ns_program<0>(b, L, inv, role, lane, carried);
+    if (r == 32) {
+      if (role & 1) f3_ns_program<1, true>(b, L, inv, role, lane, carried);
+      else f3_ns_program<0, true>(b, L, inv, role, lane, carried);
+    } else {
+      if (role & 1) f3_ns_program<1, false>(b, L, inv, role, lane, carried);
+      else f3_ns_program<0, false>(b, L, inv, role, lane, carried);
+    }
   } else {
     f3_v_program(b, L, role, lane, carried);
   }
