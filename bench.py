@@ -254,7 +254,8 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "f32 storage (C, y, y_hat) / f64 r x r state" if args.storage == "f32" else "f64",
+            "dtype": "f64",      # the arithmetic type: float64 accumulation of every d -> r contraction and float64 r x r state
+            "storage_dtype": args.storage,   # C, y, y_hat in HBM (f32: one rounding of C per block)
             "data": "synthetic",
             "config": {"workload": f"{'rPSMF' if args.robust else 'PSMF'} full filter, random-walk dynamics, d={d} r={r} "
                                    f"T={T} synthetic Gaussian series, rows sharded over {world} GPU(s)",
