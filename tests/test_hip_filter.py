@@ -378,3 +378,35 @@ def test_collective_path_single_rank_streaming_kernels():
             os.environ.pop("PSMF_FORCE_COLLECTIVE", None)
     for k in ("C", "V", "mu", "P"):
         assert relerr(out[1][k], out[0][k]) < 1e-12, k
+
+
+@pytest.mark.parametrize("robust", [False, True])
+def test_split_runs_carry_the_state(robust):
+    """A series filtered in two psmf_run calls (split in the middle of a block, state read back in between) equals one call:
+    the r x r state travels between blocks / runs as the kernels' register dump, the row-major copies are written by the
+    last block of each run (f64 storage: agreement to round-off; different block boundaries, same recursion)."""
+    c = _capi()
+    d, r, T, T1 = 2048, 32, 330, 141
+    Y, C0 = _problem(d, r, T, 77, "t" if robust else "normal")
+    V0, P0, Q = 0.1 * np.eye(r), np.eye(r), 0.1 * np.eye(r)
+    mode = O.Mode(robust=robust)
+    out = []
+    for split in (False, True):
+        f = c.DeviceFilter(d, r, storage="f64", engine="block", **_mode_kwargs(mode))
+        f.upload_series(Y)
+        f.set_state(C0, V0, P0, Q, np.zeros(r), rho=1.0, lambda0=1.8)
+        if split:
+            f.run(0, T1)
+            mid = f.get_state()
+            assert np.all(np.isfinite(mid["P"])) and np.allclose(mid["P"], mid["P"].T, rtol=0, atol=1e-9 * np.max(np.abs(mid["P"])))
+            f.run(T1, T)
+        else:
+            f.run(0, T)
+        out.append((f.get_state(), f.y_pred(0, T)))
+        f.close()
+    for k in ("C", "V", "mu", "P"):
+        assert relerr(out[1][0][k], out[0][0][k]) < 1e-9, k
+    assert relerr(out[1][1], out[0][1]) < 1e-9
+    st = O.State(C=C0, V=V0, mu=np.zeros(r), P=P0, Q=Q, rho=1.0, lam=1.8)
+    st, Yp, _ = O.run_epoch(st, Y, mode, O.RandomWalkDyn())
+    _compare(out[1][0], st, TOL["f64"])
