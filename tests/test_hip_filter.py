@@ -410,3 +410,25 @@ def test_split_runs_carry_the_state(robust):
     st = O.State(C=C0, V=V0, mu=np.zeros(r), P=P0, Q=Q, rho=1.0, lam=1.8)
     st, Yp, _ = O.run_epoch(st, Y, mode, O.RandomWalkDyn())
     _compare(out[1][0], st, TOL["f64"])
+
+
+@pytest.mark.parametrize("fixed_lambda", [False, True])
+@pytest.mark.parametrize("d,r,T", [(1536, 32, 150), (1200, 20, 120), (900, 12, 110)])
+def test_rpsmf_scaling_factors_and_fixed_lambda(d, r, T, fixed_lambda, engine):
+    """rPSMF with use_scaling-style factors alpha, beta != 1 (rpsmf.py:45-51,133-171) and fixed_lambda (rpsmf.py:36-40,170-171):
+    every filter kernel of both engines against the oracle (f64 storage)."""
+    c = _capi()
+    Y, C0 = _problem(d, r, T, 500 + d + r, "t")
+    V0, P0, Q = 0.1 * np.eye(r), np.eye(r), 0.1 * np.eye(r)
+    mode = O.Mode(robust=True, alpha=0.93, beta=1.07, fixed_lambda=fixed_lambda)
+    st = O.State(C=C0, V=V0, mu=np.zeros(r), P=P0, Q=Q, rho=1.0, lam=1.8)
+    st, Yp, _ = O.run_epoch(st, Y, mode, O.RandomWalkDyn())
+    f = c.DeviceFilter(d, r, storage="f64", engine=engine, **_mode_kwargs(mode))
+    f.upload_series(Y)
+    f.set_state(C0, V0, P0, Q, np.zeros(r), rho=1.0, lambda0=1.8)
+    f.run(0, T)
+    s = f.get_state()
+    _compare(s, st, TOL["f64"])
+    assert relerr(f.y_pred(0, T), Yp) < TOL["f64"]
+    assert relerr(s["rho"], st.rho) < TOL["f64"] and relerr(s["lam"], st.lam) < 1e-12
+    f.close()
