@@ -37,7 +37,7 @@ typedef float f32x4s __attribute__((ext_vector_type(4)));
 
 constexpr int F3_NT = 512;
 constexpr int F3_S = 34;            // row stride of the row-major 32 x 32 LDS images
-constexpr int F3_MAXIT = 8;
+constexpr int F3_MAXIT = 12;
 
 #define F3_DPP64(x, ctrl)                                                                                  \
   __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(x), ctrl, 0xF, 0xF, true),                \
@@ -251,7 +251,7 @@ struct F3Ctl {
     const double worst_ = fmax(nx_, ny_);                                                                  \
     ++ctl.c_it;                                                                                            \
     if (worst_ < p.ns_tol2) done = true;          /* ||R|| below the tolerance BEFORE the update just made */ \
-    else if (!(worst_ < 0.09) || it == F3_MAXIT - 1) failed = true;  /* too far (||R|| > 0.3) or not converging */ \
+    else if (!(worst_ < p.ns_far2) || it == F3_MAXIT - 1) failed = true;  /* start too far or not converging */   \
   } while (0)
 
 // The direct symmetric sweep of both matrices on all 8 waves (half X: image X, half Y: image Y), in place in

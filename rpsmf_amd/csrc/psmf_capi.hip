@@ -645,6 +645,8 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
   // effect on the error against the float64 oracle: none).  PSMF_NS_TOL overrides.
   const double ns_tol = getenv("PSMF_NS_TOL") ? atof(getenv("PSMF_NS_TOL")) : (cfg->storage == PSMF_F64 ? 3e-7 : 1e-4);
   sp.ns_tol2 = ns_tol * ns_tol;
+  const double ns_far = getenv("PSMF_NS_FAR") ? atof(getenv("PSMF_NS_FAR")) : 0.3;
+  sp.ns_far2 = ns_far * ns_far;
   sp.alpha = cfg->alpha; sp.beta = cfg->beta;
   sp.lr = cfg->adam_lr; sp.lr_end = cfg->adam_lr_end; sp.lr_steps = cfg->adam_lr_steps;
   sp.b1 = cfg->adam_b1; sp.b2 = cfg->adam_b2;

@@ -62,6 +62,7 @@ struct StepParams {
   int use_ns;           // 1: Newton-Schulz refinement of the r x r inverses (f64 MFMA), sweep as fallback
   double alpha, beta, lr, lr_end, lr_steps, b1, b2;
   double ns_tol2;       // Newton-Schulz: squared Frobenius residual accepted BEFORE the last update (the update squares it)
+  double ns_far2;       // Newton-Schulz: squared residual beyond which the start is given up for the direct sweep (filter3)
 };
 
 }  // namespace psmf
