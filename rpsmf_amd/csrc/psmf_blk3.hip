@@ -148,7 +148,8 @@ __device__ __forceinline__ void f3_assemble_K(const BlockParams& b, const F3Lds&
     const int idx = min(tid + u * F3_NT, nb * nb - 1), q = idx / nb, q2 = idx - q * nb;
     yy[u] = b.XG[(size_t)(RB + q) * XGB + q2];
   }
-  for (int idx = tid; idx < RB * RB; idx += F3_NT) sK[idx] = 0.0;
+  if (r + nb < RB)            // a full block writes every entry of K below
+    for (int idx = tid; idx < RB * RB; idx += F3_NT) sK[idx] = 0.0;
   for (int idx = tid; idx < RB * 32; idx += F3_NT) {
     const int m = idx >> 5, c = idx & 31;
     const double v = b.Aprev[m * r + min(c, r - 1)];

@@ -72,8 +72,13 @@ struct BlockParams {
 // (it practically always is: the cross-Gram runs one block ahead).  Every wait is bounded.
 constexpr long long HANDOFF_MAX_POLLS = 1LL << 21;     // x ~1 us: seconds, then the abort flag
 
-__device__ __forceinline__ long long flag_load(const long long* f) { return __hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void flag_store(long long* f, long long v) { __hip_atomic_store(f, v, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+// Relaxed agent-scope accesses: every flag is written by a kernel that starts AFTER the kernel whose data it announces has
+// ended, and (in the normal case) read before the reader touches that data for the first time in a kernel that started
+// after it was set -- the kernel boundaries are the release and the acquire.  (Acquire loads / release stores here cost an
+// L1 invalidate / L2 write-back each: ~1 us per block.)  The one exception, a flag observed only after polling, is
+// followed by an explicit acquire fence in blk_handoff_begin.
+__device__ __forceinline__ long long flag_load(const long long* f) { return __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void flag_store(long long* f, long long v) { __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // returns false (uniformly) if the run was aborted; ends with a workgroup barrier
 __device__ __forceinline__ bool blk_handoff_begin(const BlockParams& b) {
