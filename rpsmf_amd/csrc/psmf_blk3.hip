@@ -449,11 +449,11 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
     // =============================== phase 2: second iteration, G update ===============================
     bool done = false, failed = !try_ns;
     int it = 0;
-    if (try_ns) F3_DECIDE();
     bool fetch_late = false;         // converged: the partner's final column is only needed by the NEXT step -> after phase F
-    if (try_ns && !failed) {
-      if (!done) { F3_FETCH_PARTNER(0); F3_ITERATE(1); }
-      else fetch_late = true;
+    if (try_ns) {
+      F3_FETCH_PARTNER(0);           // issued with the norms' reads: one LDS round trip for both (harmless if the start failed:
+      F3_DECIDE();                   //  the sweep path reloads the operands)
+      if (!done && !failed) F3_ITERATE(1);
     }
     {
       // G_k = G_{k-1} + (h w^T + w h^T) / N + ee w w^T / N^2   (tracked Gram)
