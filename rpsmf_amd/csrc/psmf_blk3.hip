@@ -253,6 +253,8 @@ struct F3Ctl {
     ++ctl.c_it;                                                                                            \
     if (worst_ < p.ns_tol2) done = true;          /* ||R|| below the tolerance BEFORE the update just made */ \
     else if (!(worst_ < p.ns_far2) || it == F3_MAXIT - 1) failed = true;  /* start too far or not converging */   \
+    /* ||R_next||_F <= (||R||_F + ||M (Xc - Xa)||) ||R||_F: one more iteration is the last, no check needed */   \
+    else last = worst_ * worst_ < 0.25 * p.ns_tol2;                                                        \
   } while (0)
 
 // The direct symmetric sweep of both matrices on all 8 waves (half X: image X, half Y: image Y), in place in
@@ -380,13 +382,39 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
     }                                                                                                      \
   } while (0)
 
+#define F3_ITERATE(parity_out)                                                                             \
+  do {                                                                                                     \
+    const double nr_ = f3_ns_iter<C, FULL>(Mf, Xc, Xa, Xn, mk);                                               \
+    const float nw_ = wave_sum_f32_dpp((float)nr_);                                                        \
+    f64x2* dp_ = reinterpret_cast<f64x2*>(L.dump) + (size_t)(((parity_out) * 4 + role) * 4) * 64 + lane;   \
+    _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) dp_[e_ * 64] = f64x2{Xn[2 * e_], Xn[2 * e_ + 1]};    \
+    f32x4s* pp_ = reinterpret_cast<f32x4s*>(L.dumpP) + (size_t)(((parity_out) * 4 + role) * 2) * 64 + 16 * lrow + pcol; \
+    _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_)                                                       \
+      pp_[t_ * 64] = f32x4s{(float)Xn[t_ * 4], (float)Xn[t_ * 4 + 1], (float)Xn[t_ * 4 + 2], (float)Xn[t_ * 4 + 3]}; \
+    if (lane == 0) L.nrm[(parity_out) * 4 + role] = (double)nw_;                                           \
+    _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) Xc[e_] = Xn[e_];                                      \
+  } while (0)
+#define F3_FETCH_PARTNER(parity_in)                                                                        \
+  do {   /* both columns of the new iterate as float32 A operands: own tiles -> output tile C, partner's -> 1 - C */ \
+    _Pragma("unroll") for (int w_ = 0; w_ < 2; ++w_) {                                                     \
+      const int src_ = w_ == 0 ? role : (role ^ 1);                                                        \
+      const int to_ = w_ == 0 ? C : 1 - C;                                                                 \
+      const f32x4s* pq_ = reinterpret_cast<const f32x4s*>(L.dumpP) + (size_t)(((parity_in) * 4 + src_) * 2) * 64 + lane; \
+      _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_) {                                                   \
+        const f32x4s v_ = pq_[t_ * 64];                                                                    \
+        Xa[to_ * 8 + t_ * 4 + 0] = v_[0]; Xa[to_ * 8 + t_ * 4 + 1] = v_[1];                                 \
+        Xa[to_ * 8 + t_ * 4 + 2] = v_[2]; Xa[to_ * 8 + t_ * 4 + 3] = v_[3];                                 \
+      }                                                                                                    \
+    }                                                                                                      \
+  } while (0)
   F3Ctl ctl = {carried, 0, 0, 0, 0, 0};
   int w_par = 0;
-  bool w_from_img = false;
+  bool w_from_img = false, fetch_late = false;
   double iq_w = carried ? st->f3_sc[0] : 1.0 / q0;          // 1 / q that Wf was formed with
   BLK_T0();
   for (int jb = 0; jb < b.nb; ++jb) {
     // phase 0 (wave 4 forms w, s, kappa meanwhile): what the step that just ended left to do off the critical path
+    if (fetch_late) F3_FETCH_PARTNER(w_par);     // (after BF: the partner published it in the last phase it ran)
     if (jb > 0) F3_W_AND_TRACES();
     BLK_T(7);
     f3_barrier();                                                     // ---- B1
@@ -417,43 +445,23 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
             else Mf[e] = m;
           }
     }
-#define F3_ITERATE(parity_out)                                                                             \
-  do {                                                                                                     \
-    const double nr_ = f3_ns_iter<C, FULL>(Mf, Xc, Xa, Xn, mk);                                               \
-    const float nw_ = wave_sum_f32_dpp((float)nr_);                                                        \
-    f64x2* dp_ = reinterpret_cast<f64x2*>(L.dump) + (size_t)(((parity_out) * 4 + role) * 4) * 64 + lane;   \
-    _Pragma("unroll") for (int e_ = 0; e_ < 4; ++e_) dp_[e_ * 64] = f64x2{Xn[2 * e_], Xn[2 * e_ + 1]};    \
-    f32x4s* pp_ = reinterpret_cast<f32x4s*>(L.dumpP) + (size_t)(((parity_out) * 4 + role) * 2) * 64 + 16 * lrow + pcol; \
-    _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_)                                                       \
-      pp_[t_ * 64] = f32x4s{(float)Xn[t_ * 4], (float)Xn[t_ * 4 + 1], (float)Xn[t_ * 4 + 2], (float)Xn[t_ * 4 + 3]}; \
-    if (lane == 0) L.nrm[(parity_out) * 4 + role] = (double)nw_;                                           \
-    _Pragma("unroll") for (int e_ = 0; e_ < 8; ++e_) Xc[e_] = Xn[e_];                                      \
-  } while (0)
-#define F3_FETCH_PARTNER(parity_in)                                                                        \
-  do {   /* both columns of the new iterate as float32 A operands: own tiles -> output tile C, partner's -> 1 - C */ \
-    _Pragma("unroll") for (int w_ = 0; w_ < 2; ++w_) {                                                     \
-      const int src_ = w_ == 0 ? role : (role ^ 1);                                                        \
-      const int to_ = w_ == 0 ? C : 1 - C;                                                                 \
-      const f32x4s* pq_ = reinterpret_cast<const f32x4s*>(L.dumpP) + (size_t)(((parity_in) * 4 + src_) * 2) * 64 + lane; \
-      _Pragma("unroll") for (int t_ = 0; t_ < 2; ++t_) {                                                   \
-        const f32x4s v_ = pq_[t_ * 64];                                                                    \
-        Xa[to_ * 8 + t_ * 4 + 0] = v_[0]; Xa[to_ * 8 + t_ * 4 + 1] = v_[1];                                 \
-        Xa[to_ * 8 + t_ * 4 + 2] = v_[2]; Xa[to_ * 8 + t_ * 4 + 3] = v_[3];                                 \
-      }                                                                                                    \
-    }                                                                                                      \
-  } while (0)
     if (try_ns) F3_ITERATE(0);
     BLK_T(2);
     f3_barrier();                                                     // ---- B2
     BLK_T(1);
     // =============================== phase 2: second iteration, G update ===============================
-    bool done = false, failed = !try_ns;
+    bool done = false, failed = !try_ns, last = false;
     int it = 0;
-    bool fetch_late = false;         // converged: the partner's final column is only needed by the NEXT step -> after phase F
+    fetch_late = false;              // converged: the partner's final column is only needed by the NEXT step -> its phase 0
     if (try_ns) {
       F3_FETCH_PARTNER(0);           // issued with the norms' reads: one LDS round trip for both (harmless if the start failed:
       F3_DECIDE();                   //  the sweep path reloads the operands)
-      if (!done && !failed) F3_ITERATE(1);
+      if (!done && !failed) {
+        F3_ITERATE(1);
+        par = 1;
+        it = 1;
+        if (last) { done = true; fetch_late = true; ++ctl.c_it; }
+      }
     }
     {
       // G_k = G_{k-1} + (h w^T + w h^T) / N + ee w w^T / N^2   (tracked Gram)
@@ -475,19 +483,21 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
       mub_j = L.mub[16 * C + lcol];
     }
     BLK_T(3);
-    f3_barrier();                                                     // ---- B3
-    BLK_T(1);
-    // =============================== further iterations ===============================
-    if (try_ns && !done && !failed) { par = 1; it = 1; }
-    while (try_ns && !done && !failed) {
-      F3_DECIDE();
-      if (done) fetch_late = true;
-      if (done || failed) break;
-      F3_FETCH_PARTNER(par);
-      F3_ITERATE(par ^ 1);
-      par ^= 1;
-      ++it;
-      f3_barrier();
+    // =============================== further iterations (only when the outcome is not known yet) ===============================
+    if (!done) {
+      f3_barrier();                                                   // ---- B3
+      BLK_T(1);
+      while (try_ns && !done && !failed) {
+        F3_DECIDE();
+        if (done) fetch_late = true;
+        if (done || failed) break;
+        F3_FETCH_PARTNER(par);
+        F3_ITERATE(par ^ 1);
+        par ^= 1;
+        ++it;
+        if (last) { done = true; fetch_late = true; ++ctl.c_it; break; }
+        f3_barrier();
+      }
     }
     BLK_T(4);
     // `par` = parity of the dump that holds the columns published by the last iteration that ran
@@ -535,13 +545,13 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
         if (lane == 0) L.hv[C] = hvp;
       }
     }
-    if (fetch_late) F3_FETCH_PARTNER(par);
     BLK_T(5);
     f3_barrier();                                                     // ---- BF
     BLK_T(1);
   }
   BLK_TOUT();
   // ---- block end ----
+  if (fetch_late) F3_FETCH_PARTNER(w_par);
   if (b.nb > 0) F3_W_AND_TRACES();
   f3_barrier();                       // wave 4 has published pscale and 1 / omega of the last step
   const double ps = L.sc[F3_PSCALE], iom = L.sc[F3_IOM];
@@ -729,9 +739,16 @@ __device__ __forceinline__ void f3_v_program(const BlockParams& b, const F3Lds& 
     f3_barrier();                                                     // ---- B2
     BLK_T(1);
     // =============================== phase 2 ===============================
-    bool done = false, failed = !try_ns;
+    bool done = false, failed = !try_ns, last = false;
     int it = 0;
-    if (try_ns) F3_DECIDE();
+    if (try_ns) {
+      F3_DECIDE();
+      if (!done && !failed) {
+        par = 1;
+        it = 1;
+        if (last) done = true;
+      }
+    }
     if (isV3) {
       const int c = lane & 31, hf = lane >> 5;
       const double wn = L.w[c] * L.sc[F3_INVN];
@@ -756,14 +773,16 @@ __device__ __forceinline__ void f3_v_program(const BlockParams& b, const F3Lds& 
       for (int t = 0; t < 16; ++t) pr[t] = vscale * (pr[t] - L.w[16 * hf + t] * wjn);   // psmf.py:135-138
     }
     BLK_T(3);
-    f3_barrier();                                                     // ---- B3
-    if (try_ns && !done && !failed) { par = 1; it = 1; }
-    while (try_ns && !done && !failed) {
-      F3_DECIDE();
-      if (done || failed) break;
-      par ^= 1;
-      ++it;
-      f3_barrier();
+    if (!done) {
+      f3_barrier();                                                   // ---- B3
+      while (try_ns && !done && !failed) {
+        F3_DECIDE();
+        if (done || failed) break;
+        par ^= 1;
+        ++it;
+        if (last) { done = true; break; }
+        f3_barrier();
+      }
     }
     if (!done) {
       if (try_ns) { ++ctl.c_fail; ctl.ns_skip = 3; }

@@ -70,7 +70,8 @@ struct BlockParams {
 // but filter kernels; each one, when it starts, (a) announces that its predecessor has finished -- the kernel boundary
 // made that kernel's stores visible -- which releases the bulk stream's apply, and (b) checks that its own K is there
 // (it practically always is: the cross-Gram runs one block ahead).  Every wait is bounded.
-constexpr long long HANDOFF_MAX_POLLS = 1LL << 21;     // x ~1 us: seconds, then the abort flag
+constexpr long long HANDOFF_MAX_TICKS = 20LL * 100000000LL;   // 20 s of the 100 MHz real-time counter, then the abort flag
+                                                               // (a first RCCL collective may take seconds to connect)
 
 // Relaxed agent-scope accesses: every flag is written by a kernel that starts AFTER the kernel whose data it announces has
 // ended, and (in the normal case) read before the reader touches that data for the first time in a kernel that started
@@ -92,9 +93,11 @@ __device__ __forceinline__ bool blk_handoff_begin(const BlockParams& b) {
     if (ab0 != 0) ok = 0;
     if (ok && xg0 < b.seq) {
       long long polls = 0;
+      const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
       while (flag_load(b.flags + 0) < b.seq) {
         __builtin_amdgcn_s_sleep(16);
-        if (++polls > HANDOFF_MAX_POLLS || flag_load(b.flags + 2) != 0) { ok = 0; break; }
+        ++polls;
+        if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > HANDOFF_MAX_TICKS || flag_load(b.flags + 2) != 0) { ok = 0; break; }
       }
       if (polls > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // K was written after this kernel started
       if (!ok) { flag_store(b.flags + 2, 1); if (b.sp.st->err == 0) b.sp.st->err = -7; }
@@ -110,10 +113,14 @@ __global__ void psmf_flag_set_k(long long* f, long long v) { flag_store(f, v); }
 // bulk stream: hold the stream until flags[1] >= v (the filter kernel of block v - 1 has finished)
 __global__ void psmf_flag_wait_k(long long* flags, long long v, DevState* st) {
   if (threadIdx.x != 0) return;
-  long long polls = 0;
+  const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
   while (flag_load(flags + 1) < v) {
     __builtin_amdgcn_s_sleep(32);
-    if (++polls > HANDOFF_MAX_POLLS || flag_load(flags + 2) != 0) { flag_store(flags + 2, 1); if (st->err == 0) st->err = -7; break; }
+    if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > HANDOFF_MAX_TICKS || flag_load(flags + 2) != 0) {
+      flag_store(flags + 2, 1);
+      if (st->err == 0) st->err = -7;
+      break;
+    }
   }
 }
 

@@ -1153,6 +1153,27 @@ int psmf_comm_init(psmf_handle h, int nranks, int rank, const void* unique_id) {
   NCCL_TRY(h, ncclCommInitRank(&h->comm, nranks, id, rank));
   h->nranks = nranks;
   h->rank = rank;
+  {
+    // Connect now: the first collective of each message size sets up its channels (seconds on 8 GPUs), and in the pipelined
+    // block engine a filter kernel would be polling for its result meanwhile.  Same sizes, same streams as the engines use.
+    const size_t xg_elems = (size_t)(psmf::RB + psmf::XGB) * psmf::XGB;
+    double* tmp = nullptr;
+    HIP_TRY(h, hipMalloc(&tmp, xg_elems * sizeof(double)));
+    HIP_TRY(h, hipMemsetAsync(tmp, 0, xg_elems * sizeof(double), h->stream));
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    const size_t sizes[4] = {(size_t)h->cfg.r + 1, (size_t)h->cfg.r * h->cfg.r, (size_t)psmf::RB * psmf::RB, xg_elems};
+    hipStream_t streams[2] = {h->stream, h->bulk};
+    for (int si = 0; si < 2; ++si) {
+      if (!streams[si]) continue;
+      for (int zi = 0; zi < 4; ++zi) {
+        const ncclResult_t e = ncclAllReduce(tmp, tmp, sizes[zi], ncclDouble, ncclSum, h->comm, streams[si]);
+        if (e != ncclSuccess) { hipFree(tmp); return fail(h, PSMF_ERR_RCCL, std::string("warm-up all-reduce: ") + ncclGetErrorString(e)); }
+      }
+      const hipError_t he = hipStreamSynchronize(streams[si]);
+      if (he != hipSuccess) { hipFree(tmp); return fail(h, PSMF_ERR_HIP, std::string("warm-up all-reduce: ") + hipGetErrorString(he)); }
+    }
+    hipFree(tmp);
+  }
   h->use_coll = nranks > 1 || getenv("PSMF_FORCE_COLLECTIVE") != nullptr;
   h->sp.external_reduce = h->use_coll ? 1 : 0;
   destroy_graph(h);
