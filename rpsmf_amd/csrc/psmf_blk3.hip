@@ -197,6 +197,11 @@ __device__ __forceinline__ void f3_assemble_K(const BlockParams& b, const F3Lds&
 // pi(4 a + v) = a + 4 v: the float32 MFMA returns row 4 (l >> 4) + v in register v where the float64 one returns
 // (l >> 4) + 4 v, and feeding it the rows in that order makes its output land in T-layout.
 // Returns this lane's share of ||R_c||_F^2.
+// Knock-out switches for tools/blk3_knock.hip (timing what each piece costs on the critical path; results are wrong
+// with any of them set).  0 in the product: every `if` below folds away.
+#ifndef F3_KNOCK
+#define F3_KNOCK 0
+#endif
 template <int C, bool FULL>
 __device__ __forceinline__ double f3_ns_iter(const double (&Mf)[16], const double (&Xc)[8], const float (&Xa)[16], double (&Xn)[8],
                                              const F3Mask<FULL>& mk) {
@@ -229,7 +234,8 @@ __device__ __forceinline__ double f3_ns_iter(const double (&Mf)[16], const doubl
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-      for (int to = 0; to < 2; ++to) d2[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(Xa[to * 8 + kt * 4 + kk], Rf[kt * 4 + kk], d2[to], 0, 0, 0);
+      for (int to = 0; to < 2; ++to)
+        if (!(F3_KNOCK & 512)) d2[to] = __builtin_amdgcn_mfma_f32_16x16x4f32(Xa[to * 8 + kt * 4 + kk], Rf[kt * 4 + kk], d2[to], 0, 0, 0);
 #pragma unroll
   for (int to = 0; to < 2; ++to)
 #pragma unroll
@@ -255,6 +261,7 @@ struct F3Ctl {
     else if (!(worst_ < p.ns_far2) || it == F3_MAXIT - 1) failed = true;  /* start too far or not converging */   \
     /* ||R_next||_F <= (||R||_F + ||M (Xc - Xa)||) ||R||_F: one more iteration is the last, no check needed */   \
     else last = worst_ * worst_ < 0.25 * p.ns_tol2;                                                        \
+    if (F3_KNOCK & 1) { done = false; failed = false; last = true; }      /* always exactly two iterations */ \
   } while (0)
 
 // The direct symmetric sweep of both matrices on all 8 waves (half X: image X, half Y: image Y), in place in
@@ -352,6 +359,7 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
   // the last step.  Lbar_{k+1} = (I / q - W / q^2) / omega_k is never formed: M is built from W directly (phase 1).
 #define F3_W_AND_TRACES()                                                                                  \
   do {                                                                                                     \
+    if (!(F3_KNOCK & 4))                                                                                   \
     _Pragma("unroll") for (int ti_ = 0; ti_ < 2; ++ti_)                                                    \
       _Pragma("unroll") for (int tj_ = 0; tj_ < 2; ++tj_) {                                                \
         double wv_[4];                                                                                     \
@@ -368,7 +376,7 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
           Wf[(ti_ * 2 + tj_) * 4 + q_] = F3_VALID(mk, ti_, tj_, q_) ? wv_[q_] : 0.0;                       \
       }                                                                                                    \
     BLK_T(6);                                                                                              \
-    if (isX) {                                                                                             \
+    if (isX && !(F3_KNOCK & 2)) {                                                                          \
       double g1_ = 0.0, t1_ = 0.0;                                                                         \
       _Pragma("unroll") for (int ti_ = 0; ti_ < 2; ++ti_)                                                  \
         _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                 \
@@ -457,7 +465,7 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
       F3_FETCH_PARTNER(0);           // issued with the norms' reads: one LDS round trip for both (harmless if the start failed:
       F3_DECIDE();                   //  the sweep path reloads the operands)
       if (!done && !failed) {
-        F3_ITERATE(1);
+        if (!(F3_KNOCK & 256)) F3_ITERATE(1);
         par = 1;
         it = 1;
         if (last) { done = true; fetch_late = true; ++ctl.c_it; }
@@ -465,18 +473,21 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
     }
     {
       // G_k = G_{k-1} + (h w^T + w h^T) / N + ee w w^T / N^2   (tracked Gram)
+      //     = G_{k-1} + u w^T + w hn^T,  u = h / N + (ee / N^2) w,  hn = h / N:  two FMAs per element
       const double iN = L.sc[F3_INVN], ee = L.sc[F3_EE];
       const double e2 = ee * iN * iN;
-      double hcol[2], wcol[2];
+      double hcol[2], wcol[2], hn[2];
 #pragma unroll
-      for (int tj = 0; tj < 2; ++tj) { hcol[tj] = L.h[16 * tj + lcol]; wcol[tj] = L.w[16 * tj + lcol]; }
+      for (int tj = 0; tj < 2; ++tj) { hcol[tj] = L.h[16 * tj + lcol]; wcol[tj] = L.w[16 * tj + lcol]; hn[tj] = hcol[tj] * iN; }
 #pragma unroll
       for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
         for (int qq = 0; qq < 4; ++qq) {
           const double hi = L.h[16 * ti + lrow + 4 * qq], wi = L.w[16 * ti + lrow + 4 * qq];
+          const double ui = hi * iN + e2 * wi;
 #pragma unroll
-          for (int tj = 0; tj < 2; ++tj) G[(ti * 2 + tj) * 4 + qq] += (hi * wcol[tj] + wi * hcol[tj]) * iN + e2 * (wi * wcol[tj]);
+          for (int tj = 0; tj < 2; ++tj)
+            if (!(F3_KNOCK & 16)) G[(ti * 2 + tj) * 4 + qq] += ui * wcol[tj] + wi * hn[tj];
           hrow[ti * 4 + qq] = hi;
         }
       h_j = hcol[C];
@@ -528,7 +539,7 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
     // =============================== phase F: v = P+ h, mu (the only work between the inversion and the next step) ===============================
     w_par = par;
     w_from_img = from_img;
-    if (isX) {
+    if (isX && !(F3_KNOCK & 8)) {
       // v = P+ h (own column, by symmetry), mu_k = mu_bar + kappa v (psmf.py:155-159); h.v for omega (rPSMF only)
       double vp0 = 0.0, vp1 = 0.0;
 #pragma unroll
@@ -667,7 +678,7 @@ __device__ __forceinline__ void f3_v_program(const BlockParams& b, const F3Lds& 
   for (int jb = 0; jb < b.nb; ++jb) {
     // =============================== phase 0 ===============================
     double cm = 0.0;                       // V1: a_m, V2: (K a)_m  (kept for the rank-1 update of phase 2)
-    if (isV0) {
+    if (isV0 && !(F3_KNOCK & 1024)) {
       const int j = lane & 31, hf = lane >> 5;
       double iom = iom0;
       if (jb > 0) { F3_V0_FINISH_PREV(); iom = fast_rcp(omega); }
@@ -682,7 +693,7 @@ __device__ __forceinline__ void f3_v_program(const BlockParams& b, const F3Lds& 
       kappa = fast_rcp(rho + s_k);
       if (lane == 0) { L.sc[F3_KAPPA] = kappa; L.sc[F3_IOM] = iom; L.sc[F3_Q] = q; L.sc[F3_IQ] = fast_rcp(q); }
       wj = part;                                                        // this half's share of w_j; completed in phase 1
-    } else if (isV1 || isV2) {
+    } else if ((isV1 || isV2) && !(F3_KNOCK & 32)) {
       double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
       for (int c = 0; c < 32; c += 4) {
@@ -708,7 +719,7 @@ __device__ __forceinline__ void f3_v_program(const BlockParams& b, const F3Lds& 
     const bool try_ns = ctl.have_prev && p.use_ns && ctl.ns_skip == 0;
     if (!try_ns && ctl.ns_skip > 0) --ctl.ns_skip;
     int par = 0;
-    if (isV3) {
+    if (isV3 && !(F3_KNOCK & 64)) {
       const int c = lane & 31, hf = lane >> 5;
       double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll
@@ -749,7 +760,8 @@ __device__ __forceinline__ void f3_v_program(const BlockParams& b, const F3Lds& 
         if (last) done = true;
       }
     }
-    if (isV3) {
+    if (F3_KNOCK & 128) {
+    } else if (isV3) {
       const int c = lane & 31, hf = lane >> 5;
       const double wn = L.w[c] * L.sc[F3_INVN];
 #pragma unroll
