@@ -188,6 +188,12 @@ __device__ __forceinline__ void f3_assemble_K(const BlockParams& b, const F3Lds&
   __syncthreads();
 }
 
+// Knock-out switches for tools/blk3_knock.hip (timing what each piece costs on the critical path; results are wrong
+// with any of them set).  0 in the product: every `if` below folds away.
+#ifndef F3_KNOCK
+#define F3_KNOCK 0
+#endif
+
 // One Newton-Schulz iteration of tile column C:  R = I - M X_c,  Xn = X_c + X^T R  (see the header).
 // Mf: the step's matrix, T-layout, tile (kt, ti) at [(kt * 2 + ti) * 4 + kk]; Xc: own column (T-layout, float64).
 // The correction X^T R is formed on the FLOAT32 matrix cores (v_mfma_f32_16x16x4_f32: 32 cycles against 64): R is small,
@@ -197,11 +203,6 @@ __device__ __forceinline__ void f3_assemble_K(const BlockParams& b, const F3Lds&
 // pi(4 a + v) = a + 4 v: the float32 MFMA returns row 4 (l >> 4) + v in register v where the float64 one returns
 // (l >> 4) + 4 v, and feeding it the rows in that order makes its output land in T-layout.
 // Returns this lane's share of ||R_c||_F^2.
-// Knock-out switches for tools/blk3_knock.hip (timing what each piece costs on the critical path; results are wrong
-// with any of them set).  0 in the product: every `if` below folds away.
-#ifndef F3_KNOCK
-#define F3_KNOCK 0
-#endif
 template <int C, bool FULL>
 __device__ __forceinline__ double f3_ns_iter(const double (&Mf)[16], const double (&Xc)[8], const float (&Xa)[16], double (&Xn)[8],
                                              const F3Mask<FULL>& mk) {
@@ -890,7 +891,21 @@ __global__ __launch_bounds__(F3_NT) void psmf_blk_filter3(BlockParams b) {
   __shared__ long long s_tick[2];
   L.tick = s_tick;
 
+  // Touch what the start-up will read -- the cross-Gram, the previous block's coefficients, the carried register dump --
+  // while the hand-off flags are in flight: one memory round trip for the three instead of three in a row.  (A cross-Gram
+  // that is not there yet is re-read after the poll's acquire fence.)
+  double pf = 0.0;
+  if (b.flags) {
+    if (b.assemble) {
+      pf = b.XG[(size_t)tid * 16];                                   // (RB + XGB) x XGB doubles = 512 lines of 128 bytes
+      if (tid < RB * RM / 16) pf += b.Aprev[tid * 16];
+    }
+    constexpr int kDumpLines = (int)((sizeof(st->f3_G) + sizeof(st->f3_W) + sizeof(st->f3_Xc) + sizeof(st->f3_V) + sizeof(st->f3_Xa)) / 128);
+    static_assert(kDumpLines <= F3_NT, "one line per thread");
+    if (tid < kDumpLines) pf += st->f3_G[tid * 16];                  // the dump is contiguous from f3_G
+  }
   if (!blk_handoff_begin(b)) return;
+  if (pf == 1.2345e300) hot[0] = pf;                                 // (keeps the loads; never true)
   const long long t_h = (long long)__builtin_amdgcn_s_memrealtime();
   if (!b.assemble) {
     for (int idx = tid; idx < RB * RB; idx += F3_NT) L.sK[idx] = b.K[idx];
