@@ -233,8 +233,11 @@ class DeviceFilter:
     def counters(self, reset=False):
         c = (C.c_int64 * 8)()
         self._check(self._lib.psmf_counters(self._h, c, int(bool(reset))))
+        # filter_launches counts BLOCKS (one launch each unless the blocks of a run are chained into one launch);
+        # filter_kernel_launches the launches of the filter kernel, filter_kernel_us_mean their mean duration
         return dict(ns_steps=c[0], sweep_steps=c[1], ns_iterations=c[2], ns_failed=c[3], filter_launches=c[7],
-                    filter_us_mean=0.01 * c[4] / max(1, c[7]), filter_gap_us_mean=0.01 * c[5] / max(1, c[7] - 1))
+                    filter_us_mean=0.01 * c[4] / max(1, c[7]), filter_gap_us_mean=0.01 * c[5] / max(1, c[7] - 1),
+                    filter_kernel_launches=c[6], filter_kernel_us_mean=0.01 * c[4] / max(1, c[6]))
 
     def y_pred(self, t0, nt, dtype=np.float64):
         out = np.empty((nt, self.d_local), dtype=dtype)

@@ -132,8 +132,19 @@ inline size_t blk_filter3_lds_bytes() {
 // psmf_block.hip):  K[0:r,0:r] = G (tracked), K[r+q, r+q'] = Y^T Y (lower part of XG), and the cross block
 // K[i, r+q] = sum_m Aprev[m, i] XG[m, q] on the float64 matrix cores: Aprev (RB x r) and the upper part of XG
 // (RB x nb) staged once in LDS, one 16 x 16 output tile per wave (16 MFMAs).  Ends with a barrier.
-__device__ __forceinline__ void f3_assemble_K(const BlockParams& b, const F3Lds& L, const int r, const int tid) {
-  const int nb = b.nb, lane = tid & 63, w = tid >> 6, lrow = lane >> 4, lcol = lane & 15;
+// What changes from block to block of a chained launch (uniform scalars; a modified COPY of BlockParams per block sent
+// the whole parameter set through VGPRs and scratch: 3.3 KB of spills, every phase 10-50 % slower).
+struct F3Blk {
+  long long k0;           // first step of the block is k0 + 1
+  int nb, last;
+  double* Acoef;
+  double* Bcoef;
+  const double* XG;
+  const double* Aprev;    // nullptr: the previous block of the same launch left its coefficients in sA
+};
+
+__device__ __forceinline__ void f3_assemble_K(const BlockParams& b, const F3Blk& k, const F3Lds& L, const int r, const int tid) {
+  const int nb = k.nb, lane = tid & 63, w = tid >> 6, lrow = lane >> 4, lcol = lane & 15;
   double* sK = L.sK;
   double* sA = L.sA;
   double* sX = L.sA + RB * F3_AS;
@@ -146,18 +157,19 @@ __device__ __forceinline__ void f3_assemble_K(const BlockParams& b, const F3Lds&
 #pragma unroll
   for (int u = 0; u < 5; ++u) {
     const int idx = min(tid + u * F3_NT, nb * nb - 1), q = idx / nb, q2 = idx - q * nb;
-    yy[u] = b.XG[(size_t)(RB + q) * XGB + q2];
+    yy[u] = xg_load(k.XG + (size_t)(RB + q) * XGB + q2);
   }
   if (r + nb < RB)            // a full block writes every entry of K below
     for (int idx = tid; idx < RB * RB; idx += F3_NT) sK[idx] = 0.0;
-  for (int idx = tid; idx < RB * 32; idx += F3_NT) {
-    const int m = idx >> 5, c = idx & 31;
-    const double v = b.Aprev[m * r + min(c, r - 1)];
-    sA[m * F3_AS + c] = c < r ? v : 0.0;
-  }
+  if (k.Aprev)                // (chained blocks: the previous block left its coefficients in sA)
+    for (int idx = tid; idx < RB * 32; idx += F3_NT) {
+      const int m = idx >> 5, c = idx & 31;
+      const double v = k.Aprev[m * r + min(c, r - 1)];
+      sA[m * F3_AS + c] = c < r ? v : 0.0;
+    }
   for (int idx = tid; idx < RB * F3_AS; idx += F3_NT) {
     const int m = idx / F3_AS, q = idx - m * F3_AS;
-    const double v = b.XG[(size_t)m * XGB + min(q, nb - 1)];
+    const double v = xg_load(k.XG + (size_t)m * XGB + min(q, nb - 1));
     sX[m * F3_AS + q] = q < nb ? v : 0.0;
   }
   __syncthreads();
@@ -288,11 +300,11 @@ __device__ __forceinline__ void f3_sweep_images(const F3Lds& L, const int r2, co
 // Program of the four inversion waves.  INV 0 = X (P+ = M^-1), 1 = Y (W = (M / beta + I / q)^-1); C = own tile column.
 // ------------------------------------------------------------------------------------------------------------
 template <int C, bool FULL>
-__device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds& L, const int inv, const int role, const int lane,
+__device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Blk& k, const F3Lds& L, const int inv, const int role, const int lane,
                                               const bool carried) {
   const StepParams& p = b.sp;
   DevState* st = p.st;
-  const int r = p.r, r2 = r + (r & 1), tid = threadIdx.x;
+  const int r = p.r, r2 = r + (r & 1), tid = 64 * role + lane;
   const int lrow = lane >> 4, lcol = lane & 15;
   const bool isX = inv == 0, isY = inv == 1;
   double* imgX = L.img;
@@ -421,7 +433,7 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
   bool w_from_img = false, fetch_late = false;
   double iq_w = carried ? st->f3_sc[0] : 1.0 / q0;          // 1 / q that Wf was formed with
   BLK_T0();
-  for (int jb = 0; jb < b.nb; ++jb) {
+  for (int jb = 0; jb < k.nb; ++jb) {
     // phase 0 (wave 4 forms w, s, kappa meanwhile): what the step that just ended left to do off the critical path
     if (fetch_late) F3_FETCH_PARTNER(w_par);     // (after BF: the partner published it in the last phase it ran)
     if (jb > 0) F3_W_AND_TRACES();
@@ -550,7 +562,7 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
       const double mu_new = mub_j + kap_k * vp;
       if (lrow == 0 && j < r) {
         L.mub[j] = mu_new;                    // random walk: mu_bar_{k+1} = mu_k
-        if (p.mu_hist) p.mu_hist[(size_t)(b.k0 + jb + 1 - p.series_t0) * r + j] = mu_new;
+        if (p.mu_hist) p.mu_hist[(size_t)(k.k0 + jb + 1 - p.series_t0) * r + j] = mu_new;
       }
       if (p.robust) {
         const double hvp = wave_sum_f64_dpp((lrow == 0) ? h_j * vp : 0.0);
@@ -564,7 +576,7 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
   BLK_TOUT();
   // ---- block end ----
   if (fetch_late) F3_FETCH_PARTNER(w_par);
-  if (b.nb > 0) F3_W_AND_TRACES();
+  if (k.nb > 0) F3_W_AND_TRACES();
   f3_barrier();                       // wave 4 has published pscale and 1 / omega of the last step
   const double ps = L.sc[F3_PSCALE], iom = L.sc[F3_IOM];
   // the state for the next block, as held: coalesced rows
@@ -581,7 +593,7 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
 #pragma unroll
     for (int e = 0; e < 16; ++e) st->f3_W[e * 64 + lane] = Wf[e];
   }
-  if (b.last) {
+  if (k.last) {
 #pragma unroll
     for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
@@ -609,10 +621,10 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Lds&
 // ------------------------------------------------------------------------------------------------------------
 // Program of the four vector waves: 4 = V and every scalar, 5 = A by rows, 6 = KA by rows, 7 = A^T by columns.
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void f3_v_program(const BlockParams& b, const F3Lds& L, const int role, const int lane, const bool carried) {
+__device__ __forceinline__ void f3_v_program(const BlockParams& b, const F3Blk& k, const F3Lds& L, const int role, const int lane, const bool carried) {
   const StepParams& p = b.sp;
   DevState* st = p.st;
-  const int r = p.r, r2 = r + (r & 1), tid = threadIdx.x;
+  const int r = p.r, r2 = r + (r & 1), tid = 64 * role + lane;
   const double dd = (double)p.d, idd = 1.0 / dd;
   const bool isV0 = role == 4, isV1 = role == 5, isV2 = role == 6, isV3 = role == 7;
   // Each vector wave shares its SIMD with an inversion wave.  At equal priority its ~60 VALU instructions per phase were
@@ -676,7 +688,7 @@ __device__ __forceinline__ void f3_v_program(const BlockParams& b, const F3Lds& 
   F3Ctl ctl = {carried, 0, 0, 0, 0, 0};
   if (role == 4 && lane == 0) L.tick[0] = (long long)__builtin_amdgcn_s_memrealtime();
   BLK_T0();
-  for (int jb = 0; jb < b.nb; ++jb) {
+  for (int jb = 0; jb < k.nb; ++jb) {
     // =============================== phase 0 ===============================
     double cm = 0.0;                       // V1: a_m, V2: (K a)_m  (kept for the rank-1 update of phase 2)
     if (isV0 && !(F3_KNOCK & 1024)) {
@@ -707,7 +719,7 @@ __device__ __forceinline__ void f3_v_program(const BlockParams& b, const F3Lds& 
       if (isV1) {
         cm = (lane == r + jb ? 1.0 : 0.0) - dot;                        // a_j = u_{r+j} - A mu_bar
         L.a[lane] = cm;
-        b.Bcoef[(size_t)jb * RB + lane] = dot;                          // y_hat_j = Z b_j
+        coef_store(k.Bcoef + (size_t)jb * RB + lane, dot);              // y_hat_j = Z b_j
       } else {
         cm = L.sK[lane * RB + r + jb] - dot;                            // K a_j
         L.Ka[lane] = cm;
@@ -815,7 +827,7 @@ __device__ __forceinline__ void f3_v_program(const BlockParams& b, const F3Lds& 
 
   // ---- block end ----
   if (isV0) {
-    if (b.nb > 0) F3_V0_FINISH_PREV();
+    if (k.nb > 0) F3_V0_FINISH_PREV();
     if (lane == 0) { L.sc[F3_PSCALE] = pscale; L.sc[F3_IOM] = fast_rcp(omega); L.sc[F3_Q] = q; }
   } else if (isV1) {
 #pragma unroll
@@ -826,7 +838,7 @@ __device__ __forceinline__ void f3_v_program(const BlockParams& b, const F3Lds& 
     const int j = lane & 31, hf = lane >> 5;
 #pragma unroll
     for (int t = 0; t < 16; ++t) st->f3_V[t * 64 + lane] = pr[t];
-    if (b.last) {
+    if (k.last) {
 #pragma unroll
       for (int t = 0; t < 16; ++t) {
         const int i = 16 * hf + t;
@@ -841,27 +853,25 @@ __device__ __forceinline__ void f3_v_program(const BlockParams& b, const F3Lds& 
     if (lane < r) st->mu[lane] = L.mub[lane];
     if (lane == 0) {
       st->f3_sc[1] = L.sc[F3_IOM]; st->f3_sc[2] = pscale;
-      st->k = b.k0 + b.nb;
+      st->k = k.k0 + k.nb;
       st->rho = rho; st->lam = lam; st->phi = phi; st->omega = omega; st->ee = ee_k;
       st->s_done = s_k; st->eta_done = eta_k; st->N_done = Nk;
-      if (*L.errflag && st->err == 0) st->err = (int)(b.k0 + 1);
+      if (*L.errflag && st->err == 0) st->err = (int)(k.k0 + 1);
       st->ns_valid = 3;
     }
   }
   // A_B (wave 5's rows) left through LDS before the barrier above: all four vector waves store it, coalesced
-  for (int idx = tid - 256; idx < RB * r; idx += 256) { const int m = idx / r, c = idx - m * r; b.Acoef[idx] = L.sA[m * F3_AS + c]; }
+  for (int idx = tid - 256; idx < RB * r; idx += 256) { const int m = idx / r, c = idx - m * r; coef_store(k.Acoef + idx, L.sA[m * F3_AS + c]); }
 #undef F3_V0_FINISH_PREV
 }
 
-__global__ __launch_bounds__(F3_NT) void psmf_blk_filter3(BlockParams b) {
+__global__ __launch_bounds__(F3_NT) void psmf_blk_filter3(BlockParams b0) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* sm = reinterpret_cast<double*>(smem_raw);
-  const StepParams& p = b.sp;
+  const StepParams& p = b0.sp;
   DevState* st = p.st;
-  const int r = p.r, tid = threadIdx.x, lane = tid & 63;
-  const int role = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: the role branches are scalar branches
+  const int r = p.r, tid0 = threadIdx.x;
   const int r2 = r + (r & 1);
-  const long long t_begin = (long long)__builtin_amdgcn_s_memrealtime();      // 100 MHz: in-situ duration / gap diagnostics
   // ---- LDS carve ----
   // Everything a step touches sits in STATIC LDS: its addresses are compile-time constants that fold into the ds
   // instructions' immediate offsets.  (Off the dynamic-LDS base the compiler formed (lane part + constant) + base for
@@ -891,26 +901,62 @@ __global__ __launch_bounds__(F3_NT) void psmf_blk_filter3(BlockParams b) {
   __shared__ long long s_tick[2];
   L.tick = s_tick;
 
-  // Touch what the start-up will read -- the cross-Gram, the previous block's coefficients, the carried register dump --
-  // while the hand-off flags are in flight: one memory round trip for the three instead of three in a row.  (A cross-Gram
-  // that is not there yet is re-read after the poll's acquire fence.)
-  double pf = 0.0;
-  if (b.flags) {
-    if (b.assemble) {
-      pf = b.XG[(size_t)tid * 16];                                   // (RB + XGB) x XGB doubles = 512 lines of 128 bytes
-      if (tid < RB * RM / 16) pf += b.Aprev[tid * 16];
+  // ---- one launch = `chain` consecutive blocks (1 when the blocks are launched one by one) ----
+  // Chained, the blocks of a run pay the kernel launch, the cold instruction cache and the hand-off round trips once
+  // instead of once per block; the state still travels from block to block through the f3_* dump (this CU's L1 / L2).
+  const int nchain = b0.chain > 1 ? b0.chain : 1;
+  for (int j = 0; j < nchain; ++j) {
+  // (the thread index is made opaque per block: otherwise everything the programs' prologues derive from it -- lane masks,
+  //  LDS addresses, layouts -- is loop-invariant, gets hoisted out of this loop and stays live across it: 3.3 KB of spills)
+  int tid = tid0;
+  asm volatile("" : "+v"(tid));
+  const int lane = tid & 63;
+  const int role = __builtin_amdgcn_readfirstlane(tid >> 6);       // wave-uniform: the role branches are scalar branches
+  const BlockParams& b = b0;
+  F3Blk k;
+  k.k0 = b0.k0; k.nb = b0.nb; k.last = b0.last; k.Acoef = b0.Acoef; k.Bcoef = b0.Bcoef; k.XG = b0.XG; k.Aprev = b0.Aprev;
+  int assemble = b0.assemble;
+  long long seq = b0.seq;
+  if (b0.chain > 1) {
+    const int slot = j & 1;
+    k.k0 = b0.k0 + (long long)j * b0.chain_B;
+    const long long left = b0.chain_kend - k.k0;
+    k.nb = (int)(left < b0.chain_B ? left : b0.chain_B);
+    k.Acoef = b0.Acoef0 + (size_t)slot * RB * RM;
+    k.Bcoef = b0.Bcoef0 + (size_t)slot * RB * RB;
+    seq = b0.seq + j;
+    k.last = (j == nchain - 1) ? b0.last : 0;
+    if (j > 0) {
+      assemble = 1;
+      k.XG = b0.XG0 + (size_t)slot * (RB + XGB) * XGB;
+      k.Aprev = nullptr;                                               // left in sA by the block that just ended
     }
-    constexpr int kDumpLines = (int)((sizeof(st->f3_G) + sizeof(st->f3_W) + sizeof(st->f3_Xc) + sizeof(st->f3_V) + sizeof(st->f3_Xa)) / 128);
-    static_assert(kDumpLines <= F3_NT, "one line per thread");
-    if (tid < kDumpLines) pf += st->f3_G[tid * 16];                  // the dump is contiguous from f3_G
   }
-  if (!blk_handoff_begin(b)) return;
-  if (pf == 1.2345e300) hot[0] = pf;                                 // (keeps the loads; never true)
+  const long long t_begin = (long long)__builtin_amdgcn_s_memrealtime();      // 100 MHz: in-situ duration / gap diagnostics
+  if (j > 0) {
+    if (!blk_chain_next(b0, seq)) return;
+  } else {
+    // Touch what the start-up will read -- the cross-Gram, the previous block's coefficients, the carried register dump --
+    // while the hand-off flags are in flight: one memory round trip for the three instead of three in a row.  (A cross-Gram
+    // that is not there yet is re-read after the poll's acquire fence.)
+    double pf = 0.0;
+    if (b.flags) {
+      if (assemble) {
+        pf = k.XG[(size_t)tid * 16];                                   // (RB + XGB) x XGB doubles = 512 lines of 128 bytes
+        if (tid < RB * RM / 16) pf += k.Aprev[tid * 16];
+      }
+      constexpr int kDumpLines = (int)((sizeof(st->f3_G) + sizeof(st->f3_W) + sizeof(st->f3_Xc) + sizeof(st->f3_V) + sizeof(st->f3_Xa)) / 128);
+      static_assert(kDumpLines <= F3_NT, "one line per thread");
+      if (tid < kDumpLines) pf += st->f3_G[tid * 16];                  // the dump is contiguous from f3_G
+    }
+    if (!blk_handoff_begin(b)) return;
+    if (pf == 1.2345e300) hot[0] = pf;                                 // (keeps the loads; never true)
+  }
   const long long t_h = (long long)__builtin_amdgcn_s_memrealtime();
-  if (!b.assemble) {
+  if (!assemble) {
     for (int idx = tid; idx < RB * RB; idx += F3_NT) L.sK[idx] = b.K[idx];
   } else {
-    f3_assemble_K(b, L, r, tid);
+    f3_assemble_K(b, k, L, r, tid);
   }
   if (tid == 0) *L.errflag = 0;
   if (tid < RM) { L.mub[tid] = (tid < r) ? st->mu[tid] : 0.0; L.w[tid] = 0.0; L.h[tid] = 0.0; }
@@ -936,14 +982,14 @@ __global__ __launch_bounds__(F3_NT) void psmf_blk_filter3(BlockParams b) {
   if (role < 4) {
     const int inv = role >> 1;
     if (r == 32) {
-      if (role & 1) f3_ns_program<1, true>(b, L, inv, role, lane, carried);
-      else f3_ns_program<0, true>(b, L, inv, role, lane, carried);
+      if (role & 1) f3_ns_program<1, true>(b, k, L, inv, role, lane, carried);
+      else f3_ns_program<0, true>(b, k, L, inv, role, lane, carried);
     } else {
-      if (role & 1) f3_ns_program<1, false>(b, L, inv, role, lane, carried);
-      else f3_ns_program<0, false>(b, L, inv, role, lane, carried);
+      if (role & 1) f3_ns_program<1, false>(b, k, L, inv, role, lane, carried);
+      else f3_ns_program<0, false>(b, k, L, inv, role, lane, carried);
     }
   } else {
-    f3_v_program(b, L, role, lane, carried);
+    f3_v_program(b, k, L, role, lane, carried);
   }
   if (tid == 0) {
     // cnt[4]: sum of in-kernel durations, cnt[5]: sum of the gaps to the previous filter kernel, cnt[7]: launches (10 ns ticks)
@@ -953,6 +999,14 @@ __global__ __launch_bounds__(F3_NT) void psmf_blk_filter3(BlockParams b) {
     if (st->cnt[6] != 0) st->cnt[5] += t_begin - st->cnt[6];
     st->cnt[6] = t_end;
     st->cnt[7] += 1;
+    if (j == 0) st->dbg[5] += 1;            // kernel launches
+  }
+  }   // chained blocks
+  if (b0.chain > 1) {
+    // the last block of the chain: complete, announced (the apply kernel of the bulk stream is waiting for it)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid0 == 0) flag_store(b0.flags + 1, b0.seq + nchain);
   }
 }
 

@@ -62,6 +62,15 @@ struct BlockParams {
   long long* flags;
   long long seq;          // this block's sequence number
   int last;               // filter3: last block of the run -> also write the row-major r x r state (DevState)
+  // chain (filter3): ONE launch advances `chain` consecutive blocks of `chain_B` steps (the last one may be shorter, the
+  // run ends at chain_kend); block j of the launch uses slot j & 1 of the ping-pong buffers below, sequence number seq + j,
+  // and is assembled from block j - 1 (j > 0).  See psmf_blk_filter3.
+  int chain;
+  int chain_B;
+  long long chain_kend;
+  double* Acoef0;         // 2 x RB x RM
+  double* Bcoef0;         // 2 x RB x RB
+  const double* XG0;      // 2 x (RB + XGB) x XGB
 };
 
 // ---- hand-off through device flags -------------------------------------------------------------------------------
@@ -107,6 +116,39 @@ __device__ __forceinline__ bool blk_handoff_begin(const BlockParams& b) {
   __syncthreads();
   return *s_flag != 0;
 }
+
+// chain: between two blocks of one launch.  The stores of the block that just ended are complete (coefficients for the
+// apply kernel were stored with agent scope, see coef_store), so it is announced; then the block's own cross-Gram is
+// awaited (it practically always is there).  Returns false (uniformly) if the run was aborted; ends with a barrier.
+__device__ __forceinline__ bool blk_chain_next(const BlockParams& b, const long long seq) {
+  __shared__ int s_ok;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int ok = 1;
+    flag_store(b.flags + 1, seq);                      // blocks < seq are complete
+    const long long xg0 = flag_load(b.flags + 0), ab0 = flag_load(b.flags + 2);
+    if (ab0 != 0) ok = 0;
+    if (ok && xg0 < seq) {
+      const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+      while (flag_load(b.flags + 0) < seq) {
+        __builtin_amdgcn_s_sleep(4);
+        if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > HANDOFF_MAX_TICKS || flag_load(b.flags + 2) != 0) { ok = 0; break; }
+      }
+      if (!ok) { flag_store(b.flags + 2, 1); if (b.sp.st->err == 0) b.sp.st->err = -7; }
+    }
+    s_ok = ok;
+  }
+  __syncthreads();
+  __builtin_amdgcn_s_dcache_inv();      // the scalar cache does not see this kernel's own vector stores (DevState fields)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  return s_ok != 0;
+}
+
+// Coefficients the apply kernel (other XCDs, released by a device flag instead of a kernel boundary when blocks are
+// chained) reads: agent-scope stores go through to where every XCD sees them.  The cross-Gram is read the same way.
+__device__ __forceinline__ void coef_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double xg_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 __global__ void psmf_flag_set_k(long long* f, long long v) { flag_store(f, v); }
 

@@ -343,6 +343,9 @@ int enqueue_blocks_pipelined(psmf_filter* h, int64_t k_begin, int64_t k_end) {
   const bool use_flags = h->fstream != nullptr && h->flags != nullptr && !flags_off;
   const long long s0 = h->seq_next;
   h->seq_next += nblk;
+  // chain: the filter kernels of the whole run as ONE launch (psmf_blk_filter3; the bulk stream is driven as before)
+  static const bool chain_off = getenv("PSMF_BLOCK_CHAIN") && atoi(getenv("PSMF_BLOCK_CHAIN")) == 0;
+  const bool chain = use_flags && !chain_off && nblk > 1 && blk_dual_ok(h) && h->geo.rpad == 32 && blk_use_filter3();
   // first block: plain Gram of the stored C
   fill_block_params(h, b, k0_of(0), nb_of(0), 0);
   launch_blk_gram(h, b, h->bulk);
@@ -350,6 +353,20 @@ int enqueue_blocks_pipelined(psmf_filter* h, int64_t k_begin, int64_t k_end) {
     NCCL_TRY(h, ncclAllReduce(h->Kmat, h->Kmat, psmf::RB * psmf::RB, ncclDouble, ncclSum, h->comm, h->bulk));
   if (use_flags) hipLaunchKernelGGL(psmf::psmf_flag_set_k, dim3(1), dim3(1), 0, h->bulk, h->flags + 0, s0);
   else HIP_TRY(h, hipEventRecord(h->evX[0], h->bulk));
+  if (chain) {
+    psmf::BlockParams c;
+    fill_block_params(h, c, k0_of(0), nb_of(0), 0);
+    c.flags = h->flags;
+    c.seq = s0;
+    c.last = 1;
+    c.chain = (int)nblk;
+    c.chain_B = B;
+    c.chain_kend = k_end;
+    c.Acoef0 = h->Acoef;
+    c.Bcoef0 = h->Bcoef;
+    c.XG0 = h->XG;
+    launch_blk_filter(h, c, fs);
+  }
   for (int64_t bi = 0; bi < nblk; ++bi) {
     const int slot = (int)(bi & 1);
     // bulk: cross-Gram for block bi + 1 (needs C as of the start of block bi)
@@ -375,8 +392,10 @@ int enqueue_blocks_pipelined(psmf_filter* h, int64_t k_begin, int64_t k_end) {
     if (use_flags) {
       b.flags = h->flags;
       b.seq = s0 + bi;
-      launch_blk_filter(h, b, fs);
-      if (bi + 1 == nblk) hipLaunchKernelGGL(psmf::psmf_flag_set_k, dim3(1), dim3(1), 0, fs, h->flags + 1, s0 + nblk);   // the last block has no successor to announce it
+      if (!chain) {
+        launch_blk_filter(h, b, fs);
+        if (bi + 1 == nblk) hipLaunchKernelGGL(psmf::psmf_flag_set_k, dim3(1), dim3(1), 0, fs, h->flags + 1, s0 + nblk);   // the last block has no successor to announce it
+      }
       hipLaunchKernelGGL(psmf::psmf_flag_wait_k, dim3(1), dim3(64), 0, h->bulk, h->flags, s0 + bi + 1, h->st);
     } else {
       HIP_TRY(h, hipStreamWaitEvent(fs, h->evX[bi & 3], 0));
@@ -1031,6 +1050,7 @@ int psmf_counters(psmf_handle h, int64_t* out8, int reset) {
   HIP_TRY(h, hipMemcpy(c, h->st->cnt, sizeof(c), hipMemcpyDeviceToHost));
   HIP_TRY(h, hipMemcpy(g, h->st->dbg, sizeof(g), hipMemcpyDeviceToHost));
   for (int i = 0; i < 8; ++i) out8[i] = c[i];
+  out8[6] = g[5];       // kernel launches of psmf_blk_filter3 (cnt[7] counts blocks; cnt[6] is a raw time stamp)
   if (getenv("PSMF_DBG_BREAKDOWN") && c[7] > 0)
     fprintf(stderr, "[psmf] filter3 per launch: hand-off %.2f us, K %.2f, init %.2f, steps %.2f, end %.2f\n", 0.01 * g[0] / c[7], 0.01 * g[1] / c[7],
             0.01 * g[2] / c[7], 0.01 * g[3] / c[7], 0.01 * g[4] / c[7]);
