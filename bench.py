@@ -189,6 +189,7 @@ def main():
     f.sync()
     if geo_engine_block(f):
         f.counters(reset=True)
+        f.filter_kernel_time(reset=True)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -197,6 +198,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     insitu = f.counters() if geo_engine_block(f) else None      # device-timer durations of the filter kernels of the timed region
+    chained = f.filter_kernel_time() if geo_engine_block(f) else (0, 0.0)   # HIP events around the chained filter launches of the timed region
     if dist is not None:
         import torch
 
@@ -216,24 +218,36 @@ def main():
         t_filter = f.time_kernel(0, 20)
         t_gram = f.time_kernel(1, 50)
         t_apply = f.time_kernel(2, 50)
-        # duration of the dominant kernel: its average over the launches of the TIMED REGION, from the kernel's own
-        # s_memrealtime stamps (psmf_counters); HIP events cannot bracket single kernels of the pipelined streams without
-        # adding 5-8 us each.  The stand-alone HIP-event figure (psmf_time_kernel) is reported beside it.
-        full_blocks_only = (T % B == 0)
-        t_insitu = insitu["filter_us_mean"] if insitu and insitu["filter_launches"] > 0 else t_filter
-        kernel, kernel_us, steps_per_launch = "psmf_blk_filter3", t_insitu, (B if full_blocks_only else T / (insitu["filter_launches"] / args.steps))
+        # Duration of the dominant kernel over the TIMED REGION.  Chained blocks (the default): one launch of
+        # psmf_blk_filter3 per pass, bracketed by HIP events on the stream it runs on (psmf_filter_kernel_time); it advances
+        # every timestep of the pass.  Unchained (PSMF_BLOCK_CHAIN=0): one launch per block, timed by the kernel's own
+        # s_memrealtime stamps (HIP events between those launches add 5-8 us each).  The stand-alone HIP-event figure of a
+        # single block (psmf_time_kernel) is reported beside it.
+        t_block_insitu = insitu["filter_us_mean"] if insitu and insitu["filter_launches"] > 0 else t_filter
+        if chained[0] > 0:
+            kernel, kernel_us, steps_per_launch = "psmf_blk_filter3", 1e3 * chained[1] / chained[0], args.steps * T / chained[0]
+        else:
+            full_blocks_only = (T % B == 0)
+            kernel, kernel_us = "psmf_blk_filter3", t_block_insitu
+            steps_per_launch = B if full_blocks_only else T / (insitu["filter_launches"] / args.steps)
         zbytes = (4.0 if args.storage == "f32" else 8.0) * d_local * 64
         pmc = os.path.join(ROOT, "profiles", "r1_pmc_traffic_block_engine.json")
         if (d, r, args.storage, world) == (100_000, 32, "f32", 1) and os.path.exists(pmc):
-            traffic = json.load(open(pmc))["traffic_bytes_per_launch"]   # rocprofv3 --pmc passes of this workload (filter kernel)
+            # rocprofv3 --pmc passes of this workload, taken with PSMF_BLOCK_CHAIN=0 (counter collection serialises the
+            # kernels, which a chained launch waiting for the bulk stream cannot survive): bytes per block of B timesteps,
+            # scaled to the blocks one launch advances
+            traffic = json.load(open(pmc))["traffic_bytes_per_launch"] * (steps_per_launch / B)
         extra = {"steps_per_launch": steps_per_launch,
-                 "kernel_us_hip_events_standalone": t_filter,
-                 "filter_gap_us_in_timed_region": insitu["filter_gap_us_mean"] if insitu else None,
+                 "blocks_per_launch": steps_per_launch / B,
+                 "block_us_in_kernel": t_block_insitu,
+                 "one_block_us_hip_events_standalone": t_filter,
+                 "gap_between_blocks_us": insitu["filter_gap_us_mean"] if insitu else None,
                  "kernels_us": {"psmf_blk_filter3": t_filter, "psmf_blk_xgram2+xreduce2": t_gram, "psmf_blk_apply2": t_apply},
                  "bulk_kernels_GBps": {"cross-Gram (reads Z and the next series block)": 1.5 * zbytes / (t_gram * 1e-6) / 1e9,
                                        "apply (reads Z, writes C and y_hat)": 2 * zbytes / (t_apply * 1e-6) / 1e9},
-                 "note": "blocked engine: the filter kernel is a latency-bound chain of r x r stages (one workgroup, f64-MFMA Newton-Schulz); "
-                         "achieved = step-at-a-time algorithmic bytes of the B steps it advances / its duration"}
+                 "note": "blocked engine: the filter kernel is a latency-bound chain of r x r stages (one workgroup, f64-MFMA Newton-Schulz), "
+                         "one launch per pass; achieved = step-at-a-time algorithmic bytes of the timesteps it advances / its duration "
+                         "(HIP events on its stream)"}
     else:
         kernel, kernel_us, steps_per_launch = "psmf_sweep_solve", f.time_kernel(0, 300), 1
         extra = {"steps_per_launch": 1, "kernels_us": {"psmf_sweep_solve": kernel_us, "psmf_serial": f.time_kernel(1, 300)}}

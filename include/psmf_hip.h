@@ -152,6 +152,11 @@ int psmf_geometry(psmf_handle h, int32_t* out7);
  * consecutive filter kernels in 10 ns ticks, out[7] = filter launches; reset != 0 clears them.  (New: the reference has no
  * counterpart; its np.linalg.inv calls are pypsmf/psmf/psmf.py:147-149.) */
 int psmf_counters(psmf_handle h, int64_t* out8, int reset);
+/* Blocked engine with chained blocks (one launch of the coefficient-space filter kernel per psmf_run): number of such
+ * launches completed since the last reset and the sum of their durations, measured with HIP events recorded around each
+ * launch on the stream it runs on (at most 16 runs between two psmf_sync calls are timed).  Waits like psmf_sync.
+ * (New: measurement aid for bench.py; the reference times whole runs with time.time(), ExperimentImpute/PSMF.py:59,91.) */
+int psmf_filter_kernel_time(psmf_handle h, int64_t* launches, double* total_ms, int reset);
 
 /* ================= masked, batched small-d filter (ExperimentImpute) ==================== */
 typedef struct {

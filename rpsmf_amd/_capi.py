@@ -65,6 +65,7 @@ SIGNATURES = {
     "psmf_time_kernel": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "psmf_geometry": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "psmf_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
+    "psmf_filter_kernel_time": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_int]),
     "psmf_impute_run": (C.c_int, [C.POINTER(PsmfImputeConfig), _dp, _u8p, _u8p, _dp, _dp, _dp, _dp, _dp,
                                   C.c_double, _dp, _dp, _dp, _dp, _dp, _dp, C.POINTER(C.c_float)]),
 }
@@ -238,6 +239,12 @@ class DeviceFilter:
         return dict(ns_steps=c[0], sweep_steps=c[1], ns_iterations=c[2], ns_failed=c[3], filter_launches=c[7],
                     filter_us_mean=0.01 * c[4] / max(1, c[7]), filter_gap_us_mean=0.01 * c[5] / max(1, c[7] - 1),
                     filter_kernel_launches=c[6], filter_kernel_us_mean=0.01 * c[4] / max(1, c[6]))
+
+    def filter_kernel_time(self, reset=False):
+        """(launches, total_ms) of the chained filter-kernel launches since the last reset (HIP events on their stream)."""
+        n, ms = C.c_int64(0), C.c_double(0.0)
+        self._check(self._lib.psmf_filter_kernel_time(self._h, C.byref(n), C.byref(ms), int(bool(reset))))
+        return int(n.value), float(ms.value)
 
     def y_pred(self, t0, nt, dtype=np.float64):
         out = np.empty((nt, self.d_local), dtype=dtype)

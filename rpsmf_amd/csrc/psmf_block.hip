@@ -152,6 +152,19 @@ __device__ __forceinline__ double xg_load(const double* p) { return __hip_atomic
 
 __global__ void psmf_flag_set_k(long long* f, long long v) { flag_store(f, v); }
 
+// Can a kernel of one stream wait for a kernel of another stream that was submitted AFTER it?  (The chained filter kernel
+// does; a tool that serialises kernel dispatches -- counter collection -- makes that a dead wait.)  The waiter gives up
+// after `ticks` of the 100 MHz counter and reports in out[0]: 1 = the flag came, 0 = it did not.
+__global__ void psmf_probe_wait_k(long long* f, long long v, long long ticks, int* out) {
+  const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+  int ok = 1;
+  while (flag_load(f) < v) {
+    __builtin_amdgcn_s_sleep(8);
+    if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > ticks) { ok = 0; break; }
+  }
+  out[0] = ok;
+}
+
 // bulk stream: hold the stream until flags[1] >= v (the filter kernel of block v - 1 has finished)
 __global__ void psmf_flag_wait_k(long long* flags, long long v, DevState* st) {
   if (threadIdx.x != 0) return;

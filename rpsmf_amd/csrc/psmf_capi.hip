@@ -48,6 +48,13 @@ struct psmf_filter {
   double* gpart = nullptr;
   double* mu_hist = nullptr;   // (T_cap + 1) x r
   hipStream_t fstream = nullptr;   // blocked engine, pipelined: the filter chain's own stream, pinned to reserved CUs (or nullptr)
+  bool chain_ok = false;           // the filter stream's kernels run concurrently with the bulk stream's (probed at creation)
+  // HIP-event timing of the chained filter launches (one per run): a ring of event pairs, read out at the next sync
+  static constexpr int kTimedRuns = 16;
+  hipEvent_t evK0[kTimedRuns] = {}, evK1[kTimedRuns] = {};
+  int evk_pending = 0;
+  double kernel_ms_sum = 0.0;
+  long long kernel_launches = 0;
   int reserved_cus = 0;
   double* scratch = nullptr;   // sq-error partials / predict staging
   // blocked engine
@@ -345,7 +352,7 @@ int enqueue_blocks_pipelined(psmf_filter* h, int64_t k_begin, int64_t k_end) {
   h->seq_next += nblk;
   // chain: the filter kernels of the whole run as ONE launch (psmf_blk_filter3; the bulk stream is driven as before)
   static const bool chain_off = getenv("PSMF_BLOCK_CHAIN") && atoi(getenv("PSMF_BLOCK_CHAIN")) == 0;
-  const bool chain = use_flags && !chain_off && nblk > 1 && blk_dual_ok(h) && h->geo.rpad == 32 && blk_use_filter3();
+  const bool chain = use_flags && h->chain_ok && !chain_off && nblk > 1 && blk_dual_ok(h) && h->geo.rpad == 32 && blk_use_filter3();
   // first block: plain Gram of the stored C
   fill_block_params(h, b, k0_of(0), nb_of(0), 0);
   launch_blk_gram(h, b, h->bulk);
@@ -365,7 +372,10 @@ int enqueue_blocks_pipelined(psmf_filter* h, int64_t k_begin, int64_t k_end) {
     c.Acoef0 = h->Acoef;
     c.Bcoef0 = h->Bcoef;
     c.XG0 = h->XG;
+    const int slot_ev = h->evk_pending < psmf_filter::kTimedRuns ? h->evk_pending : -1;
+    if (slot_ev >= 0) HIP_TRY(h, hipEventRecord(h->evK0[slot_ev], fs));
     launch_blk_filter(h, c, fs);
+    if (slot_ev >= 0) { HIP_TRY(h, hipEventRecord(h->evK1[slot_ev], fs)); ++h->evk_pending; }
   }
   for (int64_t bi = 0; bi < nblk; ++bi) {
     const int slot = (int)(bi & 1);
@@ -624,6 +634,22 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
       CREATE_TRY(hipEventCreateWithFlags(&h->evX[i], hipEventDisableTiming));
     }
     CREATE_TRY(hipEventCreateWithFlags(&h->evS, hipEventDisableTiming));
+    for (int i = 0; i < psmf_filter::kTimedRuns; ++i) { CREATE_TRY(hipEventCreate(&h->evK0[i])); CREATE_TRY(hipEventCreate(&h->evK1[i])); }
+    if (h->fstream && h->flags) {
+      // chained filter launches need the two streams to run concurrently: probe it (a waiter on the filter stream, then the
+      // setter on the bulk stream; the waiter gives up after 50 ms)
+      int* dres = nullptr;
+      CREATE_TRY(hipMalloc((void**)&dres, sizeof(int)));
+      CREATE_TRY(hipMemset(dres, 0, sizeof(int)));
+      hipLaunchKernelGGL(psmf::psmf_probe_wait_k, dim3(1), dim3(1), 0, h->fstream, h->flags + 7, 1LL, 5000000LL, dres);
+      hipLaunchKernelGGL(psmf::psmf_flag_set_k, dim3(1), dim3(1), 0, h->bulk, h->flags + 7, 1LL);
+      CREATE_TRY(hipStreamSynchronize(h->fstream));
+      CREATE_TRY(hipStreamSynchronize(h->bulk));
+      int res = 0;
+      CREATE_TRY(hipMemcpy(&res, dres, sizeof(int), hipMemcpyDeviceToHost));
+      hipFree(dres);
+      h->chain_ok = res == 1;
+    }
     const size_t flds = psmf::blk_filter_lds_bytes();
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_filter<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_filter<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
@@ -695,6 +721,7 @@ void psmf_destroy(psmf_handle h) {
   if (h->flags) hipFree(h->flags);
   for (int i = 0; i < 4; ++i) { if (h->evF[i]) hipEventDestroy(h->evF[i]); if (h->evA[i]) hipEventDestroy(h->evA[i]); if (h->evX[i]) hipEventDestroy(h->evX[i]); }
   if (h->evS) hipEventDestroy(h->evS);
+  for (int i = 0; i < psmf_filter::kTimedRuns; ++i) { if (h->evK0[i]) hipEventDestroy(h->evK0[i]); if (h->evK1[i]) hipEventDestroy(h->evK1[i]); }
   if (h->bulk) { hipStreamSynchronize(h->bulk); hipStreamDestroy(h->bulk); }
   if (h->fstream) { hipStreamSynchronize(h->fstream); hipStreamDestroy(h->fstream); }
   if (h->scratch) hipFree(h->scratch);
@@ -929,6 +956,12 @@ int psmf_sync(psmf_handle h) {
   hipLaunchKernelGGL(psmf::psmf_publish_err_k, dim3(1), dim3(1), 0, h->stream, (const DevState*)h->st, h->err_host_dev);
   const double t_s1 = g_host_timing ? host_now_ms() : 0.0;
   HIP_TRY(h, spin_stream(h->stream));
+  for (int i = 0; i < h->evk_pending; ++i) {         // the chained filter launches that finished: their durations
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, h->evK0[i], h->evK1[i]) == hipSuccess) { h->kernel_ms_sum += ms; ++h->kernel_launches; }
+    else (void)hipGetLastError();
+  }
+  h->evk_pending = 0;
   if (g_host_timing) { const double t = host_now_ms(); if (t_s1 - t_s0 > 5.0) fprintf(stderr, "[psmf host timing] memcpyAsync call %.1f ms\n", t_s1 - t_s0); if (t - t_s1 > 5.0) fprintf(stderr, "[psmf host timing] spin wait %.1f ms\n", t - t_s1); }
   const int err = *h->err_host;
   if (err == -7) return fail(h, PSMF_ERR_HIP, "pipelined blocks: a device-flag hand-off timed out (PSMF_BLOCK_FLAGS=0 selects event hand-off)");
@@ -1055,6 +1088,16 @@ int psmf_counters(psmf_handle h, int64_t* out8, int reset) {
     fprintf(stderr, "[psmf] filter3 per launch: hand-off %.2f us, K %.2f, init %.2f, steps %.2f, end %.2f\n", 0.01 * g[0] / c[7], 0.01 * g[1] / c[7],
             0.01 * g[2] / c[7], 0.01 * g[3] / c[7], 0.01 * g[4] / c[7]);
   if (reset) { HIP_TRY(h, hipMemset(h->st->cnt, 0, sizeof(c))); HIP_TRY(h, hipMemset(h->st->dbg, 0, sizeof(g))); }
+  return PSMF_OK;
+}
+
+int psmf_filter_kernel_time(psmf_handle h, int64_t* launches, double* total_ms, int reset) {
+  if (!h || !launches || !total_ms) return PSMF_ERR_ARG;
+  int rc = psmf_sync(h);
+  if (rc) return rc;
+  *launches = h->kernel_launches;
+  *total_ms = h->kernel_ms_sum;
+  if (reset) { h->kernel_launches = 0; h->kernel_ms_sum = 0.0; }
   return PSMF_OK;
 }
 
