@@ -48,7 +48,7 @@ struct psmf_filter {
   double* gpart = nullptr;
   double* mu_hist = nullptr;   // (T_cap + 1) x r
   hipStream_t fstream = nullptr;   // blocked engine, pipelined: the filter chain's own stream, pinned to reserved CUs (or nullptr)
-  bool chain_ok = false;           // the filter stream's kernels run concurrently with the bulk stream's (probed at creation)
+  bool streams_concurrent = false;           // the filter stream's kernels run concurrently with the bulk stream's (probed at creation)
   // HIP-event timing of the chained filter launches (one per run): a ring of event pairs, read out at the next sync
   static constexpr int kTimedRuns = 16;
   hipEvent_t evK0[kTimedRuns] = {}, evK1[kTimedRuns] = {};
@@ -347,12 +347,12 @@ int enqueue_blocks_pipelined(psmf_filter* h, int64_t k_begin, int64_t k_end) {
   psmf::BlockParams b;
   // hand-off by device flags when the filter chain has a stream (hardware queue) of its own; by events otherwise
   static const bool flags_off = getenv("PSMF_BLOCK_FLAGS") && atoi(getenv("PSMF_BLOCK_FLAGS")) == 0;
-  const bool use_flags = h->fstream != nullptr && h->flags != nullptr && !flags_off;
+  const bool use_flags = h->fstream != nullptr && h->flags != nullptr && !flags_off && h->streams_concurrent;   // (a tool that serialises dispatches: events)
   const long long s0 = h->seq_next;
   h->seq_next += nblk;
   // chain: the filter kernels of the whole run as ONE launch (psmf_blk_filter3; the bulk stream is driven as before)
   static const bool chain_off = getenv("PSMF_BLOCK_CHAIN") && atoi(getenv("PSMF_BLOCK_CHAIN")) == 0;
-  const bool chain = use_flags && h->chain_ok && !chain_off && nblk > 1 && blk_dual_ok(h) && h->geo.rpad == 32 && blk_use_filter3();
+  const bool chain = use_flags && !chain_off && nblk > 1 && blk_dual_ok(h) && h->geo.rpad == 32 && blk_use_filter3();
   // first block: plain Gram of the stored C
   fill_block_params(h, b, k0_of(0), nb_of(0), 0);
   launch_blk_gram(h, b, h->bulk);
@@ -636,7 +636,7 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
     CREATE_TRY(hipEventCreateWithFlags(&h->evS, hipEventDisableTiming));
     for (int i = 0; i < psmf_filter::kTimedRuns; ++i) { CREATE_TRY(hipEventCreate(&h->evK0[i])); CREATE_TRY(hipEventCreate(&h->evK1[i])); }
     if (h->fstream && h->flags) {
-      // chained filter launches need the two streams to run concurrently: probe it (a waiter on the filter stream, then the
+      // the device-flag hand-off and the chained filter launches need the two streams to run concurrently: probe it (a waiter on the filter stream, then the
       // setter on the bulk stream; the waiter gives up after 50 ms)
       int* dres = nullptr;
       CREATE_TRY(hipMalloc((void**)&dres, sizeof(int)));
@@ -648,7 +648,7 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
       int res = 0;
       CREATE_TRY(hipMemcpy(&res, dres, sizeof(int), hipMemcpyDeviceToHost));
       hipFree(dres);
-      h->chain_ok = res == 1;
+      h->streams_concurrent = res == 1;
     }
     const size_t flds = psmf::blk_filter_lds_bytes();
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_filter<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
