@@ -225,7 +225,7 @@ def main():
         # single block (psmf_time_kernel) is reported beside it.
         t_block_insitu = insitu["filter_us_mean"] if insitu and insitu["filter_launches"] > 0 else t_filter
         if chained[0] > 0:
-            kernel, kernel_us, steps_per_launch = "psmf_blk_filter3", 1e3 * chained[1] / chained[0], args.steps * T / chained[0]
+            kernel, kernel_us, steps_per_launch = "psmf_blk_filter3", 1e3 * chained[1] / chained[0], float(T)   # (at most 16 launches between two syncs are timed)
         else:
             full_blocks_only = (T % B == 0)
             kernel, kernel_us = "psmf_blk_filter3", t_block_insitu
