@@ -412,6 +412,42 @@ def test_split_runs_carry_the_state(robust):
     _compare(out[1][0], st, TOL["f64"])
 
 
+@pytest.mark.parametrize("r,T", [(32, 330), (20, 250)])
+def test_chained_blocks_one_launch_per_run(r, T):
+    """The blocked engine's default on a GPU box: the coefficient-space filter kernels of a run are ONE launch that hands over
+    from block to block inside the kernel (psmf_blk_filter3, BlockParams.chain) -- not a silent per-block or per-step fallback.
+    Counters: blocks = ceil(T / (64 - r)), launches = 1; the HIP-event timing of the launch is reported; results vs the oracle
+    (a short last block, r < 32 masks and the state carried into a second run included)."""
+    import os
+    if os.environ.get("PSMF_BLOCK_CHAIN") == "0" or os.environ.get("PSMF_BLOCK_FLAGS") == "0" or os.environ.get("PSMF_BLOCK_PIPE") == "0" \
+            or os.environ.get("PSMF_RESERVED_CUS") == "0" or os.environ.get("PSMF_FILTER3") == "0":
+        pytest.skip("a fallback was selected in the environment")
+    c = _capi()
+    d = 2048
+    Y, C0 = _problem(d, r, T, 4242 + r, "normal")
+    V0, P0, Q = 0.1 * np.eye(r), np.eye(r), 0.1 * np.eye(r)
+    f = c.DeviceFilter(d, r, storage="f64", engine="block")
+    f.upload_series(Y)
+    f.set_state(C0, V0, P0, Q, np.zeros(r), rho=1.0, lambda0=1.8)
+    f.counters(reset=True)
+    f.filter_kernel_time(reset=True)
+    T1 = T - 100
+    f.run(0, T1)
+    cnt = f.counters()
+    B = 64 - r
+    assert cnt["filter_launches"] == -(-T1 // B)
+    assert cnt["filter_kernel_launches"] == 1
+    n, ms = f.filter_kernel_time()
+    assert n == 1 and 0.0 < ms < 1e3
+    f.run(T1, T)                               # carried state, another chain
+    assert f.counters()["filter_kernel_launches"] == 2
+    s = f.get_state()
+    f.close()
+    st = O.State(C=C0, V=V0, mu=np.zeros(r), P=P0, Q=Q, rho=1.0, lam=1.8)
+    st, _, _ = O.run_epoch(st, Y, O.Mode(), O.RandomWalkDyn())
+    _compare(s, st, TOL["f64"])
+
+
 @pytest.mark.parametrize("fixed_lambda", [False, True])
 @pytest.mark.parametrize("d,r,T", [(1536, 32, 150), (1200, 20, 120), (900, 12, 110)])
 def test_rpsmf_scaling_factors_and_fixed_lambda(d, r, T, fixed_lambda, engine):
