@@ -964,7 +964,15 @@ int psmf_sync(psmf_handle h) {
   h->evk_pending = 0;
   if (g_host_timing) { const double t = host_now_ms(); if (t_s1 - t_s0 > 5.0) fprintf(stderr, "[psmf host timing] memcpyAsync call %.1f ms\n", t_s1 - t_s0); if (t - t_s1 > 5.0) fprintf(stderr, "[psmf host timing] spin wait %.1f ms\n", t - t_s1); }
   const int err = *h->err_host;
-  if (err == -7) return fail(h, PSMF_ERR_HIP, "pipelined blocks: a device-flag hand-off timed out (PSMF_BLOCK_FLAGS=0 selects event hand-off)");
+  if (err == -7) {
+    long long fl[8] = {0};
+    if (h->flags) (void)hipMemcpy(fl, h->flags, sizeof(fl), hipMemcpyDeviceToHost);
+    char msg[320];
+    snprintf(msg, sizeof(msg), "pipelined blocks: a device-flag hand-off timed out (PSMF_BLOCK_CHAIN=0: one filter launch per block; "
+             "PSMF_BLOCK_FLAGS=0: event hand-off); flags: cross-Gram %lld, filter %lld, next block to enqueue %lld",
+             fl[0], fl[1], h->seq_next);
+    return fail(h, PSMF_ERR_HIP, msg);
+  }
   if (err != 0) {
     char msg[128];
     snprintf(msg, sizeof(msg), "singular r x r system (I + kappa Pbar G) at step %d", err);
