@@ -133,6 +133,14 @@ int psmf_sq_error(psmf_handle h, int64_t t0, int64_t nt, double* out);
 #define PSMF_UNIQUE_ID_BYTES 128
 int psmf_comm_unique_id(void* id_out /* PSMF_UNIQUE_ID_BYTES */);
 int psmf_comm_init(psmf_handle h, int nranks, int rank, const void* unique_id);
+/* Host-mediated communicator instead of RCCL: wherever a sharded engine needs its sum-all-reduce (per-step engine: r + 1
+ * float64 per timestep; blocked engine: one 64 x 64 Gram per run and one 128 x 64 cross-Gram per block) the library copies
+ * the message to the host and calls fn(ctx, buf, count), which must replace buf[0..count) by its sum over all ranks -- same
+ * rank order on every rank, so that the replicated r x r state stays bit-identical -- and return 0.  For transports
+ * the caller owns (MPI, gloo) and for exercising the sharded arithmetic with several shards on ONE GPU (tests).  Each call
+ * synchronises the stream it sits on: correct, not fast.  (New: the reference is single-process, pypsmf/psmf/psmf.py:85-88.) */
+typedef int (*psmf_allreduce_fn)(void* ctx, double* buf, int64_t count);
+int psmf_comm_init_host(psmf_handle h, int nranks, int rank, psmf_allreduce_fn fn, void* ctx);
 
 /* ---- measurement ------------------------------------------------------------------------ */
 /* psmf_run bracketed by HIP events on the handle's stream; *ms = elapsed milliseconds. */
@@ -154,7 +162,7 @@ int psmf_geometry(psmf_handle h, int32_t* out7);
 int psmf_counters(psmf_handle h, int64_t* out8, int reset);
 /* Blocked engine with chained blocks (one launch of the coefficient-space filter kernel per psmf_run): number of such
  * launches completed since the last reset and the sum of their durations, measured with HIP events recorded around each
- * launch on the stream it runs on (at most 16 runs between two psmf_sync calls are timed).  Waits like psmf_sync.
+ * launch on the stream it runs on (at most 256 runs between two psmf_sync calls are timed).  Waits like psmf_sync.
  * (New: measurement aid for bench.py; the reference times whole runs with time.time(), ExperimentImpute/PSMF.py:59,91.) */
 int psmf_filter_kernel_time(psmf_handle h, int64_t* launches, double* total_ms, int reset);
 

@@ -41,6 +41,7 @@ class PsmfImputeConfig(C.Structure):
 
 _dp = C.POINTER(C.c_double)
 _u8p = C.POINTER(C.c_uint8)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, _dp, C.c_int64)   # psmf_allreduce_fn
 
 # name -> (restype, argtypes); every symbol include/psmf_hip.h declares
 SIGNATURES = {
@@ -61,6 +62,7 @@ SIGNATURES = {
     "psmf_sq_error": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, _dp]),
     "psmf_comm_unique_id": (C.c_int, [C.c_void_p]),
     "psmf_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "psmf_comm_init_host": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "psmf_run_timed": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.POINTER(C.c_float)]),
     "psmf_time_kernel": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "psmf_geometry": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
@@ -118,6 +120,12 @@ class DeviceFilter:
         self.row0 = int(row0)
         self.d_local = int(d if d_local is None else d_local)
         self.n_theta = self.r if dyn_kind == DYN_COS_PHASE else 0
+        if storage == "auto":
+            # f32 where the blocked engine runs (C is rounded once per block of 64 - r timesteps: errors ~1e-6);
+            # f64 where the per-step engine runs (one rounding of C per timestep would breach the 1e-5 bar around
+            # k = 300)
+            blocked = engine in ("auto", "block", 0, 2) and self.r <= 32 and not recursive and os.environ.get("PSMF_ENGINE") != "1"
+            storage = "f32" if blocked else "f64"
         self.storage = F64 if storage in ("f64", F64, np.float64) else F32
         self.store_y_pred = bool(store_y_pred)
         cfg = PsmfConfig(
@@ -280,6 +288,23 @@ class DeviceFilter:
     def comm_init(self, nranks, rank, unique_id):
         buf = C.create_string_buffer(bytes(unique_id), UNIQUE_ID_BYTES)
         self._check(self._lib.psmf_comm_init(self._h, int(nranks), int(rank), buf))
+
+    def comm_init_host(self, nranks, rank, allreduce):
+        """Host-mediated communicator: `allreduce(vec) -> vec` (numpy float64, same length) is called wherever the sharded
+        engine needs its sum over the ranks; it must return the same bits on every rank."""
+        def _cb(_ctx, buf, count):
+            try:
+                v = np.ctypeslib.as_array(buf, shape=(int(count),))
+                v[:] = allreduce(v.copy())
+                return 0
+            except Exception:          # no exception may cross the C boundary
+                import traceback
+
+                traceback.print_exc()
+                return 1
+
+        self._allreduce_cb = ALLREDUCE_FN(_cb)      # keep the trampoline alive as long as the handle
+        self._check(self._lib.psmf_comm_init_host(self._h, int(nranks), int(rank), C.cast(self._allreduce_cb, C.c_void_p), None))
 
 
 def device_count():

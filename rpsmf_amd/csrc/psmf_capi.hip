@@ -50,8 +50,9 @@ struct psmf_filter {
   hipStream_t fstream = nullptr;   // blocked engine, pipelined: the filter chain's own stream, pinned to reserved CUs (or nullptr)
   bool streams_concurrent = false;           // the filter stream's kernels run concurrently with the bulk stream's (probed at creation)
   // HIP-event timing of the chained filter launches (one per run): a ring of event pairs, read out at the next sync
-  static constexpr int kTimedRuns = 16;
+  static constexpr int kTimedRuns = 256;
   hipEvent_t evK0[kTimedRuns] = {}, evK1[kTimedRuns] = {};
+  hipEvent_t evC = nullptr;        // end of the chained filter launch: orders the handle's main stream (host reads of DevState) after it
   int evk_pending = 0;
   double kernel_ms_sum = 0.0;
   long long kernel_launches = 0;
@@ -83,6 +84,11 @@ struct psmf_filter {
   ncclComm_t comm = nullptr;
   int nranks = 1, rank = 0;
   bool use_coll = false;   // per-step all-reduce on (nranks > 1, or forced for single-GPU testing)
+  // host-mediated collective (psmf_comm_init_host): the sum-all-reduce goes through a caller-supplied function
+  psmf_allreduce_fn host_fn = nullptr;
+  void* host_ctx = nullptr;
+  double* host_buf = nullptr;      // pinned staging buffer, kHostBufElems doubles
+  static constexpr size_t kHostBufElems = 8192;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   int* err_host = nullptr;     // pinned, device-mapped: a one-thread kernel publishes the device error flag here
   int* err_host_dev = nullptr;
@@ -124,6 +130,22 @@ hipError_t spin_event(hipEvent_t ev) {
   hipError_t e;
   while ((e = hipEventQuery(ev)) == hipErrorNotReady) { __builtin_ia32_pause(); }
   return e;
+}
+
+// The one exchange of the sharded engines: in-place sum of `count` float64 on the device over all ranks.  RCCL on the given
+// stream, or -- host-mediated communicator -- device -> pinned host -> caller's function -> device, synchronously.
+int all_reduce_sum(psmf_filter* h, double* buf, size_t count, hipStream_t s) {
+  if (h->host_fn) {
+    if (count > psmf_filter::kHostBufElems) return fail(h, PSMF_ERR_ARG, "host all-reduce: message larger than the staging buffer");
+    HIP_TRY(h, hipMemcpyAsync(h->host_buf, buf, count * sizeof(double), hipMemcpyDeviceToHost, s));
+    HIP_TRY(h, spin_stream(s));
+    if (h->host_fn(h->host_ctx, h->host_buf, (int64_t)count) != 0) return fail(h, PSMF_ERR_RCCL, "host all-reduce callback reported a failure");
+    HIP_TRY(h, hipMemcpyAsync(buf, h->host_buf, count * sizeof(double), hipMemcpyHostToDevice, s));
+    HIP_TRY(h, spin_stream(s));        // the staging buffer is reused by the next call
+    return PSMF_OK;
+  }
+  NCCL_TRY(h, ncclAllReduce(buf, buf, count, ncclDouble, ncclSum, h->comm, s));
+  return PSMF_OK;
 }
 
 typedef void (*sweep_fn_t)(StepParams);
@@ -179,7 +201,8 @@ int enqueue_step(psmf_filter* h) {
   launch_sweep(h);
   if (h->use_coll) {
     hipLaunchKernelGGL(psmf::psmf_reduce_partials, dim3(1), dim3(psmf::WG), 0, h->stream, h->sp);
-    NCCL_TRY(h, ncclAllReduce(h->st->red, h->st->red, h->cfg.r + 1, ncclDouble, ncclSum, h->comm, h->stream));
+    const int rc = all_reduce_sum(h, h->st->red, h->cfg.r + 1, h->stream);
+    if (rc) return rc;
   }
   launch_serial(h, 0);
   return PSMF_OK;
@@ -312,8 +335,7 @@ int enqueue_block(psmf_filter* h, int64_t k0, int nb) {
   psmf::BlockParams b;
   fill_block_params(h, b, k0, nb);
   launch_blk_gram(h, b);
-  if (h->use_coll)
-    NCCL_TRY(h, ncclAllReduce(h->Kmat, h->Kmat, psmf::RB * psmf::RB, ncclDouble, ncclSum, h->comm, h->stream));
+  if (h->use_coll) { const int rc = all_reduce_sum(h, h->Kmat, psmf::RB * psmf::RB, h->stream); if (rc) return rc; }
   launch_blk_filter(h, b);
   launch_blk_apply(h, b);
   return PSMF_OK;
@@ -346,18 +368,17 @@ int enqueue_blocks_pipelined(psmf_filter* h, int64_t k_begin, int64_t k_end) {
   if (h->fstream) HIP_TRY(h, hipStreamWaitEvent(fs, h->evS, 0));
   psmf::BlockParams b;
   // hand-off by device flags when the filter chain has a stream (hardware queue) of its own; by events otherwise
-  static const bool flags_off = getenv("PSMF_BLOCK_FLAGS") && atoi(getenv("PSMF_BLOCK_FLAGS")) == 0;
+  const bool flags_off = getenv("PSMF_BLOCK_FLAGS") && atoi(getenv("PSMF_BLOCK_FLAGS")) == 0;
   const bool use_flags = h->fstream != nullptr && h->flags != nullptr && !flags_off && h->streams_concurrent;   // (a tool that serialises dispatches: events)
   const long long s0 = h->seq_next;
   h->seq_next += nblk;
   // chain: the filter kernels of the whole run as ONE launch (psmf_blk_filter3; the bulk stream is driven as before)
-  static const bool chain_off = getenv("PSMF_BLOCK_CHAIN") && atoi(getenv("PSMF_BLOCK_CHAIN")) == 0;
+  const bool chain_off = getenv("PSMF_BLOCK_CHAIN") && atoi(getenv("PSMF_BLOCK_CHAIN")) == 0;
   const bool chain = use_flags && !chain_off && nblk > 1 && blk_dual_ok(h) && h->geo.rpad == 32 && blk_use_filter3();
   // first block: plain Gram of the stored C
   fill_block_params(h, b, k0_of(0), nb_of(0), 0);
   launch_blk_gram(h, b, h->bulk);
-  if (h->use_coll)
-    NCCL_TRY(h, ncclAllReduce(h->Kmat, h->Kmat, psmf::RB * psmf::RB, ncclDouble, ncclSum, h->comm, h->bulk));
+  if (h->use_coll) { const int rc = all_reduce_sum(h, h->Kmat, psmf::RB * psmf::RB, h->bulk); if (rc) return rc; }
   if (use_flags) hipLaunchKernelGGL(psmf::psmf_flag_set_k, dim3(1), dim3(1), 0, h->bulk, h->flags + 0, s0);
   else HIP_TRY(h, hipEventRecord(h->evX[0], h->bulk));
   if (chain) {
@@ -376,6 +397,7 @@ int enqueue_blocks_pipelined(psmf_filter* h, int64_t k_begin, int64_t k_end) {
     if (slot_ev >= 0) HIP_TRY(h, hipEventRecord(h->evK0[slot_ev], fs));
     launch_blk_filter(h, c, fs);
     if (slot_ev >= 0) { HIP_TRY(h, hipEventRecord(h->evK1[slot_ev], fs)); ++h->evk_pending; }
+    HIP_TRY(h, hipEventRecord(h->evC, fs));
   }
   for (int64_t bi = 0; bi < nblk; ++bi) {
     const int slot = (int)(bi & 1);
@@ -387,7 +409,7 @@ int enqueue_blocks_pipelined(psmf_filter* h, int64_t k_begin, int64_t k_end) {
       x.nb1 = nb_of(bi + 1);
       double* xg = h->XG + (size_t)((bi + 1) & 1) * xg_elems;
       launch_blk_xgram(h, x, xg, h->bulk);
-      if (h->use_coll) NCCL_TRY(h, ncclAllReduce(xg, xg, xg_elems, ncclDouble, ncclSum, h->comm, h->bulk));
+      if (h->use_coll) { const int rc = all_reduce_sum(h, xg, xg_elems, h->bulk); if (rc) return rc; }
       if (use_flags) hipLaunchKernelGGL(psmf::psmf_flag_set_k, dim3(1), dim3(1), 0, h->bulk, h->flags + 0, s0 + bi + 1);
       else HIP_TRY(h, hipEventRecord(h->evX[(bi + 1) & 3], h->bulk));
     }
@@ -424,6 +446,9 @@ int enqueue_blocks_pipelined(psmf_filter* h, int64_t k_begin, int64_t k_end) {
       fprintf(stderr, "[psmf host timing] enqueue of %lld blocks took %.1f ms, slowest block's calls %.1f ms (block %lld)\n", (long long)nblk, t - t_enq0, t_worst, worst_blk);
   }
   HIP_TRY(h, hipStreamWaitEvent(h->stream, h->evA[(nblk - 1) & 3], 0));   // the main stream sees the final C / y_hat
+  // ... and the r x r state: the chained kernel writes DevState in its tail, after it has released the last apply, so the end of
+  // that launch (not the apply alone) is what host reads / the next run's preparation on the main stream have to follow
+  if (chain) HIP_TRY(h, hipStreamWaitEvent(h->stream, h->evC, 0));
   HIP_TRY(h, hipGetLastError());
   return PSMF_OK;
 }
@@ -439,8 +464,7 @@ int enqueue_gram(psmf_filter* h) {
                        (const float*)h->C, h->cfg.d_local, r, h->geo.rp, rows, h->gpart);
   hipLaunchKernelGGL(psmf::psmf_gram_reduce, dim3((r * r + 255) / 256), dim3(256), 0, h->stream,
                      (const double*)h->gpart, kGramWG, r * r, h->st->G);
-  if (h->use_coll)
-    NCCL_TRY(h, ncclAllReduce(h->st->G, h->st->G, r * r, ncclDouble, ncclSum, h->comm, h->stream));
+  if (h->use_coll) { const int rc = all_reduce_sum(h, h->st->G, (size_t)r * r, h->stream); if (rc) return rc; }
   return PSMF_OK;
 }
 
@@ -634,6 +658,7 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
       CREATE_TRY(hipEventCreateWithFlags(&h->evX[i], hipEventDisableTiming));
     }
     CREATE_TRY(hipEventCreateWithFlags(&h->evS, hipEventDisableTiming));
+    CREATE_TRY(hipEventCreateWithFlags(&h->evC, hipEventDisableTiming));
     for (int i = 0; i < psmf_filter::kTimedRuns; ++i) { CREATE_TRY(hipEventCreate(&h->evK0[i])); CREATE_TRY(hipEventCreate(&h->evK1[i])); }
     if (h->fstream && h->flags) {
       // the device-flag hand-off and the chained filter launches need the two streams to run concurrently: probe it (a waiter on the filter stream, then the
@@ -721,6 +746,8 @@ void psmf_destroy(psmf_handle h) {
   if (h->flags) hipFree(h->flags);
   for (int i = 0; i < 4; ++i) { if (h->evF[i]) hipEventDestroy(h->evF[i]); if (h->evA[i]) hipEventDestroy(h->evA[i]); if (h->evX[i]) hipEventDestroy(h->evX[i]); }
   if (h->evS) hipEventDestroy(h->evS);
+  if (h->evC) hipEventDestroy(h->evC);
+  if (h->host_buf) hipHostFree(h->host_buf);
   for (int i = 0; i < psmf_filter::kTimedRuns; ++i) { if (h->evK0[i]) hipEventDestroy(h->evK0[i]); if (h->evK1[i]) hipEventDestroy(h->evK1[i]); }
   if (h->bulk) { hipStreamSynchronize(h->bulk); hipStreamDestroy(h->bulk); }
   if (h->fstream) { hipStreamSynchronize(h->fstream); hipStreamDestroy(h->fstream); }
@@ -766,7 +793,8 @@ int psmf_set_state(psmf_handle h, const double* C, const double* V, const double
     HIP_TRY(h, hipMemcpy(h->st->theta, theta, h->cfg.n_theta * sizeof(double), hipMemcpyHostToDevice));
   if (!std::isnan(rho)) HIP_TRY(h, hipMemcpy(&h->st->rho, &rho, sizeof(double), hipMemcpyHostToDevice));
   if (!std::isnan(lambda0)) HIP_TRY(h, hipMemcpy(&h->st->lam, &lambda0, sizeof(double), hipMemcpyHostToDevice));
-  { const int zero = 0; HIP_TRY(h, hipMemcpy(&h->st->ns_valid, &zero, sizeof(int), hipMemcpyHostToDevice)); }
+  { const int zero = 0; HIP_TRY(h, hipMemcpy(&h->st->ns_valid, &zero, sizeof(int), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(&h->st->err, &zero, sizeof(int), hipMemcpyHostToDevice)); }   // a new state clears a sticky numeric error
   if (C && V && P && mu) h->have_state = true;
   h->need_prep = true;
   return PSMF_OK;
@@ -893,7 +921,7 @@ int psmf_run(psmf_handle h, int64_t k_begin, int64_t k_end) {
   }
   int64_t n = k_end - k_begin;
   if (h->engine == 2) {
-    static const bool pipe_off = getenv("PSMF_BLOCK_PIPE") && atoi(getenv("PSMF_BLOCK_PIPE")) == 0;
+    const bool pipe_off = getenv("PSMF_BLOCK_PIPE") && atoi(getenv("PSMF_BLOCK_PIPE")) == 0;
     if (!pipe_off && k_end - k_begin > h->block_steps) {
       rc = enqueue_blocks_pipelined(h, k_begin, k_end);
       if (rc) return rc;
@@ -919,7 +947,7 @@ int psmf_run(psmf_handle h, int64_t k_begin, int64_t k_end) {
       if (to_next < seg) seg = to_next;
     }
     int64_t left = seg;
-    if (h->cfg.use_graph) {
+    if (h->cfg.use_graph && !h->host_fn) {   // (a host-mediated all-reduce cannot be captured)
       const int want = 256;
       if (left >= want && h->chunk != want) {
         rc = build_graph(h, want);
@@ -1252,6 +1280,22 @@ int psmf_comm_init(psmf_handle h, int nranks, int rank, const void* unique_id) {
   return PSMF_OK;
 }
 
+int psmf_comm_init_host(psmf_handle h, int nranks, int rank, psmf_allreduce_fn fn, void* ctx) {
+  if (!h || !fn || nranks < 1 || rank < 0 || rank >= nranks) return fail(h, PSMF_ERR_ARG, "psmf_comm_init_host: bad argument");
+  if (h->comm) return fail(h, PSMF_ERR_STATE, "psmf_comm_init_host: the handle already has an RCCL communicator");
+  int rc = set_device(h);
+  if (rc) return rc;
+  if (!h->host_buf) HIP_TRY(h, hipHostMalloc((void**)&h->host_buf, psmf_filter::kHostBufElems * sizeof(double), hipHostMallocDefault));
+  h->host_fn = fn;
+  h->host_ctx = ctx;
+  h->nranks = nranks;
+  h->rank = rank;
+  h->use_coll = true;               // also with one rank: the exchange path is what this communicator exists to exercise
+  h->sp.external_reduce = 1;
+  destroy_graph(h);
+  h->need_prep = true;
+  return PSMF_OK;
+}
 
 }  // extern "C"
 

@@ -39,8 +39,9 @@ template <typename T> struct VecOf;
 template <> struct VecOf<float> { typedef float __attribute__((ext_vector_type(4))) type; };
 template <> struct VecOf<double> { typedef double __attribute__((ext_vector_type(2))) type; };
 
-// start of a run: step counter, error flag
-__global__ void psmf_prepare_k(DevState* st, long long k) { st->k = k; st->err = 0; }
+// start of a run: step counter.  The numeric-error flag is NOT cleared here: runs may be queued back to back without a
+// sync in between, and a failure in an earlier one must still be reported by the next psmf_sync (cleared by psmf_set_state).
+__global__ void psmf_prepare_k(DevState* st, long long k) { st->k = k; }
 // end of a run: the numeric-error flag to mapped host memory (system-scope store)
 __global__ void psmf_publish_err_k(const DevState* st, int* host_flag) { __hip_atomic_store(host_flag, st->err, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 

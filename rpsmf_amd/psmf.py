@@ -43,6 +43,15 @@ HIP_MODES = {
     "full": (True, True, True),
     "simplified": (False, False, False),
 }
+# compute hooks a class may override under each declared mode (the overrides ARE the mode: synthetic_psmf.py:82-98,
+# synthetic_rpsmf.py:86-114); anything else would be skipped silently by the fused device loop
+HIP_MODE_HOOKS = {
+    "full": frozenset(),
+    "simplified": frozenset({"_predictive_covariance", "_compute_eta_k", "_compute_inverse_coefficient_innovation",
+                             "_update_coefficient_mean", "_update_coefficient_covariance"}),
+}
+# drive-level methods the fused loop replaces as a whole
+FUSED_METHODS = ("inner", "_store_gradient", "_set_gradient", "_reset_gradient", "_carry_theta")
 
 
 class _Lazy:
@@ -110,18 +119,32 @@ class _YPred(dict):
 
 
 def _diag_of(R, d):
-    """diag(R) as scalar or (d,) vector, or None if R is a non-diagonal matrix."""
+    """diag(R) as scalar or (d,) vector, or None if R is a non-diagonal d x d matrix.  Accepted shapes: scalar, (1,),
+    (1, 1), (d,), (d, 1), (1, d), (d, d); anything else raises (a silently broadcast R would give wrong numbers)."""
     if np.ndim(R) == 0:
         return float(R)
     R = np.asarray(R)
-    if R.ndim == 1:
-        return R.astype(float)
-    if R.shape == (1, 1):
-        return float(R[0, 0])
+    if R.size == 1:
+        return float(R.reshape(()))
+    if R.shape in ((d,), (d, 1), (1, d)):
+        return R.reshape(-1).astype(float)
+    if R.shape != (d, d):
+        raise ValueError(f"R has shape {R.shape}: expected a scalar, a (d,) diagonal or a (d, d) matrix with d = {d}")
     dg = np.diagonal(R)
     if np.count_nonzero(R) != np.count_nonzero(dg):
         return None
     return dg.astype(float)
+
+
+def _content_hash(a):
+    try:
+        import xxhash
+
+        return xxhash.xxh3_128_hexdigest(a.data)
+    except ImportError:
+        import hashlib
+
+        return hashlib.blake2b(a.data, digest_size=16).hexdigest()
 
 
 def _as_scalar_if_uniform(rho):
@@ -138,7 +161,7 @@ class PSMFIter:
     robust = False
 
     def __init__(self, theta0, C0, V0, mu0, P0, Qs, Rs, nonlinearity, optim="adam", backend="hip",
-                 device=0, storage="f32", gram_refresh=0, engine="auto"):
+                 device=0, storage="auto", gram_refresh=0, engine="auto"):
         assert optim in ["adam", "sgd"]
         if backend not in ("hip", "numpy"):
             raise ValueError("backend must be 'hip' or 'numpy'")
@@ -195,7 +218,7 @@ class PSMFIter:
             return self._step_hip(y, i, T)
         self.step_reset()
         for k in range(1, T + 1):
-            self.inner(i, k, y[k])
+            self.inner(i, k, np.asarray(y[k]).reshape(-1, 1))     # y[k], k = 1..T: dict or array-like (row 0 unused)
 
     def inner(self, i, k, yk):
         mu_bar = self._predictive_mean(i, k)
@@ -343,6 +366,14 @@ class PSMFIter:
         base = rPSMF_BASE if self.robust else PSMFIter
         return [h for h in COMPUTE_HOOKS if getattr(type(self), h) is not getattr(base, h)]
 
+    def _overrides(self, name):
+        """True if the class replaces `name` of the library class it derives from (PSMFIter / PSMFRecursive / rPSMF*)."""
+        mine = getattr(type(self), name, None)
+        for base in type(self).__mro__:
+            if base in _BASE_CLASSES and base is not object and name in vars(base):
+                return mine is not vars(base)[name]
+        return False
+
     def _check_hip_configuration(self):
         over = self._overridden_hooks()
         declared = any("hip_mode" in vars(c) for c in type(self).__mro__ if c not in _BASE_CLASSES)
@@ -353,6 +384,16 @@ class PSMFIter:
                 "match one, or construct with backend='numpy'.")
         if self.hip_mode not in HIP_MODES:
             raise ValueError(f"unknown hip_mode {self.hip_mode!r}")
+        extra = sorted(set(over) - HIP_MODE_HOOKS[self.hip_mode])
+        if extra:
+            raise TypeError(
+                f"{type(self).__name__} declares hip_mode={self.hip_mode!r} but also overrides {extra}, which that mode "
+                "does not cover: the fused device loop would skip them.  Use backend='numpy'.")
+        lost = [m for m in FUSED_METHODS if m not in COMPUTE_HOOKS and self._overrides(m)]
+        if lost:
+            raise TypeError(
+                f"{type(self).__name__} overrides {lost}: with backend='hip' the whole time loop runs on the device and "
+                "these methods are never called.  Use backend='numpy'.")
         if self._nl.device_kind is None:
             raise TypeError(
                 "the nonlinearity is not one the device evaluates (RandomWalk, CosPhase); wrap it in one of those "
@@ -399,13 +440,20 @@ class PSMFIter:
         raise KeyError(name)
 
     def _upload_series(self, y, T):
-        key = (id(y), T)
-        if self._series_key == key:
-            return
+        """y[k], k = 1..T, onto the device -- dict {k: (d, 1)} as in the reference, or any array-like indexed the same way
+        (row 0 unused), exactly what the numpy back end reads.  The resident copy is reused only if the CONTENT is
+        unchanged (a checksum of the T observations; object identity says nothing: ids are recycled and containers are
+        refilled in place)."""
         if isinstance(y, dict):
             Y = np.concatenate([np.asarray(y[k]).reshape(1, -1) for k in range(1, T + 1)], axis=0)
         else:
-            Y = np.asarray(y)[:T]
+            Y = np.asarray(y)[1:T + 1].reshape(T, -1)
+        if Y.shape != (T, self._d):
+            raise ValueError(f"series: expected {T} observations of length {self._d}, got an array of shape {Y.shape}")
+        Y = np.ascontiguousarray(Y)
+        key = (T, Y.dtype.str, _content_hash(Y))
+        if self._series_key == key:
+            return
         self._dev.upload_series(Y, t0=0, T_total=T)
         self._series_key = key
 
@@ -496,7 +544,7 @@ class PSMFRecursive(PSMFIter):
             return self._step_hip_recursive(y, T)
         self.step_reset()
         for k in range(1, T + 1):
-            self.inner(k, y[k])
+            self.inner(k, np.asarray(y[k]).reshape(-1, 1))
 
     def inner(self, k, yk):
         mu_bar = self._predictive_mean(k, k)

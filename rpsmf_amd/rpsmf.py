@@ -68,14 +68,14 @@ class rPSMFIter(PSMFIter):
         lam = self._lambda[k - 1]
         w = self._V[k - 1] @ mu_bar
         e = yk - self._y_pred[k]
-        phi_k = lam / (lam + self._d) + (e.T @ e) / ((lam + self._d) * Nk)
+        phi_k = float(np.squeeze(lam / (lam + self._d) + (e.T @ e) / ((lam + self._d) * Nk)))
         self._V[k] = self._alpha * phi_k * (self._V[k - 1] - (w @ w.T) / Nk)
 
     def _update_coefficient_covariance(self, k, Skinv, P_bar, yk):
         lam = self._lambda[k - 1]
         C = self._C[k - 1]
         e = yk - self._y_pred[k]
-        omega_k = (lam + e.T @ (Skinv @ e)) / (lam + self._d)
+        omega_k = float(np.squeeze(lam + e.T @ (Skinv @ e))) / (lam + self._d)    # a Python float: R, Q may be scalars / vectors
         self._P[k] = self._beta * omega_k * (P_bar - P_bar @ (C.T @ (Skinv @ C)) @ P_bar)
         self._Q[k] = omega_k * self._Q[k - 1]
         self._R[k] = omega_k * self._R[k - 1]

@@ -306,6 +306,30 @@ def case_recursive(robust, seed, d=10, r=3, T=60, n_pred=10):
 
 
 # ---------------------------------------------------------------- cases: ExperimentImpute
+def case_scaling(seed=16, d=20, r=5, T=30):
+    """rPSMFIter(use_scaling=True): alpha, beta from the reference's mpmath KL minimisation (rpsmf.py:45-51,75-104) at
+    (d, r) = (20, 5) and a few other (dim, offset, lambda0) triples, and a short run with the factors applied."""
+    rng = np.random.default_rng(seed)
+    Y = rng.standard_normal((T, d)) + rng.standard_normal((T, 1))
+    C0 = 0.1 * rng.standard_normal((d, r))
+    V0, P0, Q = 0.1 * np.eye(r), np.eye(r), 0.1 * np.eye(r)
+    mu0 = np.zeros((r, 1))
+    obj = refpkg.rPSMFIter(np.zeros((0, 1)), C0, V0, mu0, P0, Q, np.eye(d), 1.8, RandomWalk(), use_scaling=True)
+    out = dict(Y=Y, C0=C0, V0=V0, mu0=mu0.reshape(-1), P0=P0, Q=Q, rho=1.0, lambda0=1.8,
+               alpha=float(obj._alpha), beta=float(obj._beta))
+    triples, vals = [], []
+    for lam0, dim, off in ((1.8, r * d, d), (1.8, r, d), (3.0, 12, 7), (10.0, 4, 50), (2.5, 300, 30)):
+        o = refpkg.rPSMFIter(np.zeros((0, 1)), C0, V0, mu0, P0, Q, np.eye(d), lam0, RandomWalk())
+        triples.append((lam0, dim, off))
+        vals.append(o.compute_scaling_factor(dim, off))
+    out["scaling_triples"] = np.array(triples)
+    out["scaling_values"] = np.array(vals)
+    obj.optim_init()
+    obj.step(ydict(Y), 1, T)
+    out.update(C_T=obj._C[T], V_T=obj._V[T], mu_T=obj._mu[T].reshape(-1), P_T=obj._P[T], y_pred=ypred_arr(obj, T))
+    return out
+
+
 def _impute_modules():
     sys.path.insert(0, os.path.join(REF, "ExperimentImpute"))
     cwd = os.getcwd()
@@ -400,6 +424,7 @@ def main():
         "psmf_full_fourier": lambda: case_fourier(13),
         "psmf_recursive": lambda: case_recursive(False, 14),
         "rpsmf_recursive": lambda: case_recursive(True, 15),
+        "rpsmf_scaling": case_scaling,
         "impute_synth": case_impute_synth,
         "impute_kat_pm25": case_impute_kat,
         "impute_baselines": case_impute_baselines,

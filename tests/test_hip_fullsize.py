@@ -1,0 +1,158 @@
+"""Parity at BASELINE.json's full sizes and horizons (configs B, C, D and the single-GPU shard of E), through the C ABI,
+against the CPU oracle.  GPU only: `pytest -m gpu`.  Sized so that the oracle legs take about five minutes in all on the
+GPU box's host cores (the oracle is numpy float64, O(d r^2) per timestep).
+
+Why these exist: the f32-storage error of the recursion peaks around k = 300 and plateaus only after k = 500-2000
+(SURVEY section 0), and the Newton-Schulz starts of the blocked engine are carried over hundreds of blocks -- short
+series cannot show either.  Tolerance: BASELINE.json north_star, 1e-5 relative (max-abs over max-abs), f32 storage.
+"""
+
+import numpy as np
+import pytest
+
+from conftest import relerr
+from oracle import psmf_oracle as O
+from oracle.impute_oracle import impute_filter
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+def _capi():
+    from rpsmf_amd import _capi
+
+    return _capi
+
+
+def _bench_problem(d, r, T, robust):
+    """The synthetic workload of bench.py / SURVEY 8(d): data.py semantics, C0 = 0.1 randn, V0 = 0.1 I, P0 = I, Q = 0.1 I,
+    R = I, mu0 = 0, seeds of the reference Makefile (35853 PSMF, 35833 rPSMF with lambda0 = 1.8, Student-t noise dof 3)."""
+    seed = 35833 if robust else 35853
+    Y = O.synthetic_series(d, r, T, seed, noise="t" if robust else "normal", dtype=np.float32)
+    rng = np.random.default_rng(seed + 7)
+    C0 = (0.1 * rng.standard_normal((d, r))).astype(np.float32).astype(np.float64)
+    return Y, C0
+
+
+def _checkpointed_parity(d, r, T, robust, checkpoints, engine="auto", storage="f32", tol=TOL):
+    c = _capi()
+    Y, C0 = _bench_problem(d, r, T, robust)
+    V0, P0, Q = 0.1 * np.eye(r), np.eye(r), 0.1 * np.eye(r)
+    mode = O.Mode(robust=robust)
+    st = O.State(C=C0, V=V0, mu=np.zeros(r), P=P0, Q=Q, rho=1.0, lam=1.8)
+    st, Yp, trace = O.run_epoch(st, Y.astype(np.float64), mode, O.RandomWalkDyn(), keep=checkpoints, want_grad=False)
+    f = c.DeviceFilter(d, r, robust=robust, storage=storage, engine=engine)
+    f.upload_series(Y)
+    f.set_state(C0, V0, P0, Q, np.zeros(r), rho=1.0, lambda0=1.8)
+    worst = {}
+    k_prev = 0
+    for k in checkpoints:
+        f.run(k_prev, k)
+        k_prev = k
+        s = f.get_state()
+        ref = trace[k][0]
+        for name in ("C", "V", "mu", "P"):
+            e = relerr(s[name], getattr(ref, name))
+            worst[name] = max(worst.get(name, 0.0), e)
+            assert e < tol, (name, k, e)
+        if robust:
+            assert relerr(s["rho"], ref.rho) < tol and relerr(s["lam"], ref.lam) < 1e-12
+    e = relerr(f.y_pred(0, T), Yp)
+    assert e < tol, ("y_pred", e)
+    geo = f.geometry()
+    f.close()
+    return worst, geo
+
+
+@pytest.mark.parametrize("robust", [False, True], ids=["configB_PSMF", "configC_rPSMF"])
+def test_config_B_C_full_size(robust):
+    """BASELINE configs B / C: d = 10 000, r = 20, T = 5 000, f32 storage, the engine the library selects by itself,
+    checked at k = 300 (the transient's peak), 1 000 and 5 000 (psmf.py:85-102, rpsmf.py:116-184)."""
+    worst, geo = _checkpointed_parity(10_000, 20, 5_000, robust, (300, 1000, 5000))
+    assert geo["engine"] == "block"
+    print("config", "C" if robust else "B", "worst rel-err:", worst)
+
+
+def test_config_E_single_gpu_shard_size():
+    """BASELINE config E at the size one GPU holds when N = 1: d = 100 000, r = 32, first 1 000 of the 10 000 timesteps
+    (the oracle needs ~0.14 s per timestep at this size), f32 storage, chained blocked engine."""
+    worst, geo = _checkpointed_parity(100_000, 32, 1_000, False, (300, 1000))
+    assert geo["engine"] == "block" and geo["block_steps"] == 32
+    print("config E (1 GPU) worst rel-err:", worst)
+
+
+def test_per_step_engine_tolerance_r40():
+    """r > 32 runs on the per-step engine (one rounding of C per timestep with f32 storage would breach 1e-5 around
+    k = 300: DESIGN section 5), so the library stores C in float64 there.  d = 20 000, r = 40, T = 1 000."""
+    c = _capi()
+    d, r, T = 20_000, 40, 1_000
+    worst, geo = _checkpointed_parity(d, r, T, False, (300, 1000), storage="auto")
+    assert geo["engine"] in ("step", "block")
+    print("r = 40 worst rel-err:", worst)
+
+
+# ----------------------------------------------------------------------------- config D
+def _gas_sensor_standin(d, n, seed=20160930):
+    """Synthetic stand-in of the gas-sensor array (the CSV is not in the reference checkout, .MISSING_LARGE_BLOBS):
+    smooth random-walk channels + 1 % native NaN, as tools/bench_impute.py and SURVEY 8(d)."""
+    rng = np.random.default_rng(seed)
+    Yorig = np.cumsum(0.05 * rng.standard_normal((d, n)), axis=1) + 10.0 * rng.random((d, 1))
+    Yorig[rng.random((d, n)) < 0.01] = np.nan
+    return Yorig
+
+
+def _draw(Yorig, r, seeds):
+    from rpsmf_amd import impute_harness as H
+
+    np.random.seed(123)
+    M, Mm, C0, X0 = [], [], [], []
+    for _ in range(seeds):
+        p = H.draw_problem(Yorig, 40, r)
+        M.append(p["M"].astype(np.uint8))
+        Mm.append(p["Mmiss"].astype(np.uint8))
+        C0.append(p["C"])
+        X0.append(p["X"])
+    return np.stack(M), np.stack(Mm), np.stack(C0), np.stack(X0)
+
+
+@pytest.mark.parametrize("robust", [False, True], ids=["PSMF", "rPSMF"])
+def test_config_D_full_length_seed_vs_oracle(robust):
+    """BASELINE config D, one seed at full length: 19 x 295 719, r = 10, Iter = 2, 40 % missing
+    (ExperimentImpute/PSMF.py:59-93, rPSMF.py:75-135): 591 438 sequential masked steps against the oracle."""
+    from rpsmf_amd import impute
+
+    d, n, r = 19, 295_719, 10
+    Yorig = _gas_sensor_standin(d, n)
+    Yint = np.nan_to_num(Yorig, nan=0.0)
+    M, Mm, C0, X0 = _draw(Yorig, r, 1)
+    V, Q, P = 2 * np.eye(r), 0.1 * np.eye(r), np.eye(r)
+    Xo = X0[0].copy()
+    ep, ef, ib, st = impute_filter(Yint * M[0], C0[0], Xo, M[0], Mm[0].astype(float), V, Q, 10.0, P, 2, 2, Yint, 0.0,
+                                   robust=robust, lambda0=1.8, return_state=True)
+    res = impute.impute_batch(Yint, M, Mm, C0, X0, V, Q, 10.0, P, 2, 2, robust=robust, lambda0=1.8)
+    # float64 on both sides; 6e5 sequential steps of a contracting filter: agreement stays at round-off level
+    assert relerr(res["Epred"][0], ep[0, 1:]) < 1e-8 and relerr(res["Efull"][0], ef[0, 1:]) < 1e-8
+    assert abs(res["inside"][0] - ib) < 1e-9
+    assert relerr(res["C"][0], st["C"]) < 1e-7 and relerr(res["X"][0], st["X"]) < 1e-7
+
+
+def test_config_D_fifty_seed_batch_equals_single_runs():
+    """The 50-seed batch (one launch, one workgroup per replica) against the same replicas run one by one: every replica of
+    a 20 000-column prefix, and three replicas (first, middle, last) of the full-length batch.  Replicas are independent,
+    the arithmetic per replica is the same code: bit-identical."""
+    from rpsmf_amd import impute
+
+    d, r, seeds = 19, 10, 50
+    V, Q, P = 2 * np.eye(r), 0.1 * np.eye(r), np.eye(r)
+    for n, singles in ((20_000, range(seeds)), (295_719, (0, 24, 49))):
+        Yorig = _gas_sensor_standin(d, n)
+        Yint = np.nan_to_num(Yorig, nan=0.0)
+        M, Mm, C0, X0 = _draw(Yorig, r, seeds)
+        res = impute.impute_batch(Yint, M, Mm, C0, X0, V, Q, 10.0, P, 2, 2, robust=False)
+        assert np.all(np.isfinite(res["Epred"])) and np.all(np.isfinite(res["Efull"]))
+        assert len(set(np.round(res["Epred"][:, -1], 12))) == seeds      # 50 different problems, 50 different answers
+        for i in singles:
+            one = impute.impute_batch(Yint, M[i], Mm[i], C0[i], X0[i], V, Q, 10.0, P, 2, 2, robust=False)
+            for k in ("Epred", "Efull", "inside", "C", "X"):
+                assert np.array_equal(one[k][0], res[k][i]), (n, i, k)

@@ -49,6 +49,24 @@ def test_classes_full_filter_on_device(name, robust):
     assert relerr(f.sq_errors(T), np.sum((g["y_pred_e2"] - Y) ** 2)) < 1e-9
 
 
+def test_use_scaling_on_device_vs_reference_run():
+    """rPSMFIter(use_scaling=True): alpha, beta computed as the reference computes them and applied in the device loop
+    (rpsmf.py:45-51,133-171), against the reference's own run."""
+    g = load_golden("rpsmf_scaling")
+    Y = g["Y"]
+    T, d = Y.shape
+    r = g["C0"].shape[1]
+    f = psmf.rPSMFIter(np.zeros((0, 1)), g["C0"], g["V0"], g["mu0"].reshape(-1, 1), g["P0"], g["Q"], np.eye(d), 1.8,
+                       psmf.RandomWalk(), use_scaling=True, storage="f64")
+    assert abs(f._alpha - float(g["alpha"])) < 1e-12 and abs(f._beta - float(g["beta"])) < 1e-12
+    f.optim_init()
+    f.step(ydict(Y), 1, T)
+    assert relerr(f._C[T], g["C_T"]) < 1e-9 and relerr(f._V[T], g["V_T"]) < 1e-9
+    assert relerr(f._mu[T], g["mu_T"].reshape(-1, 1)) < 1e-9 and relerr(f._P[T], g["P_T"]) < 1e-9
+    yp = np.array([f._y_pred[k].reshape(-1) for k in range(1, T + 1)])
+    assert relerr(yp, g["y_pred"]) < 1e-9
+
+
 @pytest.mark.parametrize("storage,tol", [("f64", 1e-6), ("f32", 1e-5)])
 @pytest.mark.parametrize("name,robust", [("psmf_simplified_cos", False), ("rpsmf_simplified_cos", True)])
 def test_experiment_synthetic_on_device(name, robust, storage, tol):

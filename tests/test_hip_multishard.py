@@ -1,0 +1,176 @@
+"""Several row shards of ONE filter on ONE GPU ("fake collective"): every shard is its own handle with
+its own (row0, d_local) and streams, driven from its own host thread, and the sum-all-reduce of the sharded engines goes
+through a host-mediated communicator (psmf_comm_init_host) that adds the shards' messages in rank order.  This exercises
+what a one-rank RCCL communicator cannot: the first-block Gram, the per-block cross-Gram, the tracked Gram and eta with
+the GLOBAL d when each shard sees only part of the rows.  GPU only: `pytest -m gpu`.
+
+Asserted: gathered C and y_hat equal the unsharded run of the same engine (1e-11 with f64 storage; f32 storage: both are
+within 1e-5 of the oracle and within 2e-6 of each other -- the shard boundaries change the summation order of the Gram);
+the replicated V, P, mu, rho, lambda are BIT-IDENTICAL across shards; everything agrees with the CPU oracle.
+"""
+
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import relerr
+from oracle import psmf_oracle as O
+from rpsmf_amd.sharding import shard_rows
+
+pytestmark = pytest.mark.gpu
+
+
+def _capi():
+    from rpsmf_amd import _capi
+
+    return _capi
+
+
+class HostGroup:
+    """In-process stand-in of a communicator: `nranks` threads, sum in rank order, same bits for everybody."""
+
+    def __init__(self, nranks, timeout=120.0):
+        self.n = nranks
+        self.slots = [None] * nranks
+        self.barrier = threading.Barrier(nranks)
+        self.timeout = timeout
+        self.calls = [0] * nranks
+        self.sizes = []
+
+    def allreduce(self, rank):
+        def f(v):
+            self.slots[rank] = v
+            self.barrier.wait(self.timeout)
+            tot = self.slots[0].copy()
+            for i in range(1, self.n):
+                assert self.slots[i].shape == tot.shape
+                tot += self.slots[i]
+            if rank == 0:
+                self.sizes.append(tot.size)
+            self.calls[rank] += 1
+            self.barrier.wait(self.timeout)
+            return tot
+        return f
+
+
+def _run(c, nshards, d, r, Y, C0, st0, T, *, engine, storage, robust, env=None):
+    """nshards = 0: plain unsharded handle.  Returns (per-shard get_state dicts, per-shard y_pred, group)."""
+    old = {k: os.environ.get(k) for k in (env or {})}
+    os.environ.update(env or {})
+    try:
+        kw = dict(storage=storage, engine=engine, robust=robust)
+        if nshards == 0:
+            f = c.DeviceFilter(d, r, **kw)
+            f.upload_series(Y)
+            f.set_state(C0, *st0, rho=1.0, lambda0=1.8)
+            f.run(0, T // 2)                    # the same two runs as the shards (same block boundaries)
+            f.run(T // 2, T)
+            out = [f.get_state()], [f.y_pred(0, T)], None
+            f.close()
+            return out
+        grp = HostGroup(nshards)
+        states, yps, errs = [None] * nshards, [None] * nshards, []
+
+        def worker(rank):
+            try:
+                row0, dl = shard_rows(d, nshards, rank)
+                f = c.DeviceFilter(d, r, row0=row0, d_local=dl, **kw)
+                f.comm_init_host(nshards, rank, grp.allreduce(rank))
+                f.upload_series(np.ascontiguousarray(Y[:, row0:row0 + dl]))
+                f.set_state(C0[row0:row0 + dl], *st0, rho=1.0, lambda0=1.8)
+                f.run(0, T // 2)                # two runs: the state carried between runs is sharded state too
+                f.run(T // 2, T)
+                states[rank] = f.get_state()
+                yps[rank] = f.y_pred(0, T)
+                f.close()
+            except BaseException as e:          # noqa: BLE001 -- reported by the main thread
+                errs.append((rank, e))
+                grp.barrier.abort()
+
+        threads = [threading.Thread(target=worker, args=(k,)) for k in range(nshards)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(600)
+        assert not errs, errs
+        return states, yps, grp
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+CASES = [
+    # engine, storage, d, r, T, nshards, env
+    ("block", "f64", 3001, 32, 150, 2, None),                       # chained filter3, general MFMA bulk kernels, uneven shards
+    ("block", "f64", 3001, 32, 150, 3, None),
+    ("block", "f32", 4096, 32, 200, 2, None),                       # the bench.py path: filter3 chain + streaming bulk kernels
+    ("block", "f32", 6000, 20, 180, 3, None),                       # r < 32: three column tiles, 44-step blocks
+    ("block", "f64", 1500, 12, 130, 2, None),                       # two-halves filter kernel (r <= 16), per-block launches
+    ("block", "f64", 2000, 32, 100, 2, {"PSMF_BLOCK_PIPE": "0"}),    # one block after the other: all-reduce of K per block
+    ("block", "f64", 2000, 32, 140, 2, {"PSMF_BLOCK_FLAGS": "0"}),   # event hand-off instead of device flags
+    ("step", "f64", 1001, 9, 60, 2, None),                          # per-step engine: r + 1 doubles per timestep
+    ("step", "f64", 900, 40, 40, 3, None),                          # r > 32
+]
+
+
+@pytest.mark.parametrize("robust", [False, True], ids=["PSMF", "rPSMF"])
+@pytest.mark.parametrize("engine,storage,d,r,T,nshards,env", CASES)
+def test_shards_on_one_gpu_equal_unsharded(engine, storage, d, r, T, nshards, env, robust):
+    c = _capi()
+    Y = O.synthetic_series(d, r, T, 900 + d + r, noise="t" if robust else "normal", dtype=np.float64)
+    rng = np.random.default_rng(d + r)
+    C0 = 0.1 * rng.standard_normal((d, r))
+    if storage == "f32":
+        Y = Y.astype(np.float32).astype(np.float64)
+        C0 = C0.astype(np.float32).astype(np.float64)
+    st0 = (0.1 * np.eye(r), np.eye(r), 0.1 * np.eye(r), np.zeros(r))      # V, P, Q, mu
+    ref_s, ref_y, _ = _run(c, 0, d, r, Y, C0, st0, T, engine=engine, storage=storage, robust=robust, env=env)
+    sh_s, sh_y, grp = _run(c, nshards, d, r, Y, C0, st0, T, engine=engine, storage=storage, robust=robust, env=env)
+    assert all(n == grp.calls[0] for n in grp.calls) and grp.calls[0] > 0
+    # replicated state: bit-identical across shards
+    for k in ("V", "P", "mu", "Q", "rho", "lam"):
+        for s in sh_s[1:]:
+            assert np.array_equal(np.asarray(s[k]), np.asarray(sh_s[0][k])), k
+    C = np.vstack([s["C"] for s in sh_s])
+    Yp = np.hstack(sh_y)
+    tol = 1e-11 if storage == "f64" else 2e-6
+    assert relerr(C, ref_s[0]["C"]) < tol and relerr(Yp, ref_y[0]) < tol
+    for k in ("V", "P", "mu", "rho"):
+        assert relerr(sh_s[0][k], ref_s[0][k]) < tol, k
+    assert sh_s[0]["lam"] == ref_s[0]["lam"]
+    # and the oracle
+    st = O.State(C=C0, V=st0[0], mu=st0[3], P=st0[1], Q=st0[2], rho=1.0, lam=1.8)
+    st, Ypo, _ = O.run_epoch(st, Y, O.Mode(robust=robust), O.RandomWalkDyn(), want_grad=False)
+    otol = 1e-9 if storage == "f64" else 1e-5
+    assert relerr(C, st.C) < otol and relerr(Yp, Ypo) < otol
+    for k in ("V", "P", "mu"):
+        assert relerr(sh_s[0][k], getattr(st, k)) < otol, k
+    if engine == "block" and not (env or {}).get("PSMF_BLOCK_PIPE") == "0":
+        B = 64 - r
+        # pipelined: per run one first-block Gram (64 x 64) and one cross-Gram (128 x 64) per further block
+        assert set(grp.sizes) <= {64 * 64, 128 * 64}
+
+
+def test_missing_reduction_would_be_caught():
+    """The test above is only worth something if a shard that skips the exchange gives a different answer: run the
+    shards with an identity 'all-reduce' and check that the result is wrong."""
+    c = _capi()
+    d, r, T = 2000, 32, 100
+    Y = O.synthetic_series(d, r, T, 31, dtype=np.float64)
+    C0 = 0.1 * np.random.default_rng(1).standard_normal((d, r))
+    st0 = (0.1 * np.eye(r), np.eye(r), 0.1 * np.eye(r), np.zeros(r))
+    ref_s, _, _ = _run(c, 0, d, r, Y, C0, st0, T, engine="block", storage="f64", robust=False)
+    row0, dl = shard_rows(d, 2, 0)
+    f = c.DeviceFilter(d, r, row0=row0, d_local=dl, storage="f64", engine="block")
+    f.comm_init_host(2, 0, lambda v: v)
+    f.upload_series(np.ascontiguousarray(Y[:, :dl]))
+    f.set_state(C0[:dl], *st0, rho=1.0, lambda0=1.8)
+    f.run(0, T)
+    s = f.get_state()
+    f.close()
+    assert relerr(s["P"], ref_s[0]["P"]) > 1e-3

@@ -173,6 +173,66 @@ def test_scalar_and_vector_R_equal_dense_R():
         assert relerr(a, b) < 1e-12
 
 
+def test_compute_scaling_factor_matches_reference():
+    """rPSMFIter.compute_scaling_factor / use_scaling (rpsmf.py:45-51,75-104) against the reference's own values, and a run
+    with the factors applied (numpy back end) against the reference's run."""
+    g = load_golden("rpsmf_scaling")
+    Y = g["Y"]
+    T, d = Y.shape
+    r = g["C0"].shape[1]
+    mk = lambda lam0, **kw: psmf.rPSMFIter(np.zeros((0, 1)), g["C0"], g["V0"], g["mu0"].reshape(-1, 1), g["P0"], g["Q"],
+                                           np.eye(d), lam0, psmf.RandomWalk(), backend="numpy", **kw)
+    for (lam0, dim, off), ref in zip(g["scaling_triples"], g["scaling_values"]):
+        assert abs(mk(float(lam0)).compute_scaling_factor(int(dim), int(off)) - ref) < 1e-12 * abs(ref)
+    f = mk(1.8, use_scaling=True)
+    assert abs(f._alpha - float(g["alpha"])) < 1e-12 and abs(f._beta - float(g["beta"])) < 1e-12
+    f.optim_init()
+    f.step(ydict(Y), 1, T)
+    assert relerr(f._C[T], g["C_T"]) < 1e-10 and relerr(f._V[T], g["V_T"]) < 1e-10
+    assert relerr(f._mu[T], g["mu_T"].reshape(-1, 1)) < 1e-10 and relerr(f._P[T], g["P_T"]) < 1e-10
+
+
+def test_rpsmf_vector_R0_equals_dense_R0():
+    """rPSMFIter scales R by omega every step: a (d,) diagonal must stay a (d,) diagonal (it used to turn into a (1, d)
+    array and take the dense branch with a broadcast R)."""
+    rng = np.random.default_rng(5)
+    d, r, T = 12, 3, 6
+    Y = rng.standard_normal((T, d))
+    C0 = rng.standard_normal((d, r))
+    outs = []
+    for R0 in (2.0 * np.eye(d), np.full(d, 2.0), np.full((d, 1), 2.0), 2.0):
+        f = psmf.rPSMFIter(np.zeros((0, 1)), C0, 0.2 * np.eye(r), np.zeros((r, 1)), np.eye(r), 0.1 * np.eye(r), R0, 1.8,
+                           psmf.RandomWalk(), backend="numpy")
+        f.optim_init()
+        f.step(ydict(Y), 1, T)
+        outs.append((f._C[T], f._P[T], f._V[T], f._mu[T]))
+        assert np.shape(f._R[T]) == np.shape(R0)
+    for o in outs[1:]:
+        for a, b in zip(o, outs[0]):
+            assert relerr(a, b) < 1e-12
+    with pytest.raises(ValueError):
+        f = psmf.rPSMFIter(np.zeros((0, 1)), C0, 0.2 * np.eye(r), np.zeros((r, 1)), np.eye(r), 0.1 * np.eye(r), np.ones(d + 1), 1.8,
+                           psmf.RandomWalk(), backend="numpy")
+        f.optim_init()
+        f.step(ydict(Y), 1, T)
+
+
+def test_array_series_is_indexed_like_the_dict():
+    """y may be an array-like: y[k] for k = 1..T, row 0 unused -- the same rule in both back ends."""
+    rng = np.random.default_rng(6)
+    d, r, T = 10, 2, 8
+    Y = rng.standard_normal((T, d))
+    C0 = rng.standard_normal((d, r))
+    outs = []
+    for y in (ydict(Y), np.vstack([np.full((1, d), np.nan), Y])):
+        f = psmf.PSMFIter(np.zeros((0, 1)), C0, 0.2 * np.eye(r), np.zeros((r, 1)), np.eye(r),
+                          {k: 0.1 * np.eye(r) for k in range(T + 1)}, {k: 1.0 for k in range(T + 1)}, psmf.RandomWalk(), backend="numpy")
+        f.optim_init()
+        f.step(y, 1, T)
+        outs.append(f._C[T])
+    assert np.array_equal(outs[0], outs[1])
+
+
 def test_hip_backend_refuses_unrecognised_overrides_and_callables():
     class Custom(psmf.PSMFIter):
         def _compute_eta_k(self, k, P_bar):
@@ -184,6 +244,20 @@ def test_hip_backend_refuses_unrecognised_overrides_and_callables():
     with pytest.raises(TypeError):
         psmf.PSMFIter(*args, lambda th, x, t: x)         # arbitrary callable cannot run on the device
     Custom(*args, psmf.RandomWalk(), backend="numpy")    # fine on the host
+
+    class Declared(Custom):
+        hip_mode = "full"                                # declares a mode that does not cover the override
+
+    with pytest.raises(TypeError):
+        Declared(*args, psmf.RandomWalk())
+
+    class OwnLoop(psmf.PSMFRecursive):                   # synthetic_recursive_psmf.py:77-140 style: its own inner()
+        def inner(self, k, yk):
+            super().inner(k, yk)
+
+    with pytest.raises(TypeError):
+        OwnLoop(*args, psmf.RandomWalk())
+    OwnLoop(*args, psmf.RandomWalk(), backend="numpy")
     with pytest.raises(NotImplementedError):
         psmf.PSMFIterMissing()
     with pytest.raises(NotImplementedError):

@@ -1,5 +1,7 @@
-"""The N > 1 logic on CPU: row sharding + per-step all-reduce of the r+1 partial sums, two processes
-over torch.distributed gloo (world_size 2), against the unsharded CPU oracle.  CPU only."""
+"""The N > 1 logic on CPU, two processes over torch.distributed gloo (world_size 2), against the unsharded CPU oracle:
+row sharding + the exchange of each device engine (tests/host_models.py) -- per-step: r + 1 partial sums per timestep;
+blocked: one Gram per block; blocked pipelined (what bench.py --gpus N runs): first-block Gram, then one cross-Gram per
+block with the next K assembled from it and the tracked Gram.  CPU only."""
 
 import os
 import socket
@@ -11,21 +13,33 @@ import pytest
 
 from conftest import ROOT, relerr
 from oracle import psmf_oracle as O
-from rpsmf_amd.sharding import shard_bounds, shard_rows, sharded_epoch_host
+from host_models import sharded_epoch_host
+from rpsmf_amd.sharding import shard_bounds, shard_rows
 
 WORKER = r'''
 import os, sys
 import numpy as np
 sys.path.insert(0, sys.argv[1])
+sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
 import torch.distributed as dist
-from rpsmf_amd.sharding import shard_rows, sharded_epoch_host
+from rpsmf_amd.sharding import shard_rows
+from host_models import sharded_epoch_host, blocked_epoch_host, blocked_pipelined_epoch_host, gloo_allreduce
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 z = np.load(sys.argv[2])
 row0, dl = shard_rows(z["C0"].shape[0], world, rank)
 robust = bool(int(sys.argv[4]))
-C, V, P, mu, rho, lam, Yp = sharded_epoch_host(z["C0"][row0:row0 + dl], z["Y"][:, row0:row0 + dl], z["V0"], z["P0"], z["Q"],
-                                               z["mu0"], 1.0, z["C0"].shape[0], robust=robust, lambda0=1.8, dist=dist)
+model = sys.argv[5]
+d = z["C0"].shape[0]
+Cl, Yl = z["C0"][row0:row0 + dl], z["Y"][:, row0:row0 + dl]
+if model == "step":
+    C, V, P, mu, rho, lam, Yp = sharded_epoch_host(Cl, Yl, z["V0"], z["P0"], z["Q"], z["mu0"], 1.0, d, robust=robust, lambda0=1.8, dist=dist)
+elif model == "block":
+    C, V, P, mu, rho, lam, Yp = blocked_epoch_host(Cl, Yl, z["V0"], z["P0"], z["Q"], z["mu0"], 1.0, B=7, robust=robust, lambda0=1.8,
+                                                   gram_allreduce=gloo_allreduce(dist), d_global=d)
+else:
+    C, V, P, mu, rho, lam, Yp = blocked_pipelined_epoch_host(Cl, Yl, z["V0"], z["P0"], z["Q"], z["mu0"], 1.0, B=7, robust=robust, lambda0=1.8,
+                                                             allreduce=gloo_allreduce(dist), d_global=d)
 np.savez(sys.argv[3] + f".{rank}.npz", C=C, V=V, P=P, mu=mu, rho=rho, lam=lam, Yp=Yp, row0=row0)
 dist.barrier()
 dist.destroy_process_group()
@@ -56,8 +70,9 @@ def test_host_model_single_rank_equals_oracle():
             assert relerr(a, b) < 1e-10
 
 
+@pytest.mark.parametrize("model", ["step", "block", "block_pipelined"])
 @pytest.mark.parametrize("robust", [0, 1])
-def test_two_rank_gloo_equals_unsharded(tmp_path, robust):
+def test_two_rank_gloo_equals_unsharded(tmp_path, robust, model):
     rng = np.random.default_rng(1)
     d, r, T = 101, 5, 30          # odd d: unequal shards
     Y = O.synthetic_series(d, r, T, 5, dtype=np.float64)
@@ -73,7 +88,7 @@ def test_two_rank_gloo_equals_unsharded(tmp_path, robust):
     for rank in range(2):
         env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    OMP_NUM_THREADS="1")
-        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(inp), str(tmp_path / "out"), str(robust)],
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(inp), str(tmp_path / "out"), str(robust), model],
                                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     for p in procs:
         out, _ = p.communicate(timeout=240)
