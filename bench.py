@@ -12,11 +12,25 @@ timesteps, off the critical path; per-step engine: r+1 doubles per timestep); la
 `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N` -- torch is used
 only as rendezvous plumbing (gloo: id broadcast, barrier, max over ranks), never for compute.
 
-Extra objects on the JSON line:
-  roofline      dominant kernel: algorithmic bytes 8 d (r+1) per timestep x timesteps per launch / its
-                average duration measured with HIP events on the library's stream, vs 8 TB/s HBM.
+Extra objects on the JSON line (rank 0; the N = 1 run carries all of them):
+  roofline      dominant kernel (SURVEY 8(d) definition): algorithmic bytes 8 d (r+1) per timestep x timesteps per
+                launch / its average duration measured with HIP events on the stream it runs on, vs 8 TB/s HBM --
+                kept as the contract defines it, and labelled for what it is: the blocked engine REMOVES that
+                traffic, so this ratio is a speed-up over the step-at-a-time algorithm's roofline, not a bandwidth.
+                The distances to the actual limits are beside it:
+                  real_hbm_GBps       HBM bytes all kernels of a pass really move (rocprofv3 PMC passes, profiles/) / wall
+                  filter_chain_frac   matrix-core issue time of the Newton-Schulz products of a timestep / the measured
+                                      time per timestep inside the filter kernel (its own s_memrealtime stamps)
+                  bulk_kernels        the two d-sized kernels that do stream the data: measured GB/s vs HBM peak
+                  hbm_peak_measured   a plain copy kernel on this box, next to the nominal 8 TB/s
+  cold_pass_steps_per_s   config E as literally stated: ONE pass of T timesteps from the initial state (the first
+                ~400 timesteps invert by direct sweeps), timed on its own before the steady-state passes of `value`
   cpu_baseline  the CPU oracle (numpy restatement of the reference algorithm, O(d r^2) form)
                 timed on a bounded prefix of the same series on this box's host cores.
+  cpu_baseline_literal    the reference-shaped O(d^2 r) algebra (dense R, d x d inverse innovation: what the
+                reference itself costs) at d = 2000, where it still fits
+  other_configs BASELINE configs B, C (d = 10 000, r = 20, T = 5 000, PSMF / rPSMF) and D (masked filter, 19 x 295 719,
+                50 seeds in one launch): throughput + parity against the oracle, each
 """
 
 import argparse
@@ -30,7 +44,11 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md); measured copy peak is ~6.3 TB/s
+HBM_PEAK_GBS = 8000.0  # MI355X spec (MI355X_MICROARCH.md)
+# Newton-Schulz iteration of the filter kernel, per SIMD: one 32x32x32 float64 product (16 v_mfma_f64_16x16x4_f64, 64 cycles
+# each) + one float32 correction product (16 v_mfma_f32_16x16x4_f32, 32 cycles each); both inverses of a step iterate in
+# parallel on the four SIMDs of the workgroup's CU.  2.4 GHz.
+NS_ITER_ISSUE_US = (16 * 64 + 16 * 32) / 2.4e3
 
 
 def parse():
@@ -47,6 +65,7 @@ def parse():
     ap.add_argument("--no-y-pred", action="store_true")
     ap.add_argument("--workgroups", type=int, default=0)
     ap.add_argument("--engine", default="auto", choices=["auto", "step", "block"])
+    ap.add_argument("--no-extras", action="store_true", help="skip other_configs / literal baseline / copy peak (profiling runs)")
     return ap.parse_args()
 
 
@@ -91,29 +110,145 @@ def init_state(d, r, seed):
     return dict(C=C0, V=0.1 * np.eye(r), P=np.eye(r), Q=0.1 * np.eye(r), mu=np.zeros(r), rho=1.0, lam=1.8)
 
 
-def cpu_baseline(args, series, st0):
-    """Oracle (kind 'port') on the first cpu-steps timesteps; also returns its final state so the
-    GPU result can be checked against it in the same run."""
-    from oracle import psmf_oracle as O
-
-    n = min(args.cpu_steps, args.T)
-    Y = np.vstack([Yc for _, Yc in series.chunks(chunk=n)][:1])[:n].astype(np.float64)
-    st = O.State(C=st0["C"].copy(), V=st0["V"].copy(), mu=st0["mu"].copy(), P=st0["P"].copy(), Q=st0["Q"].copy(),
-                 rho=st0["rho"], lam=st0["lam"])
-    mode = O.Mode(robust=bool(args.robust))
-    t0 = time.perf_counter()
-    st, _, _ = O.run_epoch(st, Y, mode, O.RandomWalkDyn(), want_grad=False)
-    dt = time.perf_counter() - t0
+def blas_threads():
     try:
         import threadpoolctl
 
-        threads = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] or [1])
+        return int(max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] or [1]))
     except Exception:
-        threads = os.cpu_count() or 1
-    info = dict(value=n / dt, unit="timesteps/s", cores=int(threads), kind="port",
+        return os.cpu_count() or 1
+
+
+def oracle_prefix(series, st0, n, robust):
+    """CPU oracle over the first n timesteps of `series`; returns (final state, seconds)."""
+    from oracle import psmf_oracle as O
+
+    Y = np.vstack([Yc for _, Yc in series.chunks(chunk=n)][:1])[:n].astype(np.float64)
+    st = O.State(C=st0["C"].copy(), V=st0["V"].copy(), mu=st0["mu"].copy(), P=st0["P"].copy(), Q=st0["Q"].copy(),
+                 rho=st0["rho"], lam=st0["lam"])
+    t0 = time.perf_counter()
+    st, _, _ = O.run_epoch(st, Y, O.Mode(robust=bool(robust)), O.RandomWalkDyn(), want_grad=False)
+    return st, time.perf_counter() - t0
+
+
+def parity_of(f, st_cpu, n):
+    s = f.get_state()
+    rel = lambda a, b: float(np.max(np.abs(a - b)) / np.max(np.abs(b)))
+    return dict(steps=n, C=rel(s["C"], st_cpu.C), V=rel(s["V"], st_cpu.V), mu=rel(s["mu"], st_cpu.mu), P=rel(s["P"], st_cpu.P))
+
+
+def cpu_baseline(args, series, st0):
+    """Oracle (kind 'port') on the first cpu-steps timesteps; also returns its final state so the
+    GPU result can be checked against it in the same run."""
+    n = min(args.cpu_steps, args.T)
+    st, dt = oracle_prefix(series, st0, n, args.robust)
+    info = dict(value=n / dt, unit="timesteps/s", cores=blas_threads(), kind="port",
                 sample=f"first {n} of {args.T} timesteps of the same series (d={args.d}, r={args.r}), numpy float64 "
                        f"O(d r^2) restatement of the reference algorithm, {dt:.1f} s")
     return info, st, n
+
+
+def cpu_baseline_literal(r, seed, budget_s=12.0):
+    """The reference-shaped algebra (oracle.literal_step: dense d x d R, kron, d x d inverse innovation, d x d trace --
+    psmf.py:121-165 op for op) at d = 2000, the largest size at which it is still practical."""
+    from oracle import psmf_oracle as O
+
+    d = 2000
+    Y = O.synthetic_series(d, r, 64, seed, dtype=np.float64)
+    st0 = init_state(d, r, seed)
+    st = O.State(C=st0["C"], V=st0["V"], mu=st0["mu"], P=st0["P"], Q=st0["Q"], rho=1.0, lam=1.8)
+    mode, dyn = O.Mode(), O.RandomWalkDyn()
+    st, _ = O.literal_step(st, Y[0], 1, mode, dyn)           # warm the BLAS threads
+    n, t0 = 0, time.perf_counter()
+    while n < 63 and time.perf_counter() - t0 < budget_s:
+        st, _ = O.literal_step(st, Y[n + 1], n + 2, mode, dyn)
+        n += 1
+    dt = time.perf_counter() - t0
+    return dict(value=n / dt, unit="timesteps/s", cores=blas_threads(), kind="port",
+                sample=f"{n} timesteps at d={d}, r={r} (one d x d float64 temporary at d=100 000 would be 80 GB), numpy float64 "
+                       f"O(d^2 r) literal restatement of pypsmf/psmf/psmf.py:121-165, {dt:.1f} s")
+
+
+def run_filter_config(_capi, name, d, r, T, robust, passes=3):
+    """Configs B / C: cold pass, steady passes, parity against the oracle on the first 300 timesteps."""
+    seed = 35833 if robust else 35853
+    series = Series(d, r, T, seed, 0, d, robust)
+    st0 = init_state(d, r, seed)
+    f = _capi.DeviceFilter(d, r, robust=robust, storage="f32")
+    for a, Yc in series.chunks(chunk=1000):
+        f.upload_series(Yc, t0=a, T_total=T)
+    reset = lambda: f.set_state(st0["C"], st0["V"], st0["P"], st0["Q"], st0["mu"], rho=st0["rho"], lambda0=st0["lam"])
+    n_par = 300
+    st_cpu, dt_cpu = oracle_prefix(series, st0, n_par, robust)
+    reset()
+    f.run(0, n_par)
+    par = parity_of(f, st_cpu, n_par)
+    reset()
+    f.run(0, T)                                    # untimed: runtime pools, instruction caches
+    reset()
+    f.sync()
+    t0 = time.perf_counter()
+    f.run(0, T)
+    cold = time.perf_counter() - t0
+    if robust:
+        f.set_state(Q=st0["Q"], rho=st0["rho"], lambda0=st0["lam"])    # rPSMF epochs restart Q, R, lambda (rpsmf.py:106-114)
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        f.run(0, T, sync=False)
+    f.sync()
+    steady = (time.perf_counter() - t0) / passes
+    geo = f.geometry()
+    f.close()
+    return {"workload": f"{'rPSMF' if robust else 'PSMF'} full filter d={d} r={r} T={T}, f32 storage, 1 GPU", "value": T / steady,
+            "unit": "timesteps/s", "cold_pass_steps_per_s": T / cold, "us_per_timestep": 1e6 * steady / T, "engine": geo["engine"],
+            "parity_vs_cpu_oracle": par, "cpu_oracle_steps_per_s": n_par / dt_cpu,
+            "hbm_frac_step_at_a_time": (T / steady) * 8.0 * d * (r + 1) / (HBM_PEAK_GBS * 1e9)}
+
+
+def run_impute_config(seeds=50, n=295_719, d=19, r=10, n_par=3000):
+    """Config D: masked filter, gas-sensor shape (the CSV is not in the reference checkout: synthetic stand-in of the same
+    shape), 40 % missing, `seeds` replicas in one launch; parity of replica 0 on an n_par-column prefix against the oracle."""
+    from oracle.impute_oracle import impute_filter
+    from rpsmf_amd import impute, impute_harness as H
+
+    rng = np.random.default_rng(20160930)
+    Yorig = np.cumsum(0.05 * rng.standard_normal((d, n)), axis=1) + 10.0 * rng.random((d, 1))
+    Yorig[rng.random((d, n)) < 0.01] = np.nan
+    Yint = np.nan_to_num(Yorig, nan=0.0)
+    np.random.seed(123)
+    M, Mm, C0, X0 = [], [], [], []
+    for _ in range(seeds):
+        p = H.draw_problem(Yorig, 40, r)
+        M.append(p["M"].astype(np.uint8)); Mm.append(p["Mmiss"].astype(np.uint8)); C0.append(p["C"]); X0.append(p["X"])
+    M, Mm, C0, X0 = np.stack(M), np.stack(Mm), np.stack(C0), np.stack(X0)
+    V, Q, P = 2 * np.eye(r), 0.1 * np.eye(r), np.eye(r)
+    out = {}
+    for robust in (False, True):
+        res = impute.impute_batch(Yint, M, Mm, C0, X0, V, Q, 10.0, P, 2, 2, robust=robust, lambda0=1.8)
+        steps = seeds * 2 * n
+        # parity: replica 0 on a prefix, device vs oracle
+        Xo = X0[0][:, :n_par].copy()
+        t0 = time.perf_counter()
+        ep, ef, ib = impute_filter(Yint[:, :n_par] * M[0][:, :n_par], C0[0], Xo, M[0][:, :n_par], np.maximum(Mm[0][:, :n_par], 1e-300).astype(float),
+                                   V, Q, 10.0, P, 2, 2, Yint[:, :n_par], 0.0, robust=robust, lambda0=1.8)
+        dt = time.perf_counter() - t0
+        one = impute.impute_batch(Yint[:, :n_par], M[0][:, :n_par], np.maximum(Mm[0][:, :n_par], 0), C0[0], X0[0][:, :n_par], V, Q, 10.0, P, 2, 2,
+                                  robust=robust, lambda0=1.8)
+        rel = lambda a, b: float(np.max(np.abs(np.asarray(a) - np.asarray(b))) / np.max(np.abs(b)))
+        out["rPSMF" if robust else "PSMF"] = {
+            "workload": f"{'rPSMF' if robust else 'PSMF'} masked filter {d}x{n}, r={r}, Iter=2, 40% missing, {seeds} seeds in one launch",
+            "value": steps / (res["elapsed_ms"] * 1e-3), "unit": "timesteps/s (all replicas)", "kernel_s": res["elapsed_ms"] * 1e-3,
+            "us_per_column_per_replica": 1e3 * res["elapsed_ms"] / (2 * n),
+            "parity_vs_cpu_oracle": {"columns": n_par, "Epred": rel(one["Epred"][0], ep[0, 1:]), "Efull": rel(one["Efull"][0], ef[0, 1:]),
+                                     "inside_abs": abs(float(one["inside"][0]) - ib)},
+            "cpu_oracle_steps_per_s": 2 * n_par / dt,
+            "reference_published_s_per_seed": 100.68 if not robust else 109.38}
+    return out
+
+
+def load_pmc(name):
+    p = os.path.join(ROOT, "profiles", name)
+    return json.load(open(p)) if os.path.exists(p) else None
 
 
 def main():
@@ -164,6 +299,15 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        import torch
+
+        te = torch.tensor([x], dtype=torch.float64)
+        dist.all_reduce(te, op=dist.ReduceOp.MAX)
+        return float(te.item())
+
     # ---- CPU baseline + in-run parity of the GPU path against it (rank 0, N = 1 only)
     cpu = None
     parity = None
@@ -171,10 +315,7 @@ def main():
         cpu, st_cpu, n_cpu = cpu_baseline(args, series, st0)
         reset()
         f.run(0, n_cpu)
-        s = f.get_state()
-        rel = lambda a, b: float(np.max(np.abs(a - b)) / np.max(np.abs(b)))
-        parity = dict(steps=n_cpu, C=rel(s["C"], st_cpu.C), V=rel(s["V"], st_cpu.V), mu=rel(s["mu"], st_cpu.mu),
-                      P=rel(s["P"], st_cpu.P))
+        parity = parity_of(f, st_cpu, n_cpu)
 
     # ---- untimed pre-warm: the HIP runtime grows its signal / kernel-argument pools the first time a whole pass worth of
     # launches is queued ahead of the GPU (a one-off ~80 ms stall in the second pass, tools/probe_stall.py)
@@ -182,8 +323,16 @@ def main():
     for _ in range(2):
         f.run(0, T, sync=False)
     f.sync()
-    # ---- timed region: K passes of T timesteps, state carried from pass to pass
+    # ---- config E as literally stated: ONE pass of T timesteps from the initial state, timed on its own
     reset()
+    f.sync()
+    barrier()
+    t0 = time.perf_counter()
+    f.run(0, T, sync=False)
+    f.sync()
+    barrier()
+    cold_elapsed = max_over_ranks(time.perf_counter() - t0)
+    # ---- timed region: K passes of T timesteps, state carried from pass to pass
     for _ in range(args.warmup):
         f.run(0, T, sync=False)
     f.sync()
@@ -199,63 +348,73 @@ def main():
     elapsed = time.perf_counter() - t0
     insitu = f.counters() if geo_engine_block(f) else None      # device-timer durations of the filter kernels of the timed region
     chained = f.filter_kernel_time() if geo_engine_block(f) else (0, 0.0)   # HIP events around the chained filter launches of the timed region
-    if dist is not None:
-        import torch
-
-        te = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(te, op=dist.ReduceOp.MAX)
-        elapsed = float(te.item())
+    elapsed = max_over_ranks(elapsed)
     value = args.steps * T / elapsed
 
     # ---- roofline of the dominant kernel, HIP events on the library's stream (psmf_time_kernel)
-    bytes_per_step = (8.0 if args.storage == "f32" else 16.0) * d_local * (r + 1)   # read C, write C, read y, write y_hat
+    es = 4.0 if args.storage == "f32" else 8.0
+    bytes_per_step = 2.0 * es * d_local * (r + 1)   # read C, write C, read y, write y_hat
     geo = f.geometry()
     traffic = None
     if geo["engine"] == "block":
-        # one launch of the coefficient-space filter kernel = one block of B timesteps; the two d-sized
-        # products of the block (cross-Gram, apply) run concurrently on a second stream
+        # one launch of the coefficient-space filter kernel = every block of a pass (chained); the two d-sized
+        # products of each block (cross-Gram, apply) run concurrently on a second stream
         B = geo["block_steps"]
         t_filter = f.time_kernel(0, 20)
         t_gram = f.time_kernel(1, 50)
         t_apply = f.time_kernel(2, 50)
-        # Duration of the dominant kernel over the TIMED REGION.  Chained blocks (the default): one launch of
-        # psmf_blk_filter3 per pass, bracketed by HIP events on the stream it runs on (psmf_filter_kernel_time); it advances
-        # every timestep of the pass.  Unchained (PSMF_BLOCK_CHAIN=0): one launch per block, timed by the kernel's own
-        # s_memrealtime stamps (HIP events between those launches add 5-8 us each).  The stand-alone HIP-event figure of a
-        # single block (psmf_time_kernel) is reported beside it.
         t_block_insitu = insitu["filter_us_mean"] if insitu and insitu["filter_launches"] > 0 else t_filter
         if chained[0] > 0:
-            kernel, kernel_us, steps_per_launch = "psmf_blk_filter3", 1e3 * chained[1] / chained[0], float(T)   # (at most 16 launches between two syncs are timed)
+            kernel, kernel_us, steps_per_launch = "psmf_blk_filter3", 1e3 * chained[1] / chained[0], float(T)
+            kernel_us = min(kernel_us, 1e6 * elapsed / args.steps)   # a kernel cannot take longer than the wall time of its pass (two clocks: HIP events vs host)
         else:
             full_blocks_only = (T % B == 0)
             kernel, kernel_us = "psmf_blk_filter3", t_block_insitu
             steps_per_launch = B if full_blocks_only else T / (insitu["filter_launches"] / args.steps)
-        zbytes = (4.0 if args.storage == "f32" else 8.0) * d_local * 64
-        pmc = os.path.join(ROOT, "profiles", "r1_pmc_traffic_block_engine.json")
-        if (d, r, args.storage, world) == (100_000, 32, "f32", 1) and os.path.exists(pmc):
-            # rocprofv3 --pmc passes of this workload, taken with PSMF_BLOCK_CHAIN=0 (counter collection serialises the
-            # kernels, which a chained launch waiting for the bulk stream cannot survive): bytes per block of B timesteps,
-            # scaled to the blocks one launch advances
-            traffic = json.load(open(pmc))["traffic_bytes_per_launch"] * (steps_per_launch / B)
+        zbytes = es * d_local * 64
+        nb1 = min(B, 64)
+        xg_bytes = es * d_local * (r + B + nb1)          # cross-Gram reads C, the current and the next series block
+        ap_bytes = 2.0 * es * d_local * (r + B)          # apply reads C, Y_cur and writes C, Y_hat
+        pmc = load_pmc("r2_pmc_traffic_block_engine.json") or load_pmc("r1_pmc_traffic_block_engine.json")
+        real_hbm = None
+        if (d, r, args.storage, world) == (100_000, 32, "f32", 1) and pmc:
+            # rocprofv3 --pmc passes of this workload (counter collection serialises the kernels; the library then runs
+            # one filter launch per block): bytes per block of B timesteps, scaled to the blocks one launch advances
+            traffic = pmc["traffic_bytes_per_launch"] * (steps_per_launch / B)
+            if "all_kernels_bytes_per_block" in pmc:
+                real_hbm = pmc["all_kernels_bytes_per_block"] * (T / B) / (elapsed / args.steps) / 1e9
+        steps_timed = max(1, (insitu["ns_steps"] + insitu["sweep_steps"])) if insitu else 1
+        iters_per_step = insitu["ns_iterations"] / steps_timed if insitu else None
+        step_us = t_block_insitu / B
         extra = {"steps_per_launch": steps_per_launch,
                  "blocks_per_launch": steps_per_launch / B,
                  "block_us_in_kernel": t_block_insitu,
                  "one_block_us_hip_events_standalone": t_filter,
                  "gap_between_blocks_us": insitu["filter_gap_us_mean"] if insitu else None,
+                 "real_hbm_GBps": real_hbm,
+                 "filter_chain_frac": (iters_per_step * NS_ITER_ISSUE_US / step_us) if iters_per_step else None,
+                 "filter_chain": {"newton_schulz_iterations_per_timestep": iters_per_step, "mfma_issue_us_per_iteration": NS_ITER_ISSUE_US,
+                                  "us_per_timestep_in_kernel": step_us,
+                                  "timesteps_by_direct_sweep": insitu["sweep_steps"] if insitu else None},
                  "kernels_us": {"psmf_blk_filter3": t_filter, "psmf_blk_xgram2+xreduce2": t_gram, "psmf_blk_apply2": t_apply},
-                 "bulk_kernels_GBps": {"cross-Gram (reads Z and the next series block)": 1.5 * zbytes / (t_gram * 1e-6) / 1e9,
-                                       "apply (reads Z, writes C and y_hat)": 2 * zbytes / (t_apply * 1e-6) / 1e9},
-                 "note": "blocked engine: the filter kernel is a latency-bound chain of r x r stages (one workgroup, f64-MFMA Newton-Schulz), "
-                         "one launch per pass; achieved = step-at-a-time algorithmic bytes of the timesteps it advances / its duration "
-                         "(HIP events on its stream)"}
+                 "bulk_kernels": {"psmf_blk_xgram2+xreduce2": {"bytes": xg_bytes, "us": t_gram, "GBps": xg_bytes / (t_gram * 1e-6) / 1e9,
+                                                              "frac_of_hbm_peak": xg_bytes / (t_gram * 1e-6) / 1e9 / HBM_PEAK_GBS},
+                                  "psmf_blk_apply2": {"bytes": ap_bytes, "us": t_apply, "GBps": ap_bytes / (t_apply * 1e-6) / 1e9,
+                                                      "frac_of_hbm_peak": ap_bytes / (t_apply * 1e-6) / 1e9 / HBM_PEAK_GBS}},
+                 "note": "frac = SURVEY 8(d) bookkeeping: step-at-a-time algorithmic bytes of the timesteps one launch advances / its duration / 8 TB/s. "
+                         "The blocked engine does not move those bytes (traffic, real_hbm_GBps): the filter kernel is a latency-bound chain of r x r stages "
+                         "(one workgroup, f64-MFMA Newton-Schulz) -- its distance to its own limit is filter_chain_frac; the kernels that stream the data "
+                         "are under bulk_kernels"}
     else:
         kernel, kernel_us, steps_per_launch = "psmf_sweep_solve", f.time_kernel(0, 300), 1
         extra = {"steps_per_launch": 1, "kernels_us": {"psmf_sweep_solve": kernel_us, "psmf_serial": f.time_kernel(1, 300)}}
-        pmc = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
-        if (d, r, args.storage, world) == (100_000, 32, "f32", 1) and os.path.exists(pmc):
-            traffic = json.load(open(pmc))["traffic_bytes_per_launch"]   # rocprofv3 --pmc passes of this workload
+        pmc = load_pmc("r1_pmc_traffic.json")
+        if (d, r, args.storage, world) == (100_000, 32, "f32", 1) and pmc:
+            traffic = pmc["traffic_bytes_per_launch"]   # rocprofv3 --pmc passes of this workload
     alg_bytes = bytes_per_step * steps_per_launch
     achieved = alg_bytes / (kernel_us * 1e-6) / 1e9
+    f.close()
+
     if rank == 0:
         line = {
             "metric": "PSMF filter timesteps/sec at d=100k r=32" if (d, r) == (100_000, 32) else f"PSMF filter timesteps/sec at d={d} r={r}",
@@ -275,17 +434,36 @@ def main():
                                    f"T={T} synthetic Gaussian series, rows sharded over {world} GPU(s)",
                        "d": d, "r": r, "T": T, "timesteps_per_pass": T, "store_y_pred": not args.no_y_pred,
                        "us_per_timestep": 1e6 * elapsed / (args.steps * T), "engine": geo["engine"], "geometry": geo},
+            "cold_pass_steps_per_s": T / cold_elapsed,
             "roofline": dict({"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                               "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kernel, "kernel_us": kernel_us,
                               "algorithmic_bytes_per_launch": alg_bytes,
-                              "whole_job_frac": value * 8.0 * d * (r + 1) / (world * HBM_PEAK_GBS * 1e9)}, **extra),
+                              "whole_job_frac": value * 2.0 * es * d * (r + 1) / (world * HBM_PEAK_GBS * 1e9)}, **extra),
         }
         if cpu is not None:
             line["cpu_baseline"] = cpu
         if parity is not None:
             line["parity_vs_cpu_oracle"] = parity
+        if world == 1 and not args.no_extras:
+            try:
+                line["roofline"]["hbm_peak_measured"] = {"GBps": _capi.measure_copy_bandwidth(local_rank, 1 << 30, 20),
+                                                         "what": "copy kernel, 1 GiB read + 1 GiB written per launch, 16-byte accesses"}
+            except Exception as e:      # never lose the headline over an extra
+                line["roofline"]["hbm_peak_measured"] = {"error": repr(e)}
+            if args.cpu_steps > 0:
+                line["cpu_baseline_literal"] = cpu_baseline_literal(r, seed)
+                other = {}
+                for name, rob in (("B", False), ("C", True)):
+                    try:
+                        other[name] = run_filter_config(_capi, name, 10_000, 20, 5_000, rob)
+                    except Exception as e:
+                        other[name] = {"error": repr(e)}
+                try:
+                    other["D"] = run_impute_config()
+                except Exception as e:
+                    other["D"] = {"error": repr(e)}
+                line["other_configs"] = other
         print(json.dumps(line), flush=True)
-    f.close()
     if dist is not None:
         dist.destroy_process_group()
 

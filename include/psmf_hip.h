@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PSMF_ABI_VERSION 1
+#define PSMF_ABI_VERSION 2
 #define PSMF_RMAX 64 /* largest supported rank r */
 
 typedef enum {
@@ -39,10 +39,21 @@ typedef enum {
 
 typedef enum { PSMF_F32 = 0, PSMF_F64 = 1 } psmf_dtype;
 
-/* State transition f(theta, x, t) evaluated on the device.
- * PSMF_DYN_RANDOM_WALK  f = x                         pypsmf/psmf/nonlinearities.py:42-56
- * PSMF_DYN_COS_PHASE    f = cos(2 pi theta t + x)     ExperimentSynthetic/synthetic_psmf.py:105-106 */
-typedef enum { PSMF_DYN_RANDOM_WALK = 0, PSMF_DYN_COS_PHASE = 1 } psmf_dyn_kind;
+/* State transition f(theta, x, t); theta packs its blocks in the reference's order (BaseNonLinearity.dims).
+ * PSMF_DYN_RANDOM_WALK  f = x                                   pypsmf/psmf/nonlinearities.py:42-56
+ * PSMF_DYN_COS_PHASE    f = cos(2 pi theta t + x)               ExperimentSynthetic/synthetic_psmf.py:105-106   theta: [r]
+ * PSMF_DYN_SCALED_WALK  f = A x (+ b)                           nonlinearities.py:59-78     theta: A [r*r], b [r] if dyn_flags & 1
+ * PSMF_DYN_SINUSOID     f = [A] sin(2 pi b t + [c o] x)         nonlinearities.py:81-114    theta: A [r*r] if dyn_flags & 1 (scaled),
+ *                                                                                           b [r], c [r] if dyn_flags & 2 (phased)
+ * PSMF_DYN_FOURIER      f = sum_n A_n sin(2 pi b_n t + c_n o x) + D_n cos(2 pi e_n t + f_n o x)   nonlinearities.py:117-150
+ *                                                               theta: A_1, D_1, .., A_N, D_N [r*r each], then b_n, c_n, e_n, f_n [r each]
+ *                                                               per n; N = dyn_terms <= 4
+ * PSMF_DYN_HOST         any callable: the host evaluates mu_bar = f(theta, mu, k) and P_bar = F P F^T + Q (r-sized) and
+ *                       advances the device one timestep at a time with psmf_step_host (the d-sized work stays on the device)
+ * Kinds 2-4 are evaluated inside the blocked engine (r <= 32), with analytic Jacobians df/dx, df/dtheta (the reference uses
+ * autograd, psmf.py:41-44); the per-step engine evaluates kinds 0, 1 and is the engine of kind 5. */
+typedef enum { PSMF_DYN_RANDOM_WALK = 0, PSMF_DYN_COS_PHASE = 1, PSMF_DYN_SCALED_WALK = 2, PSMF_DYN_SINUSOID = 3,
+               PSMF_DYN_FOURIER = 4, PSMF_DYN_HOST = 5 } psmf_dyn_kind;
 
 typedef struct psmf_filter* psmf_handle;
 
@@ -60,7 +71,7 @@ typedef struct {
   int32_t pbar_predict;  /* 1: Pbar = F P F^T + Q  psmf.py:107-115; 0: Pbar = P_{k-1}         */
   int32_t fixed_lambda;  /* rpsmf.py:36-40                                                    */
   int32_t dyn_kind;      /* psmf_dyn_kind                                                     */
-  int32_t n_theta;       /* 0 for random walk, r for cos-phase                                */
+  int32_t n_theta;       /* length of theta: 0 random walk / host, r cos-phase, see psmf_dyn_kind       */
   int32_t storage;       /* psmf_dtype of C, y, y_pred in HBM (arithmetic on r x r is f64)    */
   int32_t store_y_pred;  /* keep y_hat_k = C_{k-1} mu_bar_k for every step (psmf.py:93)       */
   int32_t recursive;     /* 1: PSMFRecursive -- Adam step on theta inside the time loop every
@@ -72,8 +83,10 @@ typedef struct {
   int32_t use_graph;     /* 1: replay the per-step launches from a hipGraph                   */
   int32_t n_workgroups;  /* row-sweep workgroups, 0 = auto                                    */
   int32_t engine;        /* 0 = auto, 1 = per-step engine (one row sweep per timestep),
-                            2 = exact time-blocked engine (one Gram Z^T Z per block of 64 - r steps,
-                            the steps in coefficient space; needs r <= 32, recursive = 0)       */
+                            2 = exact time-blocked engine (one Gram Z^T Z per block of min(64 - r, 48) steps,
+                            the steps in coefficient space; needs r <= 32)                      */
+  int32_t dyn_flags;     /* see psmf_dyn_kind                                                  */
+  int32_t dyn_terms;     /* PSMF_DYN_FOURIER: N                                                */
   double alpha, beta;    /* rPSMF scaling factors (rpsmf.py:45-51), 1.0 unless use_scaling     */
   double adam_lr, adam_lr_end, adam_lr_steps; /* lr (Constant) or lr_start/lr_end/steps
                             (ExponentialLearningRate, learning_rate.py:20-27; steps = 0 ->
@@ -103,6 +116,11 @@ int psmf_get_state(psmf_handle h, double* C, double* V, double* P, double* Q, do
 /* Adam moments for the recursive mode (psmf.py:190-204): m, v of length n_theta. */
 int psmf_set_adam(psmf_handle h, const double* m, const double* v);
 
+/* Per-step schedules of PSMFIter's R[k], Q[k] (psmf.py:115,123,141): R_k = rho_k[k] I and Q_k = q_k[k] * Q for the 1-based
+ * step k = 1 .. n - 1 (entry 0 unused; steps beyond n - 1 are refused by psmf_run).  NULL = constant (rho / Q of
+ * psmf_set_state).  Not with robust = 1 (rPSMF runs on its own omega-scaled Q_{k-1}, R_{k-1}, rpsmf.py:123,128,141). */
+int psmf_set_schedules(psmf_handle h, const double* rho_k, const double* q_k, int64_t n);
+
 /* ---- series ---------------------------------------------------------------------------- */
 /* Y: nt x d_local time-major block holding y_{t0+1} .. y_{t0+nt}; T_total sizes the device
  * buffers on first use.  replaces the dict y[k] of (d,1) arrays passed to step (psmf.py:85-88) */
@@ -116,6 +134,16 @@ int psmf_upload_series(psmf_handle h, const void* Y, int dtype, int64_t t0, int6
 int psmf_run(psmf_handle h, int64_t k_begin, int64_t k_end);
 int psmf_sync(psmf_handle h); /* waits, then reports a device-side numeric failure if any */
 
+/* Host-stepped dynamics (dyn_kind = PSMF_DYN_HOST): ONE timestep, k -> k + 1 (k = number of finished steps), with
+ * mu_bar = f(theta, mu_k, k + 1) [r] and P_bar = F P_k F^T + Q [r x r] formed by the caller (psmf.py:104-115); the device
+ * does everything d-sized of inner() (psmf.py:90-102).  Returns what the caller needs for the next step and for the
+ * theta gradient: mu_{k+1} [r], g_f = d(incremental likelihood)/df [r] (gradsum += J_theta^T g_f, psmf.py:167-177),
+ * P_{k+1}, Q_{k+1} [r x r] (rPSMF scales Q by omega).  Any output may be NULL.  Synchronous. */
+int psmf_step_host(psmf_handle h, int64_t k, const double* mu_bar, const double* P_bar, double* mu_out, double* gf_out,
+                   double* P_out, double* Q_out);
+/* out[q] = C mu[q] for n given r-vectors (n x d_local float64): the y_hat of a roll-out the caller computed (psmf.py:182-188). */
+int psmf_project(psmf_handle h, const double* mu, int64_t n, double* out);
+
 /* y_hat for steps t0+1..t0+nt (needs store_y_pred) -> out (nt x d_local), dtype f32/f64 */
 int psmf_download_y_pred(psmf_handle h, void* out, int dtype, int64_t t0, int64_t nt);
 /* posterior means mu_{k0} .. mu_{k0+nk-1} of the last run (row k = state after step k; the row of the
@@ -128,6 +156,9 @@ int psmf_predict(psmf_handle h, int64_t T, int64_t n_pred, double* out);
 /* sum_t sum_i (y_hat - y)^2 over steps t0+1..t0+nt of the uploaded series (local rows);
  * tracking.py:63-76 error norms without copying y_pred back. */
 int psmf_sq_error(psmf_handle h, int64_t t0, int64_t nt, double* out);
+/* the same for the roll-out window: sum over q < n_pred and the local rows of (C mu_pred_q - Y_true[q])^2, Y_true the held-out
+ * observations y_{T+1} .. y_{T+n_pred} (n_pred x d_local float64, host): tracking.py:74-76 (`_E_pred`). */
+int psmf_predict_sq_error(psmf_handle h, int64_t T, int64_t n_pred, const double* Y_true, double* out);
 
 /* ---- multi-GPU (row shards, one process per GPU, RCCL over xGMI) ------------------------- */
 #define PSMF_UNIQUE_ID_BYTES 128
@@ -165,6 +196,10 @@ int psmf_counters(psmf_handle h, int64_t* out8, int reset);
  * launch on the stream it runs on (at most 256 runs between two psmf_sync calls are timed).  Waits like psmf_sync.
  * (New: measurement aid for bench.py; the reference times whole runs with time.time(), ExperimentImpute/PSMF.py:59,91.) */
 int psmf_filter_kernel_time(psmf_handle h, int64_t* launches, double* total_ms, int reset);
+
+/* Measured HBM bandwidth of a plain streaming copy (`bytes` read + `bytes` written per launch, `iters` launches, HIP events):
+ * the "measured copy-kernel peak" SURVEY 8(d) asks for beside the nominal 8 TB/s.  *gbps = (read + written bytes) / time. */
+int psmf_measure_copy_bandwidth(int device, size_t bytes, int iters, double* gbps);
 
 /* ================= masked, batched small-d filter (ExperimentImpute) ==================== */
 typedef struct {

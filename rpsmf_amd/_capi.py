@@ -12,10 +12,10 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpsmf_hip.so")
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 RMAX = 64
 F32, F64 = 0, 1
-DYN_RANDOM_WALK, DYN_COS_PHASE = 0, 1
+DYN_RANDOM_WALK, DYN_COS_PHASE, DYN_SCALED_WALK, DYN_SINUSOID, DYN_FOURIER, DYN_HOST = 0, 1, 2, 3, 4, 5
 UNIQUE_ID_BYTES = 128
 
 OK, ERR_ARG, ERR_HIP, ERR_RCCL, ERR_NUMERIC, ERR_STATE, ERR_NO_DEVICE = 0, -1, -2, -3, -4, -5, -6
@@ -29,7 +29,7 @@ class PsmfConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "abi_version", "d", "r", "row0", "d_local", "robust", "coef_update", "eta_full", "pbar_predict",
         "fixed_lambda", "dyn_kind", "n_theta", "storage", "store_y_pred", "recursive", "update_every",
-        "gram_refresh", "device", "use_graph", "n_workgroups", "engine")] + [(n, C.c_double) for n in (
+        "gram_refresh", "device", "use_graph", "n_workgroups", "engine", "dyn_flags", "dyn_terms")] + [(n, C.c_double) for n in (
         "alpha", "beta", "adam_lr", "adam_lr_end", "adam_lr_steps", "adam_b1", "adam_b2")]
 
 
@@ -53,6 +53,10 @@ SIGNATURES = {
     "psmf_zero_gradsum": (C.c_int, [C.c_void_p]),
     "psmf_get_state": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
     "psmf_set_adam": (C.c_int, [C.c_void_p, _dp, _dp]),
+    "psmf_set_schedules": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int64]),
+    "psmf_step_host": (C.c_int, [C.c_void_p, C.c_int64, _dp, _dp, _dp, _dp, _dp, _dp]),
+    "psmf_project": (C.c_int, [C.c_void_p, _dp, C.c_int64, _dp]),
+    "psmf_predict_sq_error": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, _dp, _dp]),
     "psmf_upload_series": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_int64]),
     "psmf_run": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64]),
     "psmf_sync": (C.c_int, [C.c_void_p]),
@@ -68,6 +72,7 @@ SIGNATURES = {
     "psmf_geometry": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "psmf_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
     "psmf_filter_kernel_time": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_int]),
+    "psmf_measure_copy_bandwidth": (C.c_int, [C.c_int, C.c_size_t, C.c_int, _dp]),
     "psmf_impute_run": (C.c_int, [C.POINTER(PsmfImputeConfig), _dp, _u8p, _u8p, _dp, _dp, _dp, _dp, _dp,
                                   C.c_double, _dp, _dp, _dp, _dp, _dp, _dp, C.POINTER(C.c_float)]),
 }
@@ -93,6 +98,19 @@ def load_library():
     return lib
 
 
+def dyn_n_theta(kind, r, flags=0, terms=0):
+    """length of theta for a device dynamics kind (psmf_dyn_kind in include/psmf_hip.h)"""
+    if kind == DYN_COS_PHASE:
+        return r
+    if kind == DYN_SCALED_WALK:
+        return r * r + (r if flags & 1 else 0)
+    if kind == DYN_SINUSOID:
+        return (r * r if flags & 1 else 0) + r + (r if flags & 2 else 0)
+    if kind == DYN_FOURIER:
+        return terms * (2 * r * r + 4 * r)
+    return 0
+
+
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(_dp)
 
@@ -113,18 +131,19 @@ class DeviceFilter:
                  fixed_lambda=False, dyn_kind=DYN_RANDOM_WALK, storage="f32", store_y_pred=True,
                  recursive=False, update_every=1, gram_refresh=0, device=0, use_graph=True,
                  n_workgroups=0, engine="auto", alpha=1.0, beta=1.0, adam_lr=1e-3, adam_lr_end=0.0, adam_lr_steps=0.0,
-                 adam_b1=0.9, adam_b2=0.999, row0=0, d_local=None):
+                 adam_b1=0.9, adam_b2=0.999, row0=0, d_local=None, dyn_flags=0, dyn_terms=0):
         self._lib = load_library()
         self._h = C.c_void_p()
         self.d, self.r = int(d), int(r)
         self.row0 = int(row0)
         self.d_local = int(d if d_local is None else d_local)
-        self.n_theta = self.r if dyn_kind == DYN_COS_PHASE else 0
+        self.dyn_kind = int(dyn_kind)
+        self.n_theta = dyn_n_theta(self.dyn_kind, self.r, int(dyn_flags), int(dyn_terms))
         if storage == "auto":
             # f32 where the blocked engine runs (C is rounded once per block of 64 - r timesteps: errors ~1e-6);
             # f64 where the per-step engine runs (one rounding of C per timestep would breach the 1e-5 bar around
             # k = 300)
-            blocked = engine in ("auto", "block", 0, 2) and self.r <= 32 and not recursive and os.environ.get("PSMF_ENGINE") != "1"
+            blocked = engine in ("auto", "block", 0, 2) and self.r <= 32 and self.dyn_kind != DYN_HOST and os.environ.get("PSMF_ENGINE") != "1"
             storage = "f32" if blocked else "f64"
         self.storage = F64 if storage in ("f64", F64, np.float64) else F32
         self.store_y_pred = bool(store_y_pred)
@@ -135,7 +154,7 @@ class DeviceFilter:
             n_theta=self.n_theta, storage=self.storage, store_y_pred=int(store_y_pred),
             recursive=int(recursive), update_every=int(update_every), gram_refresh=int(gram_refresh),
             device=int(device), use_graph=int(use_graph), n_workgroups=int(n_workgroups),
-            engine={"auto": 0, "step": 1, "block": 2}.get(engine, engine),
+            engine={"auto": 0, "step": 1, "block": 2}.get(engine, engine), dyn_flags=int(dyn_flags), dyn_terms=int(dyn_terms),
             alpha=float(alpha), beta=float(beta), adam_lr=float(adam_lr), adam_lr_end=float(adam_lr_end),
             adam_lr_steps=float(adam_lr_steps), adam_b1=float(adam_b1), adam_b2=float(adam_b2))
         rc = self._lib.psmf_create(C.byref(self._h), C.byref(cfg))
@@ -214,6 +233,43 @@ class DeviceFilter:
         T_total = t0 + nt if T_total is None else int(T_total)
         self._check(self._lib.psmf_upload_series(self._h, Y.ctypes.data_as(C.c_void_p), dt, t0, nt, T_total))
         self.T = max(self.T, T_total)
+
+    def set_schedules(self, rho_k=None, q_k=None):
+        """R_k = rho_k[k] I, Q_k = q_k[k] Q for the 1-based step k (entry 0 unused); None = constant."""
+        rho_k, q_k = _f64(rho_k), _f64(q_k)
+        n = max(0 if rho_k is None else rho_k.size, 0 if q_k is None else q_k.size)
+        for a in (rho_k, q_k):
+            if a is not None and a.size != n:
+                raise ValueError("schedules must have the same length")
+        self._check(self._lib.psmf_set_schedules(self._h, _ptr(rho_k), _ptr(q_k), n))
+
+    def step_host(self, k, mu_bar, P_bar, want_PQ=True):
+        """One timestep k -> k + 1 with host-evaluated mu_bar [r], P_bar [r, r] (dyn_kind = DYN_HOST).
+        Returns (mu, gf, P, Q) of the finished step."""
+        r = self.r
+        mu_bar, P_bar = _f64(mu_bar, (r,)), _f64(P_bar, (r, r))
+        mu, gf = np.empty(r), np.empty(r)
+        P = np.empty((r, r)) if want_PQ else None
+        Q = np.empty((r, r)) if want_PQ else None
+        self._check(self._lib.psmf_step_host(self._h, int(k), _ptr(mu_bar), _ptr(P_bar), _ptr(mu), _ptr(gf), _ptr(P), _ptr(Q)))
+        return mu, gf, P, Q
+
+    def project(self, mu):
+        """C @ mu[q] for each of the n given r-vectors -> (n, d_local)"""
+        mu = _f64(mu)
+        mu = mu.reshape(-1, self.r)
+        out = np.empty((mu.shape[0], self.d_local))
+        self._check(self._lib.psmf_project(self._h, _ptr(mu), mu.shape[0], _ptr(out)))
+        return out
+
+    def predict_sq_error(self, T, Y_true):
+        """sum of (C mu_pred_q - Y_true[q])^2 over the roll-out window; Y_true: (n_pred, d_local)"""
+        Y_true = _f64(Y_true)
+        if Y_true.ndim != 2 or Y_true.shape[1] != self.d_local:
+            raise ValueError(f"held-out observations must be (n_pred, {self.d_local})")
+        v = C.c_double()
+        self._check(self._lib.psmf_predict_sq_error(self._h, int(T), Y_true.shape[0], _ptr(Y_true), C.byref(v)))
+        return v.value
 
     def run(self, k_begin, k_end, sync=True):
         self._check(self._lib.psmf_run(self._h, int(k_begin), int(k_end)))
@@ -305,6 +361,16 @@ class DeviceFilter:
 
         self._allreduce_cb = ALLREDUCE_FN(_cb)      # keep the trampoline alive as long as the handle
         self._check(self._lib.psmf_comm_init_host(self._h, int(nranks), int(rank), C.cast(self._allreduce_cb, C.c_void_p), None))
+
+
+def measure_copy_bandwidth(device=0, nbytes=1 << 30, iters=20):
+    """GB/s (read + written) of a streaming copy kernel on `device`."""
+    lib = load_library()
+    v = C.c_double()
+    rc = lib.psmf_measure_copy_bandwidth(int(device), int(nbytes), int(iters), C.byref(v))
+    if rc != OK:
+        raise PsmfError("psmf_measure_copy_bandwidth failed: " + lib.psmf_last_error(None).decode())
+    return v.value
 
 
 def device_count():

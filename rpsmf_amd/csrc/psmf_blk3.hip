@@ -1,5 +1,5 @@
 // Role-specialised coefficient-space filter of the blocked engine ("filter3") for the common
-// configuration (full filter, random-walk dynamics, Q = q I, 16 < r <= 32): same recursion as
+// configuration (full filter, random-walk dynamics, Q = q I, r <= 32; blocks of at most 48 timesteps): same recursion as
 // psmf_blk_filter2 (psmf_block.hip), re-laid out around what bounds a step on MI355X.
 //
 // On gfx950 v_mfma_f64_16x16x4_f64 runs at the float64 VECTOR rate (64 cycles per instruction and SIMD),
@@ -62,15 +62,19 @@ __device__ __forceinline__ double wave_sum_f64_dpp(double v) {
   return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 
-// Which T-layout elements lie inside the r x r matrix / on the diagonal (16 < r <= 32): tile (0, 0) is always inside,
-// column tile 1 is inside iff (l & 15) < r - 16, row tile 1 iff (l >> 4) + 4 q < r - 16; only the tiles (t, t) hold
-// diagonal elements, where (l & 15) == (l >> 4) + 4 q.  Nine lane predicates (kept in SGPR pairs) in all.
-template <bool FULL>      // FULL: r == 32, nothing to mask (five predicates fewer to keep in SGPR pairs)
+// Which T-layout elements lie inside the r x r matrix / on the diagonal.  16 < r <= 32: tile (0, 0) is always inside,
+// column tile 1 is inside iff (l & 15) < r - 16, row tile 1 iff (l >> 4) + 4 q < r - 16.  r <= 16 (SMALL): only tile (0, 0)
+// holds matrix elements -- column (l & 15) < r, row (l >> 4) + 4 q < r -- the rest of the 32 x 32 iterate is identity
+// padding (the same kernel, same speed per timestep as r = 32: the r x r work of a step is latency, not throughput).
+// Only the tiles (t, t) hold diagonal elements, where (l & 15) == (l >> 4) + 4 q.  Nine lane predicates (SGPR pairs) in all.
+template <int MODE>       // 0: r == 32, nothing to mask (five predicates fewer to keep in SGPR pairs); 1: 16 < r < 32; 2: r <= 16
 struct F3Mask {
-  static constexpr bool full = FULL;
-  bool c1, r1[4], dg[4];
+  static constexpr bool full = MODE == 0;
+  static constexpr bool small = MODE == 2;
+  bool c1, r1[4], dg[4];      // MODE 2: c1 / r1 describe tile 0 (column / row < r)
 };
-#define F3_VALID(mk, ti, tj, q) ((mk).full || (((ti) == 0 || (mk).r1[q]) && ((tj) == 0 || (mk).c1)))
+#define F3_VALID(mk, ti, tj, q) ((mk).full || ((mk).small ? ((ti) == 0 && (tj) == 0 && (mk).r1[q] && (mk).c1) \
+                                                          : (((ti) == 0 || (mk).r1[q]) && ((tj) == 0 || (mk).c1))))
 #define F3_DIAG(mk, ti, tj, q) (((ti) == (tj)) && (mk).dg[q])
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains vmcnt: the y_hat coefficients and the
@@ -215,7 +219,7 @@ __device__ __forceinline__ void f3_assemble_K(const BlockParams& b, const F3Blk&
 // pi(4 a + v) = a + 4 v: the float32 MFMA returns row 4 (l >> 4) + v in register v where the float64 one returns
 // (l >> 4) + 4 v, and feeding it the rows in that order makes its output land in T-layout.
 // Returns this lane's share of ||R_c||_F^2.
-template <int C, bool FULL>
+template <int C, int FULL>
 __device__ __forceinline__ double f3_ns_iter(const double (&Mf)[16], const double (&Xc)[8], const float (&Xa)[16], double (&Xn)[8],
                                              const F3Mask<FULL>& mk) {
   // the two 16 x 16 output tiles of a product are independent accumulator chains: alternate them, so that no MFMA
@@ -299,7 +303,7 @@ __device__ __forceinline__ void f3_sweep_images(const F3Lds& L, const int r2, co
 // ------------------------------------------------------------------------------------------------------------
 // Program of the four inversion waves.  INV 0 = X (P+ = M^-1), 1 = Y (W = (M / beta + I / q)^-1); C = own tile column.
 // ------------------------------------------------------------------------------------------------------------
-template <int C, bool FULL>
+template <int C, int FULL>      // FULL: the F3Mask mode
 __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Blk& k, const F3Lds& L, const int inv, const int role, const int lane,
                                               const bool carried) {
   const StepParams& p = b.sp;
@@ -314,9 +318,10 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Blk&
   const int pcol = (lcol >> 2) + 4 * (lcol & 3);     // pi(lcol)       // Wf: W of the last step (zero outside r x r): Lbar = (I / q - W / q^2) / omega
   const double q0 = st->Q[0];
   F3Mask<FULL> mk;
-  mk.c1 = lcol < r - 16;
+  const int rt = FULL == 2 ? r : r - 16;               // extent of the partially filled tile (tile 0 when r <= 16, else tile 1)
+  mk.c1 = lcol < rt;
 #pragma unroll
-  for (int qq = 0; qq < 4; ++qq) { mk.r1[qq] = lrow + 4 * qq < r - 16; mk.dg[qq] = lcol == lrow + 4 * qq; }
+  for (int qq = 0; qq < 4; ++qq) { mk.r1[qq] = lrow + 4 * qq < rt; mk.dg[qq] = lcol == lrow + 4 * qq; }
 #pragma unroll
   for (int ti = 0; ti < 2; ++ti)
 #pragma unroll
@@ -982,11 +987,14 @@ __global__ __launch_bounds__(F3_NT) void psmf_blk_filter3(BlockParams b0) {
   if (role < 4) {
     const int inv = role >> 1;
     if (r == 32) {
-      if (role & 1) f3_ns_program<1, true>(b, k, L, inv, role, lane, carried);
-      else f3_ns_program<0, true>(b, k, L, inv, role, lane, carried);
+      if (role & 1) f3_ns_program<1, 0>(b, k, L, inv, role, lane, carried);
+      else f3_ns_program<0, 0>(b, k, L, inv, role, lane, carried);
+    } else if (r > 16) {
+      if (role & 1) f3_ns_program<1, 1>(b, k, L, inv, role, lane, carried);
+      else f3_ns_program<0, 1>(b, k, L, inv, role, lane, carried);
     } else {
-      if (role & 1) f3_ns_program<1, false>(b, k, L, inv, role, lane, carried);
-      else f3_ns_program<0, false>(b, k, L, inv, role, lane, carried);
+      if (role & 1) f3_ns_program<1, 2>(b, k, L, inv, role, lane, carried);
+      else f3_ns_program<0, 2>(b, k, L, inv, role, lane, carried);
     }
   } else {
     f3_v_program(b, k, L, role, lane, carried);

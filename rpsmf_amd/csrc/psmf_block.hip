@@ -16,6 +16,7 @@
 #pragma once
 #include "psmf_kernels.hip"
 #include "psmf_ns.hip"
+#include "psmf_dyn.hip"
 
 namespace psmf {
 
@@ -509,6 +510,15 @@ __global__ __launch_bounds__(WG) void psmf_blk_filter(BlockParams b) {
   double* rowbuf = s_p2 + 8 * RB;     // 4 * RM
   double* s4 = rowbuf + 4 * RM;       // 4 (+ errflag)
   int* errflag = reinterpret_cast<int*>(s4 + 4);
+  // dynamics (psmf_dyn.hip): dense Jacobian F, P and P F^T images (row stride RS), trig values of the terms, g_f
+  double* sF = s4 + 6;                // RM/2 x RS
+  double* sPm = sF + (RM / 2) * RS;
+  double* sT = sPm + (RM / 2) * RS;
+  double* s_val = sT + (RM / 2) * RS; // DYN_MAX_TERMS x RM
+  double* s_tp = s_val + DYN_MAX_TERMS * RM;
+  double* s_gf = s_tp + DYN_MAX_TERMS * RM;   // RM
+  double* s_u = s_gf + RM;            // RM
+  const bool dense = dyn_dense(p.dyn_kind, p.dyn_flags);
 
   if (!blk_handoff_begin(b)) return;
   if (!b.assemble) {
@@ -533,8 +543,6 @@ __global__ __launch_bounds__(WG) void psmf_blk_filter(BlockParams b) {
     Pv[m] = val[m] ? lp : 0.0;
   }
   double rho = st->rho, lam = st->lam;
-  double theta = (tid < p.n_theta) ? st->theta[tid] : 0.0;
-  double gsum = (tid < p.n_theta) ? st->gradsum[tid] : 0.0;
   __syncthreads();
   // A_0 = [I; 0], K A_0 = first r columns of K, G_0 = K[0:r, 0:r] (exact Gram of the stored C)
   for (int idx = tid; idx < RB * r; idx += WG) {
@@ -549,24 +557,54 @@ __global__ __launch_bounds__(WG) void psmf_blk_filter(BlockParams b) {
   double s_last = 0.0, eta_last = 0.0, N_last = 0.0, phi = 1.0, omega = 1.0, ee_last = 0.0;
   for (int jb = 0; jb < b.nb; ++jb) {
     const long long kstep = b.k0 + jb + 1;   // 1-based step index
-    // ---- S1: mu_bar, F ----
-    if (tid < r) {
-      double mb = s_mu[tid], f = 1.0;
-      if (p.dyn_kind == 1) {
-        const double arg = 2.0 * M_PI * theta * (double)kstep + mb;
-        mb = cos(arg);
-        f = -sin(arg);
-      }
-      s_mub[tid] = mb;
-      s_f[tid] = f;
-    }
-    __syncthreads();
+    // ---- S1: mu_bar = f(theta, mu, k), F = df/dx (psmf.py:104-115; psmf_dyn.hip) ----
+    dyn_forward<WG>(p, (double)kstep, s_mu, s_mub, s_f, sF, RS, s_val, s_tp, tid);     // ends with a barrier
+    // PSMFIter reads Q[k], R[k] of the step (psmf.py:115,123,141): scalar schedules (never with rPSMF's running Q, R)
+    const double qs = p.q_sched ? p.q_sched[kstep - p.series_t0] : 1.0;
+    if (p.rho_sched) rho = p.rho_sched[kstep - p.series_t0];
     // ---- S2: Pbar, w = V mu_bar, <G, Pbar>, s, eta, N, kappa ----
     double Pb[M];
     double part = 0.0, gp = 0.0;
+    if (dense && p.pbar_predict) {
+      // Pbar = F P F^T + Q with a dense F: T = P F^T, then F T, through LDS images (odd row stride: conflict-free)
+#pragma unroll
+      for (int m = 0; m < M; ++m)
+        if (val[m]) sPm[ii[m] * RS + j] = Pv[m];
+      __syncthreads();
+      double tv[M];
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        double a = 0.0;
+        if (val[m])
+          for (int q = 0; q < r; ++q) a += sPm[ii[m] * RS + q] * sF[j * RS + q];
+        tv[m] = a;
+      }
+#pragma unroll
+      for (int m = 0; m < M; ++m)
+        if (val[m]) sT[ii[m] * RS + j] = tv[m];
+      __syncthreads();
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        double a = 0.0;
+        if (val[m])
+          for (int q = 0; q < r; ++q) a += sF[ii[m] * RS + q] * sT[q * RS + j];
+        Pb[m] = val[m] ? a + qs * Qv[m] : 0.0;
+      }
+      // symmetrise (F P F^T is symmetric up to round-off; the sweep inversion assumes exact symmetry)
+      __syncthreads();
+#pragma unroll
+      for (int m = 0; m < M; ++m)
+        if (val[m]) sT[ii[m] * RS + j] = Pb[m];
+      __syncthreads();
+#pragma unroll
+      for (int m = 0; m < M; ++m)
+        if (val[m]) Pb[m] = 0.5 * (Pb[m] + sT[j * RS + ii[m]]);
+    } else {
+#pragma unroll
+      for (int m = 0; m < M; ++m) Pb[m] = val[m] ? (p.pbar_predict ? s_f[ii[m]] * Pv[m] * s_f[j] + qs * Qv[m] : Pv[m]) : 0.0;
+    }
 #pragma unroll
     for (int m = 0; m < M; ++m) {
-      Pb[m] = val[m] ? (p.pbar_predict ? s_f[ii[m]] * Pv[m] * s_f[j] + Qv[m] : Pv[m]) : 0.0;
       part += val[m] ? Vv[m] * s_mub[ii[m]] : 0.0;
       gp += Gv[m] * Pb[m];
     }
@@ -646,20 +684,22 @@ __global__ __launch_bounds__(WG) void psmf_blk_filter(BlockParams b) {
     } else {
       if (tid < r) mu_new = s_mub[tid];
     }
-    // theta gradient at the pre-update state
-    if (tid < p.n_theta && p.dyn_kind == 1) {
-      const double tk = (double)kstep;
-      const double arg = 2.0 * M_PI * theta * tk + s_mu[tid];
-      const double jt = -sin(arg) * (2.0 * M_PI * tk);
-      const double wi = s_w[tid], hi = s_h[tid];
-      double gf;
-      if (p.robust) {
-        const double D = lam * N;
-        gf = dd * wi / N + 0.5 * (dd + lam) * (-2.0 * hi / D - 2.0 * lam * ee * wi / (D * D)) / (1.0 + ee / D);
-      } else {
-        gf = dd * wi * invN - hi * invN - ee * wi * invN * invN;
+    // theta gradient at the pre-update state: g_f = d(incremental likelihood)/df (psmf.py:57-64, rpsmf.py:62-71),
+    // then gradsum += J_theta^T g_f
+    if (p.n_theta > 0) {
+      if (tid < r) {
+        const double wi = s_w[tid], hi = s_h[tid];
+        double gf;
+        if (p.robust) {
+          const double D = lam * N;
+          gf = dd * wi / N + 0.5 * (dd + lam) * (-2.0 * hi / D - 2.0 * lam * ee * wi / (D * D)) / (1.0 + ee / D);
+        } else {
+          gf = dd * wi * invN - hi * invN - ee * wi * invN * invN;
+        }
+        s_gf[tid] = gf;
       }
-      gsum += jt * gf;
+      __syncthreads();
+      dyn_backward<WG>(p, (double)kstep, s_mu, s_gf, s_val, s_tp, s_u, tid);        // ends with a barrier
     }
     double vscale = 1.0, pscale = 1.0, qscale = 1.0;
     phi = 1.0; omega = 1.0;
@@ -700,6 +740,8 @@ __global__ __launch_bounds__(WG) void psmf_blk_filter(BlockParams b) {
     }
     s_last = s; eta_last = eta; N_last = N; ee_last = ee;
     __syncthreads();
+    // PSMFRecursive: optimiser step on theta every update_every observations (psmf.py:299-304)
+    if (p.recursive && p.n_theta > 0 && (kstep % p.update_every) == 0) dyn_adam_step<WG>(p, kstep, tid);
   }
 
   // ---- block end: coefficients and state back to memory ----
@@ -715,7 +757,6 @@ __global__ __launch_bounds__(WG) void psmf_blk_filter(BlockParams b) {
     }
   }
   if (tid < r) st->mu[tid] = s_mu[tid];
-  if (tid < p.n_theta) st->gradsum[tid] = gsum;
   if (tid == 0) {
     st->k = b.k0 + b.nb;
     st->rho = rho; st->lam = lam; st->phi = phi; st->omega = omega; st->ee = ee_last;
@@ -1117,7 +1158,8 @@ inline size_t blk_filter2_lds_bytes() {
 }
 
 inline size_t blk_filter_lds_bytes() {
-  const size_t doubles = (size_t)RB * RB + 2 * (size_t)RB * RS + WG + 6 * RM + 2 * RB + 8 * RB + 4 * RM + 4 + 2;
+  const size_t doubles = (size_t)RB * RB + 2 * (size_t)RB * RS + WG + 6 * RM + 2 * RB + 8 * RB + 4 * RM + 4 + 2 +
+                         3 * (size_t)(RM / 2) * RS + 2 * (size_t)DYN_MAX_TERMS * RM + 2 * RM;
   return (doubles * 8 + 15) & ~(size_t)15;
 }
 

@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void psmf_blk_xreduce2(const double* __restric
 // ------------------------------------------------------------------------------------------------------------
 constexpr int AP2_SC = 36;     // staging row stride (floats) of the C part  [16 rows][rp <= 32]
 constexpr int AP2_SY = 20;     // staging stride (floats) of the series part  [column][16 rows]
-constexpr int AP2_NY = 48;     // series columns staged (r >= 16)
+constexpr int AP2_NY = 48;     // series columns staged = the longest block (psmf_capi.hip caps blocks at 48 timesteps)
 constexpr size_t AP2_WAVE_BYTES = (size_t)BK_TR * AP_S * 8 + BK_TR * AP2_SC * 4 + AP2_NY * AP2_SY * 4;
 inline size_t blk_apply2_lds_bytes() { return (size_t)RB * GZ_S * 8 + (size_t)BK_WAVES * AP2_WAVE_BYTES; }
 
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(BK_NT) void psmf_blk_apply2(BlockParams b) {
       for (int q = 0; q < 4; ++q) {
         const int row = lrow + 4 * q;
         if (col < r) sC[row * AP2_SC + col] = (float)acc[ct][q];
-        else sY[(col - r) * AP2_SY + row] = (float)acc[ct][q];
+        else if (col - r < AP2_NY) sY[(col - r) * AP2_SY + row] = (float)acc[ct][q];     // (r < 16: columns r + 48 .. 63 are padding)
       }
     }
 #pragma unroll

@@ -46,6 +46,10 @@ struct psmf_filter {
   void* YP = nullptr;
   double* partials = nullptr;
   double* gpart = nullptr;
+  double* thbuf = nullptr;     // theta | gradsum | adam_m | adam_v, th_cap doubles each
+  size_t th_cap = 0;
+  double* sched = nullptr;     // rho_k | q_k schedules, sched_n doubles each (psmf_set_schedules)
+  int64_t sched_n = 0;
   double* mu_hist = nullptr;   // (T_cap + 1) x r
   hipStream_t fstream = nullptr;   // blocked engine, pipelined: the filter chain's own stream, pinned to reserved CUs (or nullptr)
   bool streams_concurrent = false;           // the filter stream's kernels run concurrently with the bulk stream's (probed at creation)
@@ -244,8 +248,7 @@ void launch_blk_gram(psmf_filter* h, const psmf::BlockParams& b, hipStream_t str
 // streaming bulk kernels (psmf_bulk.hip): float32 storage, d_local a multiple of 4, 16 <= r <= 32
 bool blk_bulk2_ok(const psmf_filter* h) {
   static const bool off = getenv("PSMF_BULK2") && atoi(getenv("PSMF_BULK2")) == 0;
-  return !off && blk_use_mfma() && h->cfg.storage == PSMF_F32 && (h->cfg.d_local % 4) == 0 && h->cfg.r >= 16 && h->cfg.r <= 32 &&
-         (h->geo.rp % 4) == 0;
+  return !off && blk_use_mfma() && h->cfg.storage == PSMF_F32 && (h->cfg.d_local % 4) == 0 && h->cfg.r <= 32 && (h->geo.rp % 4) == 0;
 }
 
 void launch_blk_xgram(psmf_filter* h, const psmf::BlockParams& x, double* xg, hipStream_t stream) {
@@ -282,7 +285,7 @@ bool blk_dual_ok(const psmf_filter* h) {
 
 void launch_blk_filter(psmf_filter* h, const psmf::BlockParams& b, hipStream_t stream = nullptr) {
   if (!stream) stream = h->stream;
-  if (blk_dual_ok(h) && h->geo.rpad == 32 && blk_use_filter3()) {
+  if (blk_dual_ok(h) && blk_use_filter3()) {
     hipLaunchKernelGGL(psmf::psmf_blk_filter3, dim3(1), dim3(psmf::F3_NT), psmf::blk_filter3_lds_bytes(), stream, b);
     return;
   }
@@ -374,7 +377,7 @@ int enqueue_blocks_pipelined(psmf_filter* h, int64_t k_begin, int64_t k_end) {
   h->seq_next += nblk;
   // chain: the filter kernels of the whole run as ONE launch (psmf_blk_filter3; the bulk stream is driven as before)
   const bool chain_off = getenv("PSMF_BLOCK_CHAIN") && atoi(getenv("PSMF_BLOCK_CHAIN")) == 0;
-  const bool chain = use_flags && !chain_off && nblk > 1 && blk_dual_ok(h) && h->geo.rpad == 32 && blk_use_filter3();
+  const bool chain = use_flags && !chain_off && nblk > 1 && blk_dual_ok(h) && blk_use_filter3();
   // first block: plain Gram of the stored C
   fill_block_params(h, b, k0_of(0), nb_of(0), 0);
   launch_blk_gram(h, b, h->bulk);
@@ -557,6 +560,34 @@ int prepare(psmf_filter* h, int64_t k_begin) {
   return PSMF_OK;
 }
 
+// f(theta, x, t) on the host, for the predict roll-out (psmf.py:182-188); same term structure as psmf_dyn.hip
+void dyn_f_host(const psmf_config& c, const double* th, const double* x, double t, double* out) {
+  const int r = c.r, kind = c.dyn_kind, flags = c.dyn_flags, N = c.dyn_terms;
+  if (kind == PSMF_DYN_RANDOM_WALK) { for (int i = 0; i < r; ++i) out[i] = x[i]; return; }
+  if (kind == PSMF_DYN_SCALED_WALK) {
+    for (int i = 0; i < r; ++i) {
+      double a = (flags & 1) ? th[r * r + i] : 0.0;
+      for (int j = 0; j < r; ++j) a += th[i * r + j] * x[j];
+      out[i] = a;
+    }
+    return;
+  }
+  for (int i = 0; i < r; ++i) out[i] = 0.0;
+  std::vector<double> val(r);
+  const int nt = psmf::dyn_n_terms(kind, N);
+  for (int tI = 0; tI < nt; ++tI) {
+    const psmf::DynTerm d = psmf::dyn_term(kind, flags, N, r, tI);
+    for (int j = 0; j < r; ++j) {
+      const double arg = 2.0 * M_PI * th[d.b_off + j] * t + (d.c_off >= 0 ? th[d.c_off + j] : 1.0) * x[j];
+      val[j] = d.is_cos ? cos(arg) : sin(arg);
+    }
+    for (int i = 0; i < r; ++i) {
+      if (d.m_off >= 0) { double a = 0.0; for (int j = 0; j < r; ++j) a += th[d.m_off + i * r + j] * val[j]; out[i] += a; }
+      else out[i] += val[i];
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -577,9 +608,12 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
   if (cfg->d < 1 || cfg->d_local < 1 || cfg->row0 < 0 || cfg->row0 + cfg->d_local > cfg->d)
     return fail(nullptr, PSMF_ERR_ARG, "psmf_create: bad d / row0 / d_local");
   if (cfg->storage != PSMF_F32 && cfg->storage != PSMF_F64) return fail(nullptr, PSMF_ERR_ARG, "psmf_create: storage must be f32 or f64");
-  if (cfg->dyn_kind == PSMF_DYN_RANDOM_WALK && cfg->n_theta != 0) return fail(nullptr, PSMF_ERR_ARG, "psmf_create: random walk has no theta");
-  if (cfg->dyn_kind == PSMF_DYN_COS_PHASE && cfg->n_theta != cfg->r) return fail(nullptr, PSMF_ERR_ARG, "psmf_create: cos-phase needs n_theta == r");
-  if (cfg->dyn_kind != PSMF_DYN_RANDOM_WALK && cfg->dyn_kind != PSMF_DYN_COS_PHASE) return fail(nullptr, PSMF_ERR_ARG, "psmf_create: unknown dyn_kind");
+  if (cfg->dyn_kind < PSMF_DYN_RANDOM_WALK || cfg->dyn_kind > PSMF_DYN_HOST) return fail(nullptr, PSMF_ERR_ARG, "psmf_create: unknown dyn_kind");
+  if (cfg->dyn_kind == PSMF_DYN_FOURIER && (cfg->dyn_terms < 1 || 2 * cfg->dyn_terms > psmf::DYN_MAX_TERMS))
+    return fail(nullptr, PSMF_ERR_ARG, "psmf_create: Fourier dynamics need 1 <= dyn_terms <= 4");
+  if (cfg->n_theta != psmf::dyn_n_theta(cfg->dyn_kind, cfg->dyn_flags, cfg->dyn_terms, cfg->r))
+    return fail(nullptr, PSMF_ERR_ARG, "psmf_create: n_theta does not match dyn_kind / dyn_flags / dyn_terms (see psmf_dyn_kind)");
+  if (cfg->dyn_kind == PSMF_DYN_HOST && cfg->recursive) return fail(nullptr, PSMF_ERR_ARG, "psmf_create: host-stepped dynamics keep theta (and its optimiser) on the host");
   if (cfg->recursive && cfg->update_every < 1) return fail(nullptr, PSMF_ERR_ARG, "psmf_create: update_every must be >= 1");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
@@ -607,15 +641,24 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
   CREATE_TRY(hipMalloc((void**)&h->partials, (size_t)h->geo.n_sweep_wg * h->geo.ps * sizeof(double)));
   CREATE_TRY(hipMalloc((void**)&h->gpart, (size_t)kGramWG * cfg->r * cfg->r * sizeof(double)));
   {
-    const bool can_block = cfg->r <= psmf::RM / 2 && !cfg->recursive;
-    if (cfg->engine == 2 && !can_block) { h->err = "psmf_create: the blocked engine needs r <= 32 and recursive = 0"; return bail(PSMF_ERR_ARG); }
+    const bool can_block = cfg->r <= psmf::RM / 2 && cfg->dyn_kind != PSMF_DYN_HOST;
+    if (cfg->engine == 2 && !can_block) { h->err = "psmf_create: the blocked engine needs r <= 32 and device-evaluated dynamics"; return bail(PSMF_ERR_ARG); }
     if (cfg->engine < 0 || cfg->engine > 2) { h->err = "psmf_create: engine must be 0 (auto), 1 (per-step) or 2 (blocked)"; return bail(PSMF_ERR_ARG); }
     // auto: blocked whenever it applies -- it is exact and removes the per-step launches and row sweeps
     h->engine = cfg->engine == 0 ? (can_block ? 2 : 1) : cfg->engine;
     if (const char* e = getenv("PSMF_ENGINE")) { const int v = atoi(e); if (v == 1 || (v == 2 && can_block)) h->engine = v; }
+    if (h->engine == 1 && cfg->dyn_kind >= PSMF_DYN_SCALED_WALK && cfg->dyn_kind <= PSMF_DYN_FOURIER) {
+      h->err = "psmf_create: scaled-walk / sinusoid / Fourier dynamics are evaluated by the blocked engine (r <= 32); use PSMF_DYN_HOST otherwise";
+      return bail(PSMF_ERR_ARG);
+    }
   }
+  h->th_cap = (size_t)(cfg->n_theta > psmf::RM ? cfg->n_theta : psmf::RM);
+  CREATE_TRY(hipMalloc((void**)&h->thbuf, 4 * h->th_cap * sizeof(double)));
+  CREATE_TRY(hipMemset(h->thbuf, 0, 4 * h->th_cap * sizeof(double)));
   if (h->engine == 2) {
-    h->block_steps = psmf::RB - cfg->r;
+    // B = 64 - r timesteps per block, at most 48: the role-specialised filter kernel and the streaming bulk kernels stage
+    // up to three 16-column tiles of a series block (r < 16 would otherwise give blocks of 49..63)
+    h->block_steps = psmf::RB - cfg->r < 48 ? psmf::RB - cfg->r : 48;
     CREATE_TRY(hipMalloc((void**)&h->Kpart, (size_t)psmf::BLK_GRAM_WG * psmf::RB * psmf::RB * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&h->Kmat, (size_t)psmf::RB * psmf::RB * sizeof(double)));
     CREATE_TRY(hipMalloc((void**)&h->Acoef, (size_t)2 * psmf::RB * psmf::RM * sizeof(double)));
@@ -706,6 +749,9 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
   sp.robust = cfg->robust; sp.coef_update = cfg->coef_update; sp.eta_full = cfg->eta_full;
   sp.pbar_predict = cfg->pbar_predict; sp.fixed_lambda = cfg->fixed_lambda;
   sp.dyn_kind = cfg->dyn_kind; sp.n_theta = cfg->n_theta; sp.store_yp = 0;
+  sp.dyn_flags = cfg->dyn_flags; sp.dyn_terms = cfg->dyn_terms;
+  sp.theta = h->thbuf; sp.gradsum = h->thbuf + h->th_cap; sp.adam_m = h->thbuf + 2 * h->th_cap; sp.adam_v = h->thbuf + 3 * h->th_cap;
+  sp.rho_sched = nullptr; sp.q_sched = nullptr;
   sp.recursive = cfg->recursive; sp.update_every = cfg->update_every > 0 ? cfg->update_every : 1;
   sp.track_g = (cfg->eta_full || cfg->coef_update) ? 1 : 0;
   sp.external_reduce = 0;
@@ -737,6 +783,8 @@ void psmf_destroy(psmf_handle h) {
   if (h->partials) hipFree(h->partials);
   if (h->gpart) hipFree(h->gpart);
   if (h->mu_hist) hipFree(h->mu_hist);
+  if (h->thbuf) hipFree(h->thbuf);
+  if (h->sched) hipFree(h->sched);
   if (h->Kpart) hipFree(h->Kpart);
   if (h->Kmat) hipFree(h->Kmat);
   if (h->Acoef) hipFree(h->Acoef);
@@ -790,7 +838,7 @@ int psmf_set_state(psmf_handle h, const double* C, const double* V, const double
   }
   if (mu) HIP_TRY(h, hipMemcpy(h->st->mu, mu, r * sizeof(double), hipMemcpyHostToDevice));
   if (theta && h->cfg.n_theta > 0)
-    HIP_TRY(h, hipMemcpy(h->st->theta, theta, h->cfg.n_theta * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->sp.theta, theta, h->cfg.n_theta * sizeof(double), hipMemcpyHostToDevice));
   if (!std::isnan(rho)) HIP_TRY(h, hipMemcpy(&h->st->rho, &rho, sizeof(double), hipMemcpyHostToDevice));
   if (!std::isnan(lambda0)) HIP_TRY(h, hipMemcpy(&h->st->lam, &lambda0, sizeof(double), hipMemcpyHostToDevice));
   { const int zero = 0; HIP_TRY(h, hipMemcpy(&h->st->ns_valid, &zero, sizeof(int), hipMemcpyHostToDevice));
@@ -804,7 +852,7 @@ int psmf_zero_gradsum(psmf_handle h) {
   if (!h) return PSMF_ERR_ARG;
   int rc = set_device(h);
   if (rc) return rc;
-  HIP_TRY(h, hipMemsetAsync(h->st->gradsum, 0, sizeof(double) * psmf::RM, h->stream));
+  HIP_TRY(h, hipMemsetAsync(h->sp.gradsum, 0, sizeof(double) * h->th_cap, h->stream));
   return PSMF_OK;
 }
 
@@ -814,8 +862,8 @@ int psmf_set_adam(psmf_handle h, const double* m, const double* v) {
   if (rc) return rc;
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   const size_t nb = (size_t)h->cfg.n_theta * sizeof(double);
-  if (m && nb) HIP_TRY(h, hipMemcpy(h->st->adam_m, m, nb, hipMemcpyHostToDevice));
-  if (v && nb) HIP_TRY(h, hipMemcpy(h->st->adam_v, v, nb, hipMemcpyHostToDevice));
+  if (m && nb) HIP_TRY(h, hipMemcpy(h->sp.adam_m, m, nb, hipMemcpyHostToDevice));
+  if (v && nb) HIP_TRY(h, hipMemcpy(h->sp.adam_v, v, nb, hipMemcpyHostToDevice));
   return PSMF_OK;
 }
 
@@ -841,8 +889,8 @@ int psmf_get_state(psmf_handle h, double* C, double* V, double* P, double* Q, do
   if (P) HIP_TRY(h, hipMemcpy(P, h->st->P, rr, hipMemcpyDeviceToHost));
   if (Q) HIP_TRY(h, hipMemcpy(Q, h->st->Q, rr, hipMemcpyDeviceToHost));
   if (mu) HIP_TRY(h, hipMemcpy(mu, h->st->mu, r * sizeof(double), hipMemcpyDeviceToHost));
-  if (theta && h->cfg.n_theta) HIP_TRY(h, hipMemcpy(theta, h->st->theta, h->cfg.n_theta * sizeof(double), hipMemcpyDeviceToHost));
-  if (gradsum && h->cfg.n_theta) HIP_TRY(h, hipMemcpy(gradsum, h->st->gradsum, h->cfg.n_theta * sizeof(double), hipMemcpyDeviceToHost));
+  if (theta && h->cfg.n_theta) HIP_TRY(h, hipMemcpy(theta, h->sp.theta, h->cfg.n_theta * sizeof(double), hipMemcpyDeviceToHost));
+  if (gradsum && h->cfg.n_theta) HIP_TRY(h, hipMemcpy(gradsum, h->sp.gradsum, h->cfg.n_theta * sizeof(double), hipMemcpyDeviceToHost));
   if (scalars) {
     DevState* s = h->st;
     double tmp[12];  // rho lam s eta N kappa phi omega ee s_done eta_done N_done
@@ -913,6 +961,8 @@ int psmf_run(psmf_handle h, int64_t k_begin, int64_t k_end) {
   if (!h->have_state) return fail(h, PSMF_ERR_STATE, "psmf_run: set_state (C, V, P, mu) first");
   if (!h->Y) return fail(h, PSMF_ERR_STATE, "psmf_run: upload_series first");
   if (k_begin < 0 || k_end < k_begin || k_end > h->T_cap) return fail(h, PSMF_ERR_ARG, "psmf_run: step range outside the uploaded series");
+  if (h->cfg.dyn_kind == PSMF_DYN_HOST) return fail(h, PSMF_ERR_STATE, "psmf_run: host-stepped dynamics advance with psmf_step_host");
+  if (h->sched && k_end >= h->sched_n) return fail(h, PSMF_ERR_ARG, "psmf_run: step range beyond the R / Q schedules");
   int rc = set_device(h);
   if (rc) return rc;
   if (h->need_prep || h->k_done != k_begin) {
@@ -1176,23 +1226,32 @@ int psmf_predict(psmf_handle h, int64_t T, int64_t n_pred, double* out) {
   if (n_pred == 0) return PSMF_OK;
   int rc = psmf_sync(h);
   if (rc) return rc;
-  const int r = h->cfg.r, dl = h->cfg.d_local;
-  std::vector<double> mu(r), theta(psmf::RM, 0.0), mup((size_t)n_pred * r);
+  if (h->cfg.dyn_kind == PSMF_DYN_HOST) return fail(h, PSMF_ERR_STATE, "psmf_predict: host-stepped dynamics roll mu forward on the host; use psmf_project");
+  const int r = h->cfg.r;
+  std::vector<double> mu(r), theta((size_t)(h->cfg.n_theta > 0 ? h->cfg.n_theta : 1), 0.0), mup((size_t)n_pred * r), nx(r);
   HIP_TRY(h, hipMemcpy(mu.data(), h->st->mu, r * sizeof(double), hipMemcpyDeviceToHost));
-  if (h->cfg.n_theta) HIP_TRY(h, hipMemcpy(theta.data(), h->st->theta, h->cfg.n_theta * sizeof(double), hipMemcpyDeviceToHost));
+  if (h->cfg.n_theta) HIP_TRY(h, hipMemcpy(theta.data(), h->sp.theta, h->cfg.n_theta * sizeof(double), hipMemcpyDeviceToHost));
   for (int64_t q = 0; q < n_pred; ++q) {   // psmf.py:183-187, r-sized: done on the host
-    const double k = (double)(T + q + 1);
-    for (int i = 0; i < r; ++i) {
-      if (h->cfg.dyn_kind == PSMF_DYN_COS_PHASE) mu[i] = cos(2.0 * M_PI * theta[i] * k + mu[i]);
-      mup[(size_t)q * r + i] = mu[i];
-    }
+    dyn_f_host(h->cfg, theta.data(), mu.data(), (double)(T + q + 1), nx.data());
+    mu = nx;
+    for (int i = 0; i < r; ++i) mup[(size_t)q * r + i] = mu[i];
   }
-  const size_t mbytes = mup.size() * sizeof(double), obytes = (size_t)n_pred * dl * sizeof(double);
+  return psmf_project(h, mup.data(), n_pred, out);
+}
+
+int psmf_project(psmf_handle h, const double* mu, int64_t n_pred, double* out) {
+  if (!h || !mu || !out || n_pred < 0) return PSMF_ERR_ARG;
+  if (n_pred == 0) return PSMF_OK;
+  int rc = psmf_sync(h);
+  if (rc) return rc;
+  const int r = h->cfg.r, dl = h->cfg.d_local;
+  const size_t nmu = (size_t)n_pred * r;
+  const size_t mbytes = nmu * sizeof(double), obytes = (size_t)n_pred * dl * sizeof(double);
   rc = ensure_scratch(h, mbytes + obytes);
   if (rc) return rc;
   double* dmu = h->scratch;
-  double* dout = h->scratch + mup.size();
-  HIP_TRY(h, hipMemcpy(dmu, mup.data(), mbytes, hipMemcpyHostToDevice));
+  double* dout = h->scratch + nmu;
+  HIP_TRY(h, hipMemcpy(dmu, mu, mbytes, hipMemcpyHostToDevice));
   const int grid = (dl + psmf::WG - 1) / psmf::WG;
   const size_t lds = (size_t)64 * r * sizeof(double);
   if (h->cfg.storage == PSMF_F64)
@@ -1204,6 +1263,34 @@ int psmf_predict(psmf_handle h, int64_t T, int64_t n_pred, double* out) {
   HIP_TRY(h, hipGetLastError());
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   HIP_TRY(h, hipMemcpy(out, dout, obytes, hipMemcpyDeviceToHost));
+  return PSMF_OK;
+}
+
+int psmf_predict_sq_error(psmf_handle h, int64_t T, int64_t n_pred, const double* Y_true, double* out) {
+  if (!h || !Y_true || !out || n_pred < 0) return PSMF_ERR_ARG;
+  *out = 0.0;
+  if (n_pred == 0) return PSMF_OK;
+  const size_t dl = h->cfg.d_local, n = (size_t)n_pred * dl;
+  std::vector<double> yp(n);
+  int rc = psmf_predict(h, T, n_pred, yp.data());      // leaves the roll-out in the scratch buffer: [mu_pred | y_hat]
+  if (rc) return rc;
+  const size_t off = (size_t)n_pred * h->cfg.r;
+  const int grid = 1024;
+  rc = ensure_scratch(h, (off + 2 * n + grid) * sizeof(double));      // (may move the buffer: upload the roll-out again)
+  if (rc) return rc;
+  double* dyp = h->scratch + off;
+  double* dyt = dyp + n;
+  double* part = dyt + n;
+  HIP_TRY(h, hipMemcpy(dyp, yp.data(), n * sizeof(double), hipMemcpyHostToDevice));
+  HIP_TRY(h, hipMemcpy(dyt, Y_true, n * sizeof(double), hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(psmf::psmf_sq_error_k<double>, dim3(grid), dim3(psmf::WG), 0, h->stream, (const double*)dyp, (const double*)dyt, n, part);
+  HIP_TRY(h, hipGetLastError());
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  std::vector<double> hp(grid);
+  HIP_TRY(h, hipMemcpy(hp.data(), part, grid * sizeof(double), hipMemcpyDeviceToHost));
+  double a = 0.0;
+  for (int i = 0; i < grid; ++i) a += hp[i];
+  *out = a;
   return PSMF_OK;
 }
 
@@ -1277,6 +1364,91 @@ int psmf_comm_init(psmf_handle h, int nranks, int rank, const void* unique_id) {
   h->sp.external_reduce = h->use_coll ? 1 : 0;
   destroy_graph(h);
   h->need_prep = true;
+  return PSMF_OK;
+}
+
+int psmf_set_schedules(psmf_handle h, const double* rho_k, const double* q_k, int64_t n) {
+  if (!h || n < 0) return PSMF_ERR_ARG;
+  if (h->cfg.robust && (rho_k || q_k)) return fail(h, PSMF_ERR_ARG, "psmf_set_schedules: rPSMF runs on its own scaled Q, R (rpsmf.py:123,128,141)");
+  int rc = set_device(h);
+  if (rc) return rc;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (h->sched) { HIP_TRY(h, hipFree(h->sched)); h->sched = nullptr; }
+  h->sched_n = 0;
+  h->sp.rho_sched = h->sp.q_sched = nullptr;
+  if ((rho_k || q_k) && n > 0) {
+    HIP_TRY(h, hipMalloc((void**)&h->sched, (size_t)2 * n * sizeof(double)));
+    std::vector<double> ones((size_t)n, 1.0);
+    HIP_TRY(h, hipMemcpy(h->sched, rho_k ? rho_k : ones.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->sched + n, q_k ? q_k : ones.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    h->sched_n = n;
+    if (rho_k) h->sp.rho_sched = h->sched;
+    if (q_k) h->sp.q_sched = h->sched + n;
+  }
+  destroy_graph(h);      // the graph's kernel nodes carry StepParams by value
+  h->need_prep = true;
+  return PSMF_OK;
+}
+
+int psmf_step_host(psmf_handle h, int64_t k, const double* mu_bar, const double* P_bar, double* mu_out, double* gf_out,
+                   double* P_out, double* Q_out) {
+  if (!h || !mu_bar || !P_bar) return PSMF_ERR_ARG;
+  if (h->cfg.dyn_kind != PSMF_DYN_HOST) return fail(h, PSMF_ERR_STATE, "psmf_step_host: the handle was not created with dyn_kind = PSMF_DYN_HOST");
+  if (!h->have_state) return fail(h, PSMF_ERR_STATE, "psmf_step_host: set_state (C, V, P, mu) first");
+  if (!h->Y) return fail(h, PSMF_ERR_STATE, "psmf_step_host: upload_series first");
+  if (k < 0 || k >= h->T_cap) return fail(h, PSMF_ERR_ARG, "psmf_step_host: step outside the uploaded series");
+  if (h->sched && k + 1 >= h->sched_n) return fail(h, PSMF_ERR_ARG, "psmf_step_host: step beyond the R / Q schedules");
+  int rc = set_device(h);
+  if (rc) return rc;
+  const int r = h->cfg.r;
+  if (h->need_prep || h->k_done != k) {
+    hipLaunchKernelGGL(psmf::psmf_prepare_k, dim3(1), dim3(1), 0, h->stream, h->st, (long long)k);
+    if (h->mu_hist)
+      HIP_TRY(h, hipMemcpyAsync(h->mu_hist + (size_t)(k - h->sp.series_t0) * r, h->st->mu, r * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    if (h->sp.track_g) { rc = enqueue_gram(h); if (rc) return rc; }
+    h->need_prep = false;
+    h->k_done = k;
+  }
+  HIP_TRY(h, hipMemcpyAsync(h->st->mu_bar, mu_bar, r * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  HIP_TRY(h, hipMemcpyAsync(h->st->Pbar, P_bar, (size_t)r * r * sizeof(double), hipMemcpyHostToDevice, h->stream));
+  launch_serial(h, 1);          // w, s, eta, N, kappa of this step from the uploaded mu_bar, P_bar
+  rc = enqueue_step(h);         // row sweep (+ r x r solve), all-reduce, serial stage (stops before the next prediction)
+  if (rc) return rc;
+  HIP_TRY(h, hipGetLastError());
+  h->k_done = k + 1;
+  rc = psmf_sync(h);
+  if (rc) return rc;
+  if (mu_out) HIP_TRY(h, hipMemcpy(mu_out, h->st->mu, r * sizeof(double), hipMemcpyDeviceToHost));
+  if (gf_out) HIP_TRY(h, hipMemcpy(gf_out, h->st->gf, r * sizeof(double), hipMemcpyDeviceToHost));
+  if (P_out) HIP_TRY(h, hipMemcpy(P_out, h->st->P, (size_t)r * r * sizeof(double), hipMemcpyDeviceToHost));
+  if (Q_out) HIP_TRY(h, hipMemcpy(Q_out, h->st->Q, (size_t)r * r * sizeof(double), hipMemcpyDeviceToHost));
+  return PSMF_OK;
+}
+
+int psmf_measure_copy_bandwidth(int device, size_t bytes, int iters, double* gbps) {
+  if (!gbps || iters < 1 || bytes < (size_t)1 << 20) return fail(nullptr, PSMF_ERR_ARG, "psmf_measure_copy_bandwidth: bad argument");
+  psmf_handle h = nullptr;       // errors go to the create-error slot
+  HIP_TRY(h, hipSetDevice(device));
+  const size_t n16 = bytes / 16;
+  void *src = nullptr, *dst = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipStream_t s = nullptr;
+  HIP_TRY(h, hipMalloc(&src, n16 * 16));
+  HIP_TRY(h, hipMalloc(&dst, n16 * 16));
+  HIP_TRY(h, hipMemset(src, 1, n16 * 16));
+  HIP_TRY(h, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  HIP_TRY(h, hipEventCreate(&e0));
+  HIP_TRY(h, hipEventCreate(&e1));
+  const int grid = 256 * 16;     // 16 workgroups per CU
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(psmf::psmf_copy_k, dim3(grid), dim3(psmf::WG), 0, s, (const float4*)src, (float4*)dst, n16);
+  HIP_TRY(h, hipEventRecord(e0, s));
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(psmf::psmf_copy_k, dim3(grid), dim3(psmf::WG), 0, s, (const float4*)src, (float4*)dst, n16);
+  HIP_TRY(h, hipEventRecord(e1, s));
+  HIP_TRY(h, hipEventSynchronize(e1));
+  float ms = 0.f;
+  HIP_TRY(h, hipEventElapsedTime(&ms, e0, e1));
+  *gbps = 2.0 * (double)(n16 * 16) * iters / (ms * 1e-3) / 1e9;     // read + write
+  hipEventDestroy(e0); hipEventDestroy(e1); hipStreamDestroy(s); hipFree(src); hipFree(dst);
   return PSMF_OK;
 }
 

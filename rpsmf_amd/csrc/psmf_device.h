@@ -26,7 +26,7 @@ struct DevState {
   double mu_bar[RM];      // predictive mean of the current step
   double w[RM];           // V mu_bar
   double wN[RM];          // w / N   (rank-1 update direction used by the row sweep)
-  double theta[RM], gradsum[RM], adam_m[RM], adam_v[RM];
+  double gf[RM];          // d(incremental likelihood)/d f of the last finished step (host-stepped dynamics: the host forms J_theta^T gf)
   double red[RM + 8];     // h[0..r), ee at [r]: all-reduced partial sums (multi-GPU path)
   double rho, lam;        // running diag(R) (uniform) and Student-t dof
   double s, eta, N, kappa;  // scalars of the current step
@@ -58,6 +58,17 @@ struct StepParams {
   int n_sweep_wg, rows_per_wg, ps;
   int robust, coef_update, eta_full, pbar_predict, fixed_lambda;
   int dyn_kind, n_theta, store_yp, recursive, update_every, track_g;
+  // parameters of the dynamics, their summed gradient and Adam moments: n_theta doubles each, global memory (psmf_dyn.hip)
+  double* theta;
+  double* gradsum;
+  double* adam_m;
+  double* adam_v;
+  int dyn_flags;        // SCALED_WALK: bit 0 = bias; SINUSOID: bit 0 = scaled (matrix A), bit 1 = phased (gains c)
+  int dyn_terms;        // FOURIER: N
+  // per-step schedules of PSMFIter's Q[k], R[k] (psmf.py:115,123,141): R_k = rho_sched[k] I, Q_k = q_sched[k] * Q; index = 1-based
+  // step; nullptr = constant
+  const double* rho_sched;
+  const double* q_sched;
   int external_reduce;  // 1: partial sums were reduced into st->red (multi-GPU)
   int use_ns;           // 1: Newton-Schulz refinement of the r x r inverses (f64 MFMA), sweep as fallback
   double alpha, beta, lr, lr_end, lr_steps, b1, b2;

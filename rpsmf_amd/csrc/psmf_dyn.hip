@@ -1,0 +1,195 @@
+// State-transition functions f(theta, x, t) of the filter evaluated on the device, with analytic Jacobians
+// (the reference differentiates them with autograd: pypsmf/psmf/psmf.py:41-44,107-115,167-177):
+//
+//   PSMF_DYN_RANDOM_WALK  f = x                                              nonlinearities.py:42-56
+//   PSMF_DYN_COS_PHASE    f = cos(2 pi theta t + x)                          ExperimentSynthetic/synthetic_psmf.py:105-106
+//   PSMF_DYN_SCALED_WALK  f = A x (+ b)                                      nonlinearities.py:59-78
+//   PSMF_DYN_SINUSOID     f = [A] sin(2 pi b t + [c o] x)                    nonlinearities.py:81-114
+//   PSMF_DYN_FOURIER      f = sum_n A_n sin(2 pi b_n t + c_n o x) + D_n cos(2 pi e_n t + f_n o x)    nonlinearities.py:117-150
+//
+// All but the scaled walk are sums of TERMS  M_t trig_t(2 pi b_t t + c_t o x)  (M_t an r x r matrix or the identity, c_t a
+// gain vector or ones, trig_t = sin or cos); theta packs the blocks in the reference's order (`dims`).  Per step the
+// filter needs  mu_bar = f(theta, mu, k),  F = df/dx  (P_bar = F P F^T + Q)  and, for the theta gradient,
+// J_theta^T g_f with g_f = d(incremental likelihood)/df:
+//     dF:        F[i][j]      = sum_t M_t[i][j] trig_t'(arg_tj) c_tj
+//     d/dM_t:    g[i][j]     += g_f[i] trig_t(arg_tj)
+//     d/db_t:    g[j]        += (M_t^T g_f)_j trig_t'(arg_tj) 2 pi k
+//     d/dc_t:    g[j]        += (M_t^T g_f)_j trig_t'(arg_tj) x_j
+// Everything here is O(r^2) per term and runs inside the one-workgroup r x r stage of the blocked engine
+// (psmf_blk_filter); theta, the summed gradient and the Adam moments live in global memory (StepParams.theta ...:
+// n_theta can be 2 N r^2 + 4 N r), every element always touched by the same thread.
+#pragma once
+#include "psmf_device.h"
+
+namespace psmf {
+
+constexpr int DYN_RANDOM_WALK = 0, DYN_COS_PHASE = 1, DYN_SCALED_WALK = 2, DYN_SINUSOID = 3, DYN_FOURIER = 4, DYN_HOST = 5;
+constexpr int DYN_MAX_TERMS = 8;     // Fourier: 2 N terms, N <= 4
+
+struct DynTerm {
+  int m_off, b_off, c_off;   // offsets into theta; -1: identity matrix / unit gains
+  int is_cos;
+};
+
+__host__ __device__ inline int dyn_n_terms(int kind, int nterms_cfg) {
+  return kind == DYN_COS_PHASE || kind == DYN_SINUSOID ? 1 : (kind == DYN_FOURIER ? 2 * nterms_cfg : 0);
+}
+
+// dense Jacobian?  (otherwise F is diagonal)
+__host__ __device__ inline bool dyn_dense(int kind, int flags) {
+  return kind == DYN_SCALED_WALK || kind == DYN_FOURIER || (kind == DYN_SINUSOID && (flags & 1));
+}
+
+__host__ __device__ inline int dyn_n_theta(int kind, int flags, int N, int r) {
+  switch (kind) {
+    case DYN_COS_PHASE: return r;
+    case DYN_SCALED_WALK: return r * r + ((flags & 1) ? r : 0);
+    case DYN_SINUSOID: return ((flags & 1) ? r * r : 0) + r + ((flags & 2) ? r : 0);
+    case DYN_FOURIER: return N * (2 * r * r + 4 * r);
+    default: return 0;
+  }
+}
+
+__host__ __device__ inline DynTerm dyn_term(int kind, int flags, int N, int r, int t) {
+  DynTerm d = {-1, 0, -1, 0};
+  if (kind == DYN_COS_PHASE) { d.is_cos = 1; }
+  else if (kind == DYN_SINUSOID) {
+    int o = 0;
+    if (flags & 1) { d.m_off = 0; o = r * r; }
+    d.b_off = o;
+    if (flags & 2) d.c_off = o + r;
+  } else if (kind == DYN_FOURIER) {       // term t = 2 n (sin, A_n, b_n, c_n) or 2 n + 1 (cos, D_n, e_n, f_n)
+    const int n = t >> 1, odd = t & 1;
+    d.m_off = t * r * r;
+    d.b_off = 2 * N * r * r + (4 * n + 2 * odd) * r;
+    d.c_off = d.b_off + r;
+    d.is_cos = odd;
+  }
+  return d;
+}
+
+// Forward pass, all NTH threads of the workgroup; ends with a barrier.
+//   s_x    mu_{k-1} (LDS, r)             s_mub  out: mu_bar (r)
+//   s_fd   out: diagonal of F when !dense (r)
+//   sF     out: dense F, row stride ldf, when dense
+//   s_val, s_tp   out: [term][RM] trig(arg), trig'(arg) for the gradient
+template <int NTH>
+__device__ __forceinline__ void dyn_forward(const StepParams& p, const double tk, const double* s_x, double* s_mub, double* s_fd,
+                                            double* sF, const int ldf, double* s_val, double* s_tp, const int tid) {
+  const int r = p.r, kind = p.dyn_kind, flags = p.dyn_flags, N = p.dyn_terms;
+  const double* th = p.theta;
+  if (kind == DYN_RANDOM_WALK) {
+    if (tid < r) { s_mub[tid] = s_x[tid]; s_fd[tid] = 1.0; }
+    __syncthreads();
+    return;
+  }
+  if (kind == DYN_SCALED_WALK) {
+    if (tid < r) {
+      double a = (flags & 1) ? th[r * r + tid] : 0.0;
+      for (int j = 0; j < r; ++j) a += th[tid * r + j] * s_x[j];
+      s_mub[tid] = a;
+    }
+    for (int idx = tid; idx < r * r; idx += NTH) sF[(idx / r) * ldf + idx % r] = th[idx];
+    __syncthreads();
+    return;
+  }
+  const int nt = dyn_n_terms(kind, N);
+  for (int idx = tid; idx < nt * r; idx += NTH) {
+    const int t = idx / r, j = idx - t * r;
+    const DynTerm d = dyn_term(kind, flags, N, r, t);
+    const double c = d.c_off >= 0 ? th[d.c_off + j] : 1.0;
+    const double arg = 2.0 * M_PI * th[d.b_off + j] * tk + c * s_x[j];
+    double sn, cs;
+    sincos(arg, &sn, &cs);
+    s_val[t * RM + j] = d.is_cos ? cs : sn;
+    s_tp[t * RM + j] = d.is_cos ? -sn : cs;
+  }
+  __syncthreads();
+  const bool dense = dyn_dense(kind, flags);
+  if (tid < r) {
+    double a = 0.0, fd = 0.0;
+    for (int t = 0; t < nt; ++t) {
+      const DynTerm d = dyn_term(kind, flags, N, r, t);
+      if (d.m_off >= 0) {
+        for (int j = 0; j < r; ++j) a += th[d.m_off + tid * r + j] * s_val[t * RM + j];
+      } else {
+        a += s_val[t * RM + tid];
+        fd += s_tp[t * RM + tid] * (d.c_off >= 0 ? th[d.c_off + tid] : 1.0);
+      }
+    }
+    s_mub[tid] = a;
+    if (!dense) s_fd[tid] = fd;
+  }
+  if (dense) {
+    for (int idx = tid; idx < r * r; idx += NTH) {
+      const int j = idx % r;
+      double a = 0.0;
+      for (int t = 0; t < nt; ++t) {
+        const DynTerm d = dyn_term(kind, flags, N, r, t);
+        const double dv = s_tp[t * RM + j] * (d.c_off >= 0 ? th[d.c_off + j] : 1.0);
+        a += (d.m_off >= 0 ? th[d.m_off + idx] : ((idx / r == j) ? 1.0 : 0.0)) * dv;
+      }
+      sF[(idx / r) * ldf + j] = a;
+    }
+  }
+  __syncthreads();
+}
+
+// Gradient pass: gradsum += J_theta^T g_f.  s_gf: g_f (LDS, r), s_x: mu_{k-1}, s_u: scratch (RM).  All NTH threads; the
+// caller has a barrier between writing s_gf and this call; ends with a barrier.
+template <int NTH>
+__device__ __forceinline__ void dyn_backward(const StepParams& p, const double tk, const double* s_x, const double* s_gf,
+                                             const double* s_val, const double* s_tp, double* s_u, const int tid) {
+  const int r = p.r, kind = p.dyn_kind, flags = p.dyn_flags, N = p.dyn_terms;
+  const double* th = p.theta;
+  double* g = p.gradsum;
+  if (kind == DYN_RANDOM_WALK) return;
+  if (kind == DYN_SCALED_WALK) {
+    for (int idx = tid; idx < r * r; idx += NTH) g[idx] += s_gf[idx / r] * s_x[idx % r];
+    if ((flags & 1) && tid < r) g[r * r + tid] += s_gf[tid];
+    __syncthreads();
+    return;
+  }
+  const int nt = dyn_n_terms(kind, N);
+  for (int t = 0; t < nt; ++t) {
+    const DynTerm d = dyn_term(kind, flags, N, r, t);
+    if (d.m_off >= 0) {
+      for (int idx = tid; idx < r * r; idx += NTH) g[d.m_off + idx] += s_gf[idx / r] * s_val[t * RM + idx % r];
+      if (tid < r) {
+        double u = 0.0;
+        for (int i = 0; i < r; ++i) u += th[d.m_off + i * r + tid] * s_gf[i];
+        s_u[tid] = u;
+      }
+    } else if (tid < r) {
+      s_u[tid] = s_gf[tid];
+    }
+    if (tid < r) {          // (the same thread wrote s_u[tid])
+      const double ut = s_u[tid] * s_tp[t * RM + tid];
+      g[d.b_off + tid] += ut * (2.0 * M_PI * tk);
+      if (d.c_off >= 0) g[d.c_off + tid] += ut * s_x[tid];
+    }
+  }
+  __syncthreads();
+}
+
+// Adam step on theta inside the time loop (PSMFRecursive, psmf.py:224-242,299-304): bias correction with the step index,
+// projection theta >= 0, gradient sum restarted.  All NTH threads; ends with a barrier.
+template <int NTH>
+__device__ __forceinline__ void dyn_adam_step(const StepParams& p, const long long knext, const int tid) {
+  const double kk = (double)knext;
+  const double lr = p.lr_steps > 0.0 ? p.lr * pow(p.lr_end / p.lr, kk / p.lr_steps) : p.lr;
+  const double c1 = 1.0 / (1.0 - pow(p.b1, kk)), c2 = 1.0 / (1.0 - pow(p.b2, kk));
+  for (int idx = tid; idx < p.n_theta; idx += NTH) {
+    const double gs = p.gradsum[idx];
+    const double am = p.b1 * p.adam_m[idx] + (1.0 - p.b1) * gs;
+    const double av = p.b2 * p.adam_v[idx] + (1.0 - p.b2) * gs * gs;
+    p.adam_m[idx] = am;
+    p.adam_v[idx] = av;
+    p.theta[idx] = fmax(p.theta[idx] - lr * (am * c1) / (sqrt(av * c2) + 1e-8), 0.0);
+    p.gradsum[idx] = 0.0;
+  }
+  __threadfence_block();
+  __syncthreads();
+}
+
+}  // namespace psmf

@@ -426,10 +426,13 @@ __device__ __forceinline__ void serial_body(const StepParams& p, const int first
   const long long k0 = st->k;       // read once (thread 0 rewrites it below)
   long long knext = k0;             // index (0-based) of the step to prepare
   const bool vl = tid < r;
-  const bool tl = tid < p.n_theta;
+  // the per-step engine evaluates the random walk and cos(2 pi theta t + x) itself (n_theta = r); every other f is
+  // host-stepped here (dyn_kind 5: mu_bar, P_bar come from the host, g_f goes back) or runs in the blocked engine
+  const bool host_dyn = p.dyn_kind == 5;
+  const bool tl = tid < p.n_theta && p.dyn_kind == 1;
   const int tc = tid & (RM - 1);   // every r-sized array has RM entries: load unconditionally, mask afterwards
-  const double l_mu = st->mu[tc], l_w = st->w[tc], l_mub = st->mu_bar[tc], l_th = st->theta[tc], l_gs = st->gradsum[tc],
-               l_am = st->adam_m[tc], l_av = st->adam_v[tc];
+  const double l_mu = st->mu[tc], l_w = st->w[tc], l_mub = st->mu_bar[tc], l_th = p.theta[tc], l_gs = p.gradsum[tc],
+               l_am = p.adam_m[tc], l_av = p.adam_v[tc];
   double mu_new = vl ? l_mu : 0.0;
   const double mu_old = mu_new;
   const double w_t = vl ? l_w : 0.0;
@@ -507,6 +510,15 @@ __device__ __forceinline__ void serial_body(const StepParams& p, const int first
       }
       gsum += jt * gf;
     }
+    if (host_dyn && vl) {     // g_f for the host, which holds J_theta (same closed forms)
+      const double wi = w_t, hi = s_he[tid];
+      if (p.robust) {
+        const double D = lam * N;
+        st->gf[tid] = dd * wi / N + 0.5 * (dd + lam) * (-2.0 * hi / D - 2.0 * lam * ee * wi / (D * D)) / (1.0 + ee / D);
+      } else {
+        st->gf[tid] = dd * wi / N - hi / N - ee * wi / (N * N);
+      }
+    }
 
     // ---- robust scalars   rpsmf.py:133-171 ----
     double vscale = 1.0, pscale = 1.0, qscale = 1.0, phi = 1.0, omega = 1.0;
@@ -548,15 +560,15 @@ __device__ __forceinline__ void serial_body(const StepParams& p, const int first
         const double lr = p.lr_steps > 0.0 ? p.lr * pow(p.lr_end / p.lr, kk / p.lr_steps) : p.lr;
         am = p.b1 * am + (1.0 - p.b1) * gsum;
         av = p.b2 * av + (1.0 - p.b2) * gsum * gsum;
-        st->adam_m[tid] = am;
-        st->adam_v[tid] = av;
+        p.adam_m[tid] = am;
+        p.adam_v[tid] = av;
         const double mh = am / (1.0 - pow(p.b1, kk));
         const double vh = av / (1.0 - pow(p.b2, kk));
         theta = fmax(theta - lr * mh / (sqrt(vh) + 1e-8), 0.0);
-        st->theta[tid] = theta;
+        p.theta[tid] = theta;
         gsum = 0.0;
       }
-      st->gradsum[tid] = gsum;
+      p.gradsum[tid] = gsum;
     }
     if (vl) {
       st->mu[tid] = mu_new;
@@ -574,12 +586,16 @@ __device__ __forceinline__ void serial_body(const StepParams& p, const int first
       st->eta_done = eta0;
       st->N_done = N;
     }
+    if (host_dyn) return;        // the host evaluates f for the next step, then launches this stage with first = 1
   } else {
     if (!worker) return;
   }
 
   PSMF_STAMP(5);
   // =============== everything the NEXT sweep / solve needs (step index knext + 1) ===========
+  // PSMFIter reads Q[k], R[k] of the step itself (psmf.py:115,123,141): scalar schedules (never with rPSMF's running Q, R)
+  const double qs = p.q_sched ? p.q_sched[knext + 1 - p.series_t0] : 1.0;
+  if (p.rho_sched) rho = p.rho_sched[knext + 1 - p.series_t0];
   if (vl) {
     double mb = mu_new, f = 1.0;
     if (p.dyn_kind == 1) {   // cos(2 pi theta t + x)
@@ -587,6 +603,7 @@ __device__ __forceinline__ void serial_body(const StepParams& p, const int first
       mb = cos(arg);
       f = -sin(arg);
     }
+    if (host_dyn) mb = mub_t;     // mu_bar of the step as the host uploaded it
     s_mub[tid] = mb;         // (the current step's mu_bar was consumed from registers above)
     s_f[tid] = f;
     st->mu_bar[tid] = mb;
@@ -596,8 +613,9 @@ __device__ __forceinline__ void serial_body(const StepParams& p, const int first
 #pragma unroll
   for (int m = 0; m < M; ++m) {
     if (val[m]) {
-      const double pb = p.pbar_predict ? s_f[ii[m]] * Pv[m] * s_f[j] + Qv[m] : Pv[m];
-      st->Pbar[ii[m] * r + j] = pb;
+      double pb = p.pbar_predict ? s_f[ii[m]] * Pv[m] * s_f[j] + qs * Qv[m] : Pv[m];
+      if (host_dyn) pb = 0.5 * (st->Pbar[ii[m] * r + j] + st->Pbar[j * r + ii[m]]);   // P_bar = F P F^T + Q as the host formed it
+      else st->Pbar[ii[m] * r + j] = pb;
       part += Vv[m] * s_mub[ii[m]];
       gp += Gv[m] * pb;
     }
@@ -727,6 +745,11 @@ __global__ __launch_bounds__(WG) void psmf_predict_rows(const T* __restrict__ C,
       }
     }
   }
+}
+
+// plain streaming copy (16-byte accesses, grid-stride): the measured HBM bandwidth bench.py quotes beside the nominal peak
+__global__ __launch_bounds__(WG) void psmf_copy_k(const float4* __restrict__ src, float4* __restrict__ dst, size_t n16) {
+  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n16; i += (size_t)gridDim.x * WG) dst[i] = src[i];
 }
 
 // sum of squared prediction errors over a block of steps (tracking.py:63-76 norms)

@@ -58,7 +58,7 @@ def impute_batch(YorgInt, M, Mmiss, C0, X0, V, Q, R, P, sig, Iter, robust=False,
     Yt = np.ascontiguousarray(YorgInt.T)
     Mt = np.ascontiguousarray(np.transpose(M != 0, (0, 2, 1)).astype(np.uint8))
     Mmt = np.ascontiguousarray(np.transpose(Mmiss != 0, (0, 2, 1)).astype(np.uint8))
-    Cb = np.ascontiguousarray(C0)
+    Cb = np.array(C0, dtype=np.float64, order="C", copy=True)   # the device writes the final C here; the caller's C0 is NOT mutated (PSMF.py:80 rebinds C)
     Xb = np.ascontiguousarray(np.transpose(X0, (0, 2, 1)))
     Vm, Pm, Qm = (np.ascontiguousarray(np.asarray(a, dtype=np.float64)).reshape(r, r) for a in (V, P, Q))
     Epred = np.zeros((B, Iter))

@@ -16,7 +16,7 @@ import numpy as np
 
 from . import _capi
 
-__all__ = ["BaseNonLinearity", "RandomWalk", "CosPhase", "Sinusoid", "FourierBasis", "wrap_nonlinearity"]
+__all__ = ["BaseNonLinearity", "RandomWalk", "CosPhase", "ScaledWalk", "Sinusoid", "FourierBasis", "wrap_nonlinearity"]
 
 
 def _col(v):
@@ -24,7 +24,9 @@ def _col(v):
 
 
 class BaseNonLinearity:
-    device_kind = None
+    device_kind = None     # psmf_dyn_kind evaluated inside the device time loop, or None: host-stepped (psmf_step_host)
+    device_flags = 0
+    device_terms = 0
 
     def __init__(self, rank):
         self.rank = int(rank)
@@ -113,13 +115,102 @@ class CosPhase(BaseNonLinearity):
         return np.diag(-np.sin(self._arg(theta, x, t)) * (2.0 * np.pi * t))
 
 
-class Sinusoid(BaseNonLinearity):
+class ScaledWalk(BaseNonLinearity):
+    """f = A x (+ b): pypsmf/psmf/nonlinearities.py:59-78.  theta packs [A (r*r, row-major)] [b (r) if bias].
+    (The reference declares dims = ["r*r"] and then unpacks two blocks, so its own class raises whatever `bias` is and no
+    experiment uses it; this one is the function its docstring describes.)"""
+
+    device_kind = _capi.DYN_SCALED_WALK
+
+    def __init__(self, rank, bias=True):
+        super().__init__(rank)
+        self.bias = bool(bias)
+        self.device_flags = 1 if self.bias else 0
+
+    @property
+    def n_params(self):
+        r = self.rank
+        return r * r + (r if self.bias else 0)
+
+    def _unpack(self, theta):
+        r = self.rank
+        th = np.asarray(theta).reshape(-1)
+        return th[:r * r].reshape(r, r), (th[r * r:r * r + r].reshape(r, 1) if self.bias else 0.0)
+
+    def __call__(self, theta, x, t):
+        A, b = self._unpack(theta)
+        return A @ _col(x) + b
+
+    def jac_x(self, theta, x, t):
+        return np.array(self._unpack(theta)[0], dtype=float)
+
+    def jac_theta(self, theta, x, t):
+        r = self.rank
+        xx = np.asarray(x, dtype=float).reshape(-1)
+        J = np.zeros((r, self.n_params))
+        for i in range(r):
+            J[i, i * r:(i + 1) * r] = xx            # d f_i / d A_ij = x_j
+        if self.bias:
+            J[:, r * r:] = np.eye(r)
+        return J
+
+
+class _TrigTerms(BaseNonLinearity):
+    """Shared algebra of Sinusoid / FourierBasis: f = sum_t M_t trig_t(2 pi b_t t + c_t o x), M_t a matrix or the identity,
+    c_t gains or ones -- the term structure of rpsmf_amd/csrc/psmf_dyn.hip.  Subclasses provide `_terms(theta)` ->
+    [(M or None, b (r,), c (r,) or None, is_cos, offsets (m_off, b_off, c_off))]."""
+
+    def _eval(self, theta, x, t):
+        xx = np.asarray(x, dtype=float).reshape(-1)
+        out = []
+        for M, b, c, is_cos, offs in self._terms(theta):
+            arg = 2.0 * np.pi * b * t + (c if c is not None else 1.0) * xx
+            val, tp = (np.cos(arg), -np.sin(arg)) if is_cos else (np.sin(arg), np.cos(arg))
+            out.append((M, b, c, val, tp, offs))
+        return xx, out
+
+    def jac_x(self, theta, x, t):
+        r = self.rank
+        _, terms = self._eval(theta, x, t)
+        F = np.zeros((r, r))
+        for M, b, c, val, tp, offs in terms:
+            dv = tp * (c if c is not None else 1.0)
+            F += (M if M is not None else np.eye(r)) * dv[None, :]
+        return F
+
+    def jac_theta(self, theta, x, t):
+        r = self.rank
+        xx, terms = self._eval(theta, x, t)
+        J = np.zeros((r, self.n_params))
+        for M, b, c, val, tp, (m_off, b_off, c_off) in terms:
+            Mm = M if M is not None else np.eye(r)
+            if M is not None:
+                for i in range(r):
+                    J[i, m_off + i * r:m_off + (i + 1) * r] = val      # d f_i / d M_ij = trig(arg_j)
+            J[:, b_off:b_off + r] = Mm * (tp * 2.0 * np.pi * t)[None, :]
+            if c is not None:
+                J[:, c_off:c_off + r] = Mm * (tp * xx)[None, :]
+        return J
+
+
+class Sinusoid(_TrigTerms):
     """f = A sin(2 pi b t + c * x) with optional mixing matrix A (scaled) and gains c (phased).
     theta packs [A (r*r, row-major)] [b (r)] [c (r)] in that order."""
+
+    device_kind = _capi.DYN_SINUSOID
 
     def __init__(self, rank, scaled=True, phased=True):
         super().__init__(rank)
         self.scaled, self.phased = bool(scaled), bool(phased)
+        self.device_flags = (1 if self.scaled else 0) | (2 if self.phased else 0)
+
+    def _terms(self, theta):
+        r = self.rank
+        th = np.asarray(theta, dtype=float).reshape(-1)
+        o = r * r if self.scaled else 0
+        A = th[:r * r].reshape(r, r) if self.scaled else None
+        c = th[o + r:o + 2 * r] if self.phased else None
+        return [(A, th[o:o + r], c, False, (0, o, o + r))]
 
     @property
     def n_params(self):
@@ -144,7 +235,7 @@ class Sinusoid(BaseNonLinearity):
         return A @ s if self.scaled else s
 
 
-class FourierBasis(BaseNonLinearity):
+class FourierBasis(_TrigTerms):
     """f = sum_n A_n sin(2 pi b_n t + c_n * x) + D_n cos(2 pi e_n t + f_n * x).
 
     theta packs [A_1, D_1, ..., A_N, D_N (r*r each)] then per n [b_n, c_n, e_n, f_n (r each)],
@@ -153,14 +244,31 @@ class FourierBasis(BaseNonLinearity):
     vectors are kept as columns, which is the same thing at r = 1 and well-defined for r > 1.)
     """
 
+    device_kind = _capi.DYN_FOURIER
+
     def __init__(self, rank, N=1):
         super().__init__(rank)
         self.N = int(N)
+        self.device_terms = self.N
+        if self.N > 4:
+            self.device_kind = None      # the device evaluates up to 4 sin + 4 cos terms; more: host-stepped
 
     @property
     def n_params(self):
         r = self.rank
         return self.N * (2 * r * r + 4 * r)
+
+    def _terms(self, theta):
+        r, N = self.rank, self.N
+        th = np.asarray(theta, dtype=float).reshape(-1)
+        out = []
+        for t in range(2 * N):
+            n, odd = t >> 1, t & 1
+            m_off = t * r * r
+            b_off = 2 * N * r * r + (4 * n + 2 * odd) * r
+            out.append((th[m_off:m_off + r * r].reshape(r, r), th[b_off:b_off + r], th[b_off + r:b_off + 2 * r], bool(odd),
+                        (m_off, b_off, b_off + r)))
+        return out
 
     def __call__(self, theta, x, t):
         r, N = self.rank, self.N

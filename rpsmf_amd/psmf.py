@@ -394,38 +394,82 @@ class PSMFIter:
             raise TypeError(
                 f"{type(self).__name__} overrides {lost}: with backend='hip' the whole time loop runs on the device and "
                 "these methods are never called.  Use backend='numpy'.")
-        if self._nl.device_kind is None:
-            raise TypeError(
-                "the nonlinearity is not one the device evaluates (RandomWalk, CosPhase); wrap it in one of those "
-                "or construct with backend='numpy'")
         if self._r > _capi.RMAX:
             raise ValueError(f"r = {self._r} > {_capi.RMAX}")
 
-    def _uniform_scalar(self, D, what):
-        """The device path takes a constant, uniform-diagonal R and a constant Q."""
-        keys = sorted(D.keys()) if isinstance(D, dict) else None
-        vals = [D[k] for k in keys] if keys is not None else [D]
-        first = vals[0]
-        for v in vals[1:]:
-            if v is not first and not np.array_equal(np.asarray(v), np.asarray(first)):
-                raise NotImplementedError(f"time-varying {what} is only supported by backend='numpy'")
-        return first
-
-    def _device_rho_q(self):
-        R0 = self._uniform_scalar(self._R, "R")
-        dg = _diag_of(R0, self._d)
+    def _rho_of(self, Rk):
+        dg = _diag_of(Rk, self._d)
         rho = None if dg is None else _as_scalar_if_uniform(dg)
         if rho is None:
-            raise NotImplementedError("the device path needs R = rho * I (uniform diagonal); use backend='numpy'")
-        Q = np.asarray(self._uniform_scalar(self._Q, "Q"), dtype=float)
-        if Q.ndim == 0:
-            Q = float(Q) * np.eye(self._r)
-        return rho, Q
+            raise NotImplementedError("the device path needs R_k = rho_k * I (uniform diagonal); use backend='numpy'")
+        return rho
+
+    def _q_matrix(self, Qk):
+        Q = np.asarray(Qk, dtype=float)
+        return float(Q) * np.eye(self._r) if Q.ndim == 0 else Q.reshape(self._r, self._r)
+
+    def _device_rho_q(self, T=None):
+        """(rho, Q, rho_sched, q_sched) for the device: PSMFIter reads R[k], Q[k] of step k (psmf.py:115,123,141).
+        Constant dictionaries give (rho, Q, None, None); R_k = rho_k I and Q_k = q_k Q_1 give per-step scalar schedules
+        (index k, entry 0 unused); a Q[k] that is not a multiple of Q[1] returns q_sched = "host" (the host-stepped mode
+        forms P_bar itself and takes any Q[k])."""
+        R, Q = self._R, self._Q
+        ks = list(range(1, (T or 0) + 1))
+        if not isinstance(R, dict):
+            R = {k: R for k in [0] + ks}
+        if not isinstance(Q, dict):
+            Q = {k: Q for k in [0] + ks}
+        k1 = 1 if 1 in R else min(R.keys())
+        rho1 = self._rho_of(R[k1])
+        Q1 = self._q_matrix(Q[1 if 1 in Q else min(Q.keys())])
+        rho_s = q_s = None
+        seen_R, seen_Q = {id(R[k1]): rho1}, {}
+        for k in ks:
+            Rk = R[k]
+            if id(Rk) not in seen_R:
+                seen_R[id(Rk)] = self._rho_of(Rk)
+            rk = seen_R[id(Rk)]
+            if rk != rho1 and rho_s is None:
+                rho_s = np.full(len(ks) + 1, rho1)
+            if rho_s is not None:
+                rho_s[k] = rk
+            Qk = Q[k]
+            if id(Qk) not in seen_Q:
+                Qm = self._q_matrix(Qk)
+                if np.array_equal(Qm, Q1):
+                    seen_Q[id(Qk)] = 1.0
+                else:
+                    nz = np.flatnonzero(Q1)
+                    c = Qm.reshape(-1)[nz[0]] / Q1.reshape(-1)[nz[0]] if nz.size else np.nan
+                    seen_Q[id(Qk)] = float(c) if np.isfinite(c) and np.allclose(Qm, c * Q1, rtol=1e-14, atol=0.0) else "host"
+            qk = seen_Q[id(Qk)]
+            if qk == "host":
+                q_s = "host"
+            elif q_s != "host":
+                if qk != 1.0 and q_s is None:
+                    q_s = np.ones(len(ks) + 1)
+                if q_s is not None:
+                    q_s[k] = qk
+        return rho1, Q1, rho_s, q_s
+
+    def _host_stepped(self):
+        """True when f is evaluated on the host, one device step at a time (psmf_step_host): arbitrary callables, kinds the
+        chosen engine does not evaluate (scaled walk / sinusoid / Fourier need the blocked engine: r <= 32), or a Q[k]
+        schedule that is not a scalar multiple of Q[1]."""
+        kind = self._nl.device_kind
+        if kind is None or getattr(self, "_force_host_stepped", False):
+            return True
+        general = kind in (_capi.DYN_SCALED_WALK, _capi.DYN_SINUSOID, _capi.DYN_FOURIER)
+        return general and (self._r > 32 or self._dev_opts.get("engine") == "step")
 
     def _device_kwargs(self):
         coef, eta_full, pbar = HIP_MODES[self.hip_mode]
-        return dict(robust=self.robust, coef_update=coef, eta_full=eta_full, pbar_predict=pbar,
-                    dyn_kind=self._nl.device_kind, **self._dev_opts)
+        kw = dict(robust=self.robust, coef_update=coef, eta_full=eta_full, pbar_predict=pbar, **self._dev_opts)
+        if self._host_stepped():
+            kw.update(dyn_kind=_capi.DYN_HOST, engine="step")
+        else:
+            kw.update(dyn_kind=self._nl.device_kind, dyn_flags=self._nl.device_flags, dyn_terms=self._nl.device_terms)
+        return kw
 
     def _ensure_device(self):
         if self._dev is None:
@@ -457,15 +501,19 @@ class PSMFIter:
         self._dev.upload_series(Y, t0=0, T_total=T)
         self._series_key = key
 
-    def _push_state(self, i):
+    def _push_state(self, i, T=None):
         dev = self._dev
         C0 = self._C.raw(0)
         same_C = isinstance(C0, _Lazy) and C0.owner is self and C0.epoch == self._dev_epoch
-        rho, Q = self._device_rho_q()
+        rho, Q, rho_s, q_s = self._device_rho_q(T)
         theta = np.asarray(self._theta[i - 1], dtype=float).reshape(-1)
         dev.set_state(None if same_C else np.asarray(C0, dtype=float), self._V[0], self._P[0], Q,
                       np.asarray(self._mu[0]).reshape(-1), rho=rho, lambda0=self._device_lambda0(),
-                      theta=theta if theta.size else None)
+                      theta=theta if (theta.size and dev.n_theta) else None)
+        sched = (None if rho_s is None else tuple(rho_s), None if (q_s is None or isinstance(q_s, str)) else tuple(q_s))
+        if sched != getattr(self, "_sched_key", (None, None)):
+            dev.set_schedules(rho_s, None if isinstance(q_s, str) else q_s)
+            self._sched_key = sched
 
     def _device_lambda0(self):
         return 0.0
@@ -478,25 +526,88 @@ class PSMFIter:
         self._V = _StateDict({T: s["V"]})
         self._P = _StateDict({T: s["P"]})
         self._mu = _MuHist(self, T, s["mu"].reshape(-1, 1))
-        if s["gradsum"].size:
+        if s["gradsum"].size == np.asarray(self.theta0).size and s["gradsum"].size:
             self._gradsum = s["gradsum"].reshape(np.asarray(self.theta0).shape)
         self._y_pred = _YPred(self, T)
         return s
 
     def _step_hip(self, y, i, T):
         self.step_reset()
+        if not self._host_stepped() and not self.robust and self._device_rho_q(T)[3] == "host":
+            # Q[k] is not a scalar multiple of Q[1]: the host forms P_bar (any Q[k]); needs a handle of the host-stepped kind
+            self._force_host_stepped = True
+            if self._dev is not None:
+                self._dev.close()
+                self._dev, self._series_key, self._sched_key = None, None, (None, None)
         self._ensure_device()
         self._upload_series(y, T)
-        self._push_state(i)
+        self._push_state(i, T)
+        if self._host_stepped():
+            return self._after_device_epoch(self._run_host_stepped(i, T), T)
         self._dev.zero_gradsum()
         self._dev.run(0, T)
         self._after_device_epoch(self._pull_state(T), T)
+
+    def _q_for_step(self, k, Q_running):
+        """Q entering P_bar of step k: PSMFIter reads Q[k] (psmf.py:115); rPSMFIter its running Q_{k-1} (rpsmf.py:123)."""
+        if self.robust:
+            return Q_running
+        Q = self._Q[k] if isinstance(self._Q, dict) else self._Q
+        return self._q_matrix(Q)
+
+    def _run_host_stepped(self, i, T, recursive=False):
+        """The time loop with f on the host: per step the host evaluates mu_bar = f(theta, mu, k), F = df/dx and
+        P_bar = F P F^T + Q_k (r-sized, psmf.py:104-115), the device does everything d-sized of inner() (psmf_step_host),
+        and the theta gradient is accumulated as J_theta^T g_f from the g_f the device returns (psmf.py:167-177)."""
+        dev, nl, r = self._dev, self._nl, self._r
+        pbar_predict = HIP_MODES[self.hip_mode][2]
+        theta = self._theta[i - 1] if not recursive else self._theta[0]
+        n_th = np.asarray(theta).size
+        mu = np.asarray(self._mu[0], dtype=float).reshape(-1, 1)
+        P = np.asarray(self._P[0], dtype=float)
+        Qrun = self._q_matrix(self.Q0) if self.robust else None
+        grad = np.zeros(np.asarray(self.theta0).shape)
+        for k in range(1, T + 1):
+            mu_bar = np.asarray(nl(theta, mu, k), dtype=float).reshape(-1)
+            if pbar_predict:
+                F = nl.jac_x(theta, mu, k)
+                P_bar = F @ P @ F.T + self._q_for_step(k, Qrun)
+            else:
+                P_bar = P
+            mu_new, gf, P, Qrun_dev = dev.step_host(k - 1, mu_bar, 0.5 * (P_bar + P_bar.T))
+            if self.robust:
+                Qrun = Qrun_dev
+            if n_th:
+                Jt = nl.jac_theta(theta, mu, k)
+                grad = grad + (Jt.T @ gf).reshape(grad.shape)
+            mu = mu_new.reshape(-1, 1)
+            if recursive:
+                self._gradsum = grad
+                if k % self._update_every == 0:
+                    self.optim_update(k)
+                    grad = np.zeros_like(grad)
+                else:
+                    self._carry_theta(k)
+                theta = self._theta[k]
+        s = self._pull_state(T)
+        self._gradsum = grad
+        s["gradsum"] = np.zeros(0)
+        s["theta"] = np.asarray(theta, dtype=float).reshape(-1)
+        return s
 
     def _after_device_epoch(self, s, T):
         pass
 
     def _predict_hip(self, i, T, n_pred):
-        out = self._dev.predict(T, n_pred)
+        if self._host_stepped():
+            theta = self._theta[i - 1] if (i - 1) in self._theta else self._theta[max(self._theta)]
+            mu, roll = self._mu[T], []
+            for k in range(T + 1, T + n_pred + 1):      # psmf.py:183-187 on the host (r-sized), C mu_pred on the device
+                mu = np.asarray(self._nl(theta, mu, k), dtype=float).reshape(-1, 1)
+                roll.append(mu.reshape(-1))
+            out = self._dev.project(np.array(roll)) if roll else np.zeros((0, self._d))
+        else:
+            out = self._dev.predict(T, n_pred)
         for q in range(n_pred):
             dict.__setitem__(self._y_pred, T + q + 1, out[q].reshape(-1, 1))
 
@@ -508,8 +619,6 @@ class PSMFIter:
 
 def _recursive_kwargs(obj, kw):
     """Adds the in-loop Adam configuration (psmf.py:224-242,299-304) to the device options."""
-    if obj.optim != "adam":
-        raise NotImplementedError("the recursive device path implements Adam; use backend='numpy' for SGD")
     gam = getattr(obj, "adam_gam", ConstantLearningRate(1e-3))
     if isinstance(gam, ConstantLearningRate):
         lr = dict(adam_lr=gam.lr)
@@ -517,6 +626,11 @@ def _recursive_kwargs(obj, kw):
         lr = dict(adam_lr=gam.lr_start, adam_lr_end=gam.lr_end, adam_lr_steps=gam.steps)
     else:
         raise NotImplementedError("custom learning-rate schedules need backend='numpy'")
+    if kw.get("dyn_kind") == _capi.DYN_HOST:
+        return kw               # host-stepped: theta and its optimiser (Adam or SGD, any schedule) stay on the host
+    if obj.optim != "adam":
+        raise NotImplementedError("the in-loop optimiser on the device is Adam; SGD runs host-stepped (construct with engine='step' "
+                                  "and a plain-callable nonlinearity) or with backend='numpy'")
     kw.update(recursive=True, update_every=getattr(obj, "_update_every", 1),
               adam_b1=getattr(obj, "adam_b1", 0.9), adam_b2=getattr(obj, "adam_b2", 0.999), **lr)
     return kw
@@ -592,7 +706,9 @@ class PSMFRecursive(PSMFIter):
         self._ensure_device()
         self._upload_series(y, T)
         self._theta = {0: self._theta[0]}
-        self._push_state(1)
+        self._push_state(1, T)
+        if self._host_stepped():
+            return self._after_device_epoch(self._run_host_stepped(1, T, recursive=True), T)
         self._dev.zero_gradsum()
         self._dev.set_adam(self.adam_m.reshape(-1), self.adam_v.reshape(-1))
         self._dev.run(0, T)

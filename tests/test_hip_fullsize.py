@@ -149,7 +149,9 @@ def test_config_D_fifty_seed_batch_equals_single_runs():
         Yorig = _gas_sensor_standin(d, n)
         Yint = np.nan_to_num(Yorig, nan=0.0)
         M, Mm, C0, X0 = _draw(Yorig, r, seeds)
+        C0_before = C0.copy()
         res = impute.impute_batch(Yint, M, Mm, C0, X0, V, Q, 10.0, P, 2, 2, robust=False)
+        assert np.array_equal(C0, C0_before)          # inputs are not mutated (the reference rebinds C, PSMF.py:80)
         assert np.all(np.isfinite(res["Epred"])) and np.all(np.isfinite(res["Efull"]))
         assert len(set(np.round(res["Epred"][:, -1], 12))) == seeds      # 50 different problems, 50 different answers
         for i in singles:
