@@ -446,8 +446,8 @@ def main():
             line["parity_vs_cpu_oracle"] = parity
         if world == 1 and not args.no_extras:
             try:
-                line["roofline"]["hbm_peak_measured"] = {"GBps": _capi.measure_copy_bandwidth(local_rank, 1 << 30, 20),
-                                                         "what": "copy kernel, 1 GiB read + 1 GiB written per launch, 16-byte accesses"}
+                line["roofline"]["hbm_peak_measured"] = {"GBps": _capi.measure_copy_bandwidth(local_rank, 1 << 32, 10),
+                                                         "what": "copy kernel, 4 GiB read + 4 GiB written per launch, 16-byte accesses"}
             except Exception as e:      # never lose the headline over an extra
                 line["roofline"]["hbm_peak_measured"] = {"error": repr(e)}
             if args.cpu_steps > 0:

@@ -8,9 +8,10 @@ The device path (backend="hip", default) needs rpsmf_amd/lib/libpsmf_hip.so
 """
 
 from .learning_rate import BaseLearningRate, ConstantLearningRate, ExponentialLearningRate  # noqa: F401
-from .nonlinearities import (BaseNonLinearity, CosPhase, FourierBasis, RandomWalk, Sinusoid,  # noqa: F401
+from .nonlinearities import (BaseNonLinearity, CosPhase, FourierBasis, RandomWalk, ScaledWalk, Sinusoid,  # noqa: F401
                              wrap_nonlinearity)
 from .psmf import PSMFIter, PSMFIterMissing, PSMFRecursive  # noqa: F401
 from .rpsmf import rPSMFIter, rPSMFIterMissing, rPSMFRecursive  # noqa: F401
+from .tracking import TrackingMixin  # noqa: F401
 
 __version__ = "0.1.0"

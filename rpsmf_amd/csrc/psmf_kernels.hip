@@ -749,7 +749,13 @@ __global__ __launch_bounds__(WG) void psmf_predict_rows(const T* __restrict__ C,
 
 // plain streaming copy (16-byte accesses, grid-stride): the measured HBM bandwidth bench.py quotes beside the nominal peak
 __global__ __launch_bounds__(WG) void psmf_copy_k(const float4* __restrict__ src, float4* __restrict__ dst, size_t n16) {
-  for (size_t i = (size_t)blockIdx.x * WG + threadIdx.x; i < n16; i += (size_t)gridDim.x * WG) dst[i] = src[i];
+  const size_t stride = (size_t)gridDim.x * WG;
+  size_t i = (size_t)blockIdx.x * WG + threadIdx.x;
+  for (; i + 3 * stride < n16; i += 4 * stride) {      // four independent 16-byte loads in flight per thread
+    const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+  }
+  for (; i < n16; i += stride) dst[i] = src[i];
 }
 
 // sum of squared prediction errors over a block of steps (tracking.py:63-76 norms)

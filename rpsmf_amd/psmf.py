@@ -424,8 +424,9 @@ class PSMFIter:
         Q1 = self._q_matrix(Q[1 if 1 in Q else min(Q.keys())])
         rho_s = q_s = None
         seen_R, seen_Q = {id(R[k1]): rho1}, {}
+        kq1 = 1 if 1 in Q else min(Q.keys())
         for k in ks:
-            Rk = R[k]
+            Rk = R.get(k, R[k1])          # (a dictionary without the step's key: the constant it was built from)
             if id(Rk) not in seen_R:
                 seen_R[id(Rk)] = self._rho_of(Rk)
             rk = seen_R[id(Rk)]
@@ -433,7 +434,7 @@ class PSMFIter:
                 rho_s = np.full(len(ks) + 1, rho1)
             if rho_s is not None:
                 rho_s[k] = rk
-            Qk = Q[k]
+            Qk = Q.get(k, Q[kq1])
             if id(Qk) not in seen_Q:
                 Qm = self._q_matrix(Qk)
                 if np.array_equal(Qm, Q1):
@@ -445,7 +446,7 @@ class PSMFIter:
             qk = seen_Q[id(Qk)]
             if qk == "host":
                 q_s = "host"
-            elif q_s != "host":
+            elif not isinstance(q_s, str):
                 if qk != 1.0 and q_s is None:
                     q_s = np.ones(len(ks) + 1)
                 if q_s is not None:
@@ -533,7 +534,7 @@ class PSMFIter:
 
     def _step_hip(self, y, i, T):
         self.step_reset()
-        if not self._host_stepped() and not self.robust and self._device_rho_q(T)[3] == "host":
+        if not self._host_stepped() and not self.robust and isinstance(self._device_rho_q(T)[3], str):
             # Q[k] is not a scalar multiple of Q[1]: the host forms P_bar (any Q[k]); needs a handle of the host-stepped kind
             self._force_host_stepped = True
             if self._dev is not None:

@@ -98,18 +98,9 @@ class rPSMFIter(PSMFIter):
     def _device_lambda0(self):
         return float(self.lambda0)
 
-    def _device_rho_q(self):
-        # the epoch starts from R0, Q0 (step_reset)
-        from .psmf import _as_scalar_if_uniform, _diag_of
-
-        dg = _diag_of(self.R0, self._d)
-        rho = None if dg is None else _as_scalar_if_uniform(dg)
-        if rho is None:
-            raise NotImplementedError("the device path needs R0 = rho * I (uniform diagonal); use backend='numpy'")
-        Q = np.asarray(self.Q0, dtype=float)
-        if Q.ndim == 0:
-            Q = float(Q) * np.eye(self._r)
-        return rho, Q
+    def _device_rho_q(self, T=None):
+        # the epoch starts from R0, Q0 (step_reset) and runs on the omega-scaled Q_{k-1}, R_{k-1}: no schedules
+        return self._rho_of(self.R0), self._q_matrix(self.Q0), None, None
 
     def _device_kwargs(self):
         kw = super()._device_kwargs()

@@ -1,0 +1,322 @@
+"""The theta path on the device: state-transition functions beyond the random walk, evaluated inside the
+blocked engine with analytic Jacobians (psmf_dyn.hip) or host-stepped (psmf_step_host), the in-loop optimiser of the
+recursive classes, and the per-step R_k / Q_k schedules of PSMFIter -- against the CPU oracle (complex-step derivatives of the
+same callables) and the reference-generated golden fixtures.  GPU only: `pytest -m gpu`.
+"""
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, relerr
+from oracle import psmf_oracle as O
+import rpsmf_amd as psmf
+from rpsmf_amd import nonlinearities as NL
+
+pytestmark = pytest.mark.gpu
+
+
+def _capi():
+    from rpsmf_amd import _capi
+
+    return _capi
+
+
+def ydict(Y):
+    return {k + 1: Y[k][:, None].copy() for k in range(Y.shape[0])}
+
+
+def _problem(d, r, T, seed):
+    rng = np.random.default_rng(seed)
+    Ct = rng.standard_normal((d, r))
+    x = rng.standard_normal(r)
+    Y = np.empty((T, d))
+    for t in range(T):
+        x = 0.9 * np.sin(x + 0.3) + 0.1 * rng.standard_normal(r)
+        Y[t] = Ct @ x + 0.3 * rng.standard_normal(d)
+    return Y, 0.1 * rng.standard_normal((d, r))
+
+
+def _theta_for(nl, rng, r):
+    """A theta in the regime the experiments use (beijing_psmf.py:117: 0.1 * rand): matrices near a contraction."""
+    th = 0.1 * rng.random(nl.n_params)
+    if isinstance(nl, (NL.ScaledWalk,)) or getattr(nl, "scaled", False):
+        th[:r * r] = (0.8 * np.eye(r) + 0.05 * rng.standard_normal((r, r))).reshape(-1)
+    if isinstance(nl, NL.FourierBasis):
+        for t in range(2 * nl.N):
+            th[t * r * r:(t + 1) * r * r] = (0.5 * np.eye(r) + 0.05 * rng.standard_normal((r, r))).reshape(-1) / nl.N
+    return th
+
+
+KINDS = [
+    ("scaled_walk_bias", lambda r: NL.ScaledWalk(r, bias=True), 6),
+    ("scaled_walk", lambda r: NL.ScaledWalk(r, bias=False), 17),
+    ("sinusoid", lambda r: NL.Sinusoid(r), 8),
+    ("sinusoid_unscaled", lambda r: NL.Sinusoid(r, scaled=False), 20),
+    ("sinusoid_unphased", lambda r: NL.Sinusoid(r, phased=False), 5),
+    ("sinusoid_plain", lambda r: NL.Sinusoid(r, scaled=False, phased=False), 32),
+    ("fourier1", lambda r: NL.FourierBasis(r, N=1), 7),
+    ("fourier3", lambda r: NL.FourierBasis(r, N=3), 4),
+    ("cos_phase", lambda r: NL.CosPhase(r), 9),
+]
+
+
+@pytest.mark.parametrize("robust", [False, True], ids=["PSMF", "rPSMF"])
+@pytest.mark.parametrize("name,make,r", KINDS, ids=[k[0] for k in KINDS])
+def test_device_dynamics_vs_oracle(name, make, r, robust):
+    """mu_bar = f(theta, mu, k), P_bar = F P F^T + Q with the analytic F, and gradsum = sum_k J_theta^T g_f, all inside the
+    blocked engine's time loop, against the oracle run on the same callable (complex-step F and J_theta)."""
+    c = _capi()
+    d, T = 300, 90
+    nl = make(r)
+    rng = np.random.default_rng(11 + r)
+    Y, C0 = _problem(d, r, T, 50 + r)
+    theta = _theta_for(nl, rng, r)
+    V0, P0, Q = 0.1 * np.eye(r), np.eye(r), 0.1 * np.eye(r)
+    mu0 = 0.2 * rng.standard_normal(r)
+    mode = O.Mode(robust=robust)
+    st = O.State(C=C0, V=V0, mu=mu0, P=P0, Q=Q, rho=1.0, lam=1.8, theta=theta.copy(), gradsum=np.zeros(nl.n_params))
+    st, Yp, _ = O.run_epoch(st, Y, mode, O.CallableDyn(nl, nl.n_params))
+    f = c.DeviceFilter(d, r, robust=robust, storage="f64", dyn_kind=nl.device_kind, dyn_flags=nl.device_flags,
+                       dyn_terms=nl.device_terms)
+    assert f.geometry()["engine"] == "block" and f.n_theta == nl.n_params
+    f.upload_series(Y)
+    f.set_state(C0, V0, P0, Q, mu0, rho=1.0, lambda0=1.8, theta=theta)
+    f.zero_gradsum()
+    f.run(0, T)
+    s = f.get_state()
+    for k in ("C", "V", "mu", "P"):
+        assert relerr(s[k], getattr(st, k)) < 1e-8, k
+    assert relerr(f.y_pred(0, T), Yp) < 1e-8
+    assert relerr(s["gradsum"], st.gradsum) < 1e-7
+    # roll-out with the same f (psmf.py:182-188)
+    assert relerr(f.predict(T, 5), O.predict_rollout(st.C, st.mu, theta, O.CallableDyn(nl, nl.n_params), T, 5)) < 1e-8
+    f.close()
+
+
+def test_fourier_beijing_configuration_on_device():
+    """ExperimentBeijing's periodic configuration (FourierBasis(rank=1, N=1), full filter, Adam between epochs:
+    beijing_psmf.py:97-140) with the default back end, against the reference's own run of PSMFIter; then the experiment's
+    subclass (V re-initialised every epoch, `_mu` kept: beijing_psmf.py:82-88) against the numpy back end."""
+    g = load_golden("psmf_full_fourier")
+    T, n_pred, n_iter = int(g["T"]), int(g["n_pred"]), int(g["n_iter"])
+    Y = g["Y"]
+    d, r = g["C0"].shape
+
+    class Beijing(psmf.PSMFIter):
+        def step_reset(self):
+            super().step_reset()
+            self._V = {0: self.V0}
+
+        def _prune(self, k):
+            del self._C[k - 1], self._V[k - 1], self._P[k - 1]
+
+    def run(cls, **kw):
+        f = cls(g["theta0"].reshape(-1, 1), g["C0"], g["V0"], g["mu0"].reshape(-1, 1), g["P0"],
+                {k: g["Q"] for k in range(T + 1)}, {k: np.eye(d) for k in range(T + 1)}, psmf.FourierBasis(rank=r, N=1), **kw)
+        f.adam_init(gam=1e-3)
+        for i in range(1, n_iter + 1):
+            f.step(ydict(Y[:T]), i, T)
+            f.predict(i, T, n_pred)
+            f.adam_update(i, project=True)
+        theta = np.array([f._theta[i].reshape(-1) for i in range(n_iter + 1)])
+        yp = np.array([f._y_pred[k].reshape(-1) for k in range(1, T + n_pred + 1)])
+        return f, theta, yp
+
+    f, theta, yp = run(psmf.PSMFIter, storage="f64")
+    assert f._dev.geometry()["engine"] == "block" and f._dev.dyn_kind == _capi().DYN_FOURIER
+    assert relerr(theta, g["theta"]) < 1e-7 and relerr(yp, g["y_pred_last"]) < 1e-7
+    fb, theta_b, yp_b = run(Beijing, storage="f64")
+    fn, theta_n, yp_n = run(Beijing, backend="numpy")
+    assert relerr(theta_b, theta_n) < 1e-9 and relerr(yp_b, yp_n) < 1e-9
+    mu_b = np.array([fb._mu[k].reshape(-1) for k in range(T + 1)])
+    mu_n = np.array([fn._mu[k].reshape(-1) for k in range(T + 1)])
+    assert relerr(mu_b, mu_n) < 1e-9
+
+
+def tanh_mix(theta, x, t):
+    """an arbitrary user callable: not one of the device kinds"""
+    r = np.asarray(x).size
+    A = np.asarray(theta)[:r * r].reshape(r, r)
+    return np.tanh(A @ np.asarray(x).reshape(r, 1)) + 0.01 * np.asarray(theta)[r * r:].reshape(r, 1) * np.cos(0.1 * t)
+
+
+@pytest.mark.parametrize("robust", [False, True], ids=["PSMF", "rPSMF"])
+def test_host_stepped_arbitrary_callable(robust):
+    """A plain Python callable with backend='hip': f, F, J_theta on the host (r-sized), everything d-sized on the device, one
+    psmf_step_host per timestep -- against the oracle on the same callable; two epochs with Adam in between."""
+    d, r, T, n_pred = 2000, 5, 60, 4
+    rng = np.random.default_rng(3)
+    Y, C0 = _problem(d, r, T + n_pred, 7)
+    theta0 = np.concatenate([(0.7 * np.eye(r) + 0.05 * rng.standard_normal((r, r))).reshape(-1), rng.random(r)]).reshape(-1, 1)
+    V0, P0, Q = 0.1 * np.eye(r), np.eye(r), 0.1 * np.eye(r)
+    mu0 = np.zeros((r, 1))
+    if robust:
+        f = psmf.rPSMFIter(theta0, C0, V0, mu0, P0, Q, 1.0, 1.8, tanh_mix, storage="f64")
+    else:
+        f = psmf.PSMFIter(theta0, C0, V0, mu0, P0, {k: Q for k in range(T + 1)}, {k: 1.0 for k in range(T + 1)}, tanh_mix, storage="f64")
+    f.adam_init(gam=1e-3)
+    dyn = O.CallableDyn(tanh_mix, theta0.size)
+    st = O.State(C=C0, V=V0, mu=np.zeros(r), P=P0, Q=Q, rho=1.0, lam=1.8, theta=theta0.reshape(-1).copy())
+    m = v = np.zeros(theta0.size)
+    for i in (1, 2):
+        f.step(ydict(Y[:T]), i, T)
+        f.predict(i, T, n_pred)
+        st.gradsum = np.zeros(theta0.size)
+        if robust:
+            st.Q, st.rho, st.lam = Q, 1.0, 1.8
+        st, Yp, _ = O.run_epoch(st, Y[:T], O.Mode(robust=robust), dyn)
+        assert f._dev.dyn_kind == _capi().DYN_HOST and f._dev.geometry()["engine"] == "step"
+        assert relerr(f._C[T], st.C) < 1e-8 and relerr(f._P[T], st.P) < 1e-8 and relerr(f._mu[T], st.mu.reshape(-1, 1)) < 1e-8
+        assert relerr(f._gradsum.reshape(-1), st.gradsum) < 1e-7
+        yp = np.array([f._y_pred[k].reshape(-1) for k in range(1, T + n_pred + 1)])
+        ref = np.vstack([Yp, O.predict_rollout(st.C, st.mu, st.theta, dyn, T, n_pred)])
+        assert relerr(yp, ref) < 1e-8
+        f.adam_update(i)
+        st.theta, m, v = O.adam_update(st.theta, st.gradsum, m, v, i)
+        assert relerr(f._theta[i].reshape(-1), st.theta) < 1e-7
+
+
+def test_general_kind_beyond_r32_runs_host_stepped():
+    """Sinusoid at r = 40: the blocked engine (which evaluates it) stops at r = 32 -> host-stepped automatically."""
+    d, r, T = 500, 40, 25
+    rng = np.random.default_rng(5)
+    Y, C0 = _problem(d, r, T, 9)
+    nl = NL.Sinusoid(r, scaled=False)
+    theta0 = (0.1 * rng.random(nl.n_params)).reshape(-1, 1)
+    V0, P0, Q = 0.1 * np.eye(r), np.eye(r), 0.1 * np.eye(r)
+    f = psmf.PSMFIter(theta0, C0, V0, np.zeros((r, 1)), P0, {k: Q for k in range(T + 1)}, {k: 1.0 for k in range(T + 1)}, nl, storage="f64")
+    f.adam_init()
+    f.step(ydict(Y), 1, T)
+    assert f._dev.dyn_kind == _capi().DYN_HOST
+    st = O.State(C=C0, V=V0, mu=np.zeros(r), P=P0, Q=Q, rho=1.0, lam=0.0, theta=theta0.reshape(-1).copy(), gradsum=np.zeros(nl.n_params))
+    st, _, _ = O.run_epoch(st, Y, O.Mode(), O.CallableDyn(nl, nl.n_params))
+    assert relerr(f._C[T], st.C) < 1e-8 and relerr(f._gradsum.reshape(-1), st.gradsum) < 1e-7
+
+
+@pytest.mark.parametrize("engine", ["block", "step"])
+@pytest.mark.parametrize("robust", [False, True], ids=["PSMF", "rPSMF"])
+def test_recursive_adam_both_engines(robust, engine):
+    """PSMFRecursive / rPSMFRecursive (theta updated by Adam inside the time loop, psmf.py:287-304) in the blocked engine
+    (in-loop optimiser inside the block kernel) and in the per-step engine, against the reference's run."""
+    c = _capi()
+    g = load_golden("rpsmf_recursive" if robust else "psmf_recursive")
+    T, n_pred, ue = int(g["T"]), int(g["n_pred"]), int(g["update_every"])
+    d, r = g["C0"].shape
+    f = c.DeviceFilter(d, r, storage="f64", robust=robust, dyn_kind=c.DYN_COS_PHASE, recursive=True, update_every=ue, adam_lr=1e-3,
+                       engine=engine)
+    assert f.geometry()["engine"] == engine
+    f.upload_series(g["Y"])
+    f.set_state(g["C0"], g["V0"], g["P0"], g["Q"], g["mu0"], rho=float(g["rho"]), lambda0=float(g["lambda0"]), theta=g["theta0"])
+    f.zero_gradsum()
+    f.set_adam(np.zeros(r), np.zeros(r))
+    f.run(0, T)
+    s = f.get_state()
+    assert relerr(s["theta"], g["theta"][-1]) < 1e-6
+    assert relerr(s["C"], g["C_T"]) < 1e-6 and relerr(s["mu"], g["mu_T"]) < 1e-6 and relerr(s["P"], g["P_T"]) < 1e-6
+    yp = np.vstack([f.y_pred(0, T), f.predict(T, n_pred)])
+    assert relerr(yp, g["y_pred"]) < 1e-6
+    f.close()
+
+
+def test_recursive_sinusoid_vs_oracle():
+    """In-loop Adam with a dense-Jacobian kind and update_every = 3: theta (r^2 + 2 r parameters), its moments and the
+    gradient restart all live in the block kernel's loop; oracle = step-by-step recursion + adam_update."""
+    c = _capi()
+    d, r, T, ue = 200, 6, 50, 3
+    nl = NL.Sinusoid(r)
+    rng = np.random.default_rng(2)
+    Y, C0 = _problem(d, r, T, 13)
+    theta = _theta_for(nl, rng, r)
+    V0, P0, Q = 0.1 * np.eye(r), np.eye(r), 0.1 * np.eye(r)
+    dyn = O.CallableDyn(nl, nl.n_params)
+    st = O.State(C=C0, V=V0, mu=np.zeros(r), P=P0, Q=Q, rho=1.0, lam=0.0, theta=theta.copy(), gradsum=np.zeros(nl.n_params))
+    m = v = np.zeros(nl.n_params)
+    for k in range(1, T + 1):
+        st, _ = O.lowrank_step(st, Y[k - 1], k, O.Mode(), dyn)
+        if k % ue == 0:
+            st.theta, m, v = O.adam_update(st.theta, st.gradsum, m, v, k, lr=2e-3)
+            st.gradsum = np.zeros(nl.n_params)
+    f = c.DeviceFilter(d, r, storage="f64", dyn_kind=nl.device_kind, dyn_flags=nl.device_flags, recursive=True, update_every=ue, adam_lr=2e-3)
+    f.upload_series(Y)
+    f.set_state(C0, V0, P0, Q, np.zeros(r), rho=1.0, lambda0=0.0, theta=theta)
+    f.zero_gradsum()
+    f.set_adam(np.zeros(nl.n_params), np.zeros(nl.n_params))
+    f.run(0, T)
+    s = f.get_state()
+    assert relerr(s["theta"], st.theta) < 1e-8 and relerr(s["C"], st.C) < 1e-8 and relerr(s["P"], st.P) < 1e-8
+    f.close()
+
+
+@pytest.mark.parametrize("engine", ["block", "step"])
+def test_per_step_R_and_Q_schedules(engine):
+    """PSMFIter reads R[k], Q[k] of the step (psmf.py:115,123,141): R_k = rho_k I, Q_k = q_k Q as device schedules, through
+    the class surface, against the oracle with the same dictionaries."""
+    d, r, T = 700, 12, 75
+    Y, C0 = _problem(d, r, T, 21)
+    rng = np.random.default_rng(8)
+    Q0 = 0.1 * np.eye(r) + 0.01 * np.ones((r, r))
+    rho_k = 0.5 + rng.random(T + 1)
+    q_k = 0.5 + rng.random(T + 1)
+    q_k[1] = 1.0
+    Qs = {k: q_k[k] * Q0 for k in range(T + 1)}
+    Rs = {k: rho_k[k] for k in range(T + 1)}
+    V0, P0 = 0.1 * np.eye(r), np.eye(r)
+    f = psmf.PSMFIter(np.zeros((0, 1)), C0, V0, np.zeros((r, 1)), P0, Qs, Rs, psmf.RandomWalk(), storage="f64", engine=engine)
+    f.optim_init()
+    f.step(ydict(Y), 1, T)
+    assert f._dev.geometry()["engine"] == engine
+    st = O.State(C=C0, V=V0, mu=np.zeros(r), P=P0, Q=Q0, rho=1.0, lam=0.0)
+    st, Yp, _ = O.run_epoch(st, Y, O.Mode(), O.RandomWalkDyn(), Qs=lambda k: Qs[k], rhos=lambda k: Rs[k])
+    assert relerr(f._C[T], st.C) < 1e-9 and relerr(f._V[T], st.V) < 1e-9 and relerr(f._P[T], st.P) < 1e-9
+    yp = np.array([f._y_pred[k].reshape(-1) for k in range(1, T + 1)])
+    assert relerr(yp, Yp) < 1e-9
+
+
+def test_arbitrary_Q_schedule_switches_to_host_stepped():
+    """A Q[k] that is not a scalar multiple of Q[1] cannot be a device schedule: the host forms P_bar (psmf_step_host)."""
+    d, r, T = 400, 4, 30
+    Y, C0 = _problem(d, r, T, 23)
+    rng = np.random.default_rng(9)
+    Qs = {}
+    for k in range(T + 1):
+        A = rng.standard_normal((r, r))
+        Qs[k] = 0.05 * np.eye(r) + 0.01 * A @ A.T
+    V0, P0 = 0.1 * np.eye(r), np.eye(r)
+    f = psmf.PSMFIter(np.zeros((0, 1)), C0, V0, np.zeros((r, 1)), P0, Qs, {k: 2.0 for k in range(T + 1)}, psmf.RandomWalk(), storage="f64")
+    f.optim_init()
+    f.step(ydict(Y), 1, T)
+    assert f._dev.dyn_kind == _capi().DYN_HOST
+    st = O.State(C=C0, V=V0, mu=np.zeros(r), P=P0, Q=Qs[1], rho=2.0, lam=0.0)
+    st, _, _ = O.run_epoch(st, Y, O.Mode(), O.RandomWalkDyn(), Qs=lambda k: Qs[k])
+    assert relerr(f._C[T], st.C) < 1e-9 and relerr(f._P[T], st.P) < 1e-9
+
+
+def test_tracking_error_norms_on_device():
+    """TrackingMixin.errors_update (tracking.py:63-76): the three Frobenius norms of Y_pred - Y (full / train / pred windows)
+    reduced on the device, against the host computation from `_y_pred`."""
+    from rpsmf_amd.tracking import TrackingMixin
+
+    class Tracked(TrackingMixin, psmf.PSMFIter):
+        pass
+
+    d, r, T, n_pred = 1200, 6, 80, 20
+    Y, C0 = _problem(d, r, T + n_pred, 31)
+    y_full = ydict(Y)
+    y_train = {k: y_full[k] for k in range(1, T + 1)}
+    nl = psmf.CosPhase(r)
+    theta0 = (1e-3 * np.arange(1, r + 1)).reshape(-1, 1)
+    f = Tracked(theta0, C0, 0.1 * np.eye(r), np.zeros((r, 1)), np.eye(r), {k: 0.1 * np.eye(r) for k in range(T + 1)},
+                {k: 1.0 for k in range(T + 1)}, nl, storage="f64")
+    f.adam_init()
+    f.errors_init(y_full, T, 2, n_pred)
+    for i in (1, 2):
+        f.step(y_train, i, T)
+        f.predict(i, T, n_pred)
+        f.adam_update(i)
+        f.errors_update(i, y_full, T, n_pred)
+        f.log(i, 2, 0.0, verbose=False)
+        Yp = np.array([f._y_pred[k].reshape(-1) for k in range(1, T + n_pred + 1)])
+        assert relerr(f._E_y[i], np.linalg.norm(Yp - Y)) < 1e-10
+        assert relerr(f._E_train[i], np.linalg.norm(Yp[:T] - Y[:T])) < 1e-10
+        assert relerr(f._E_pred[i], np.linalg.norm(Yp[T:] - Y[T:])) < 1e-10
+    assert f._tracking_on_device == 2 and len(f._logs) == 2

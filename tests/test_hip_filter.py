@@ -277,7 +277,9 @@ def test_engines_agree_and_auto_selects_blocked():
     with pytest.raises(ValueError):
         c.DeviceFilter(100, 40, engine="block")      # r > 32
     with pytest.raises(ValueError):
-        c.DeviceFilter(100, 8, engine="block", recursive=True, dyn_kind=c.DYN_COS_PHASE)
+        c.DeviceFilter(100, 8, engine="block", dyn_kind=c.DYN_HOST)      # host-stepped dynamics advance one step at a time
+    with pytest.raises(ValueError):
+        c.DeviceFilter(100, 8, engine="step", dyn_kind=c.DYN_SINUSOID, dyn_flags=3)   # evaluated by the blocked engine only
 
 
 @pytest.mark.parametrize("robust", [False, True])

@@ -241,8 +241,8 @@ def test_hip_backend_refuses_unrecognised_overrides_and_callables():
     args = (np.zeros((0, 1)), np.zeros((4, 2)), np.eye(2), np.zeros((2, 1)), np.eye(2), {0: np.eye(2)}, {0: 1.0})
     with pytest.raises(TypeError):
         Custom(*args, psmf.RandomWalk())                 # overrides without a declared hip_mode
-    with pytest.raises(TypeError):
-        psmf.PSMFIter(*args, lambda th, x, t: x)         # arbitrary callable cannot run on the device
+    f = psmf.PSMFIter(*args, lambda th, x, t: x)         # arbitrary callable: accepted, f is evaluated on the host, one device step
+    assert f._host_stepped()                             # at a time (psmf_step_host) -- the d-sized work stays on the device
     Custom(*args, psmf.RandomWalk(), backend="numpy")    # fine on the host
 
     class Declared(Custom):
@@ -264,6 +264,49 @@ def test_hip_backend_refuses_unrecognised_overrides_and_callables():
         psmf.rPSMFIterMissing()
     with pytest.raises(AssertionError):
         psmf.PSMFIter(*args, psmf.RandomWalk(), optim="lbfgs", backend="numpy")
+
+
+def test_builtin_nonlinearities_numpy_backend_gradients():
+    """ScaledWalk / Sinusoid / FourierBasis with their analytic Jacobians (numpy back end) against the same functions passed
+    as plain callables (complex-step derivatives): identical epochs, gradients included."""
+    rng = np.random.default_rng(4)
+    d, r, T = 14, 3, 10
+    Y = rng.standard_normal((T, d))
+    C0 = rng.standard_normal((d, r))
+    for nl in (psmf.ScaledWalk(r), psmf.Sinusoid(r), psmf.Sinusoid(r, scaled=False, phased=False), psmf.FourierBasis(r, N=2)):
+        theta0 = (0.3 * rng.random(nl.n_params)).reshape(-1, 1)
+        outs = []
+        for fn in (nl, lambda th, x, t, nl=nl: nl(th, x, t)):
+            f = psmf.PSMFIter(theta0, C0, 0.2 * np.eye(r), np.zeros((r, 1)), np.eye(r), {k: 0.1 * np.eye(r) for k in range(T + 1)},
+                              {k: 1.0 for k in range(T + 1)}, fn, backend="numpy")
+            f.optim_init()
+            f.step(ydict(Y), 1, T)
+            outs.append((f._C[T], f._P[T], f._gradsum))
+        for a, b in zip(*outs):
+            assert relerr(a, b) < 1e-10
+
+
+def test_tracking_mixin_host_path():
+    """errors_init / errors_update / log with the reference's attribute names and line format (tracking.py:20-76)."""
+    class Tracked(psmf.TrackingMixin, psmf.PSMFIter):
+        pass
+
+    rng = np.random.default_rng(8)
+    d, r, T, n_pred = 9, 2, 12, 4
+    Y = rng.standard_normal((T + n_pred, d))
+    y = ydict(Y)
+    f = Tracked(np.zeros((0, 1)), rng.standard_normal((d, r)), 0.2 * np.eye(r), np.zeros((r, 1)), np.eye(r),
+                {k: 0.1 * np.eye(r) for k in range(T + 1)}, {k: 1.0 for k in range(T + 1)}, psmf.RandomWalk(), backend="numpy")
+    f.optim_init()
+    f.errors_init(y, T, 1, n_pred)
+    assert relerr(f._E_y[0], np.linalg.norm(Y)) < 1e-14 and relerr(f._E_pred[0], np.linalg.norm(Y[T:])) < 1e-14
+    f.step({k: y[k] for k in range(1, T + 1)}, 1, T)
+    f.predict(1, T, n_pred)
+    f.errors_update(1, y, T, n_pred)
+    Yp = np.array([f._y_pred[k].reshape(-1) for k in range(1, T + n_pred + 1)])
+    assert relerr(f._E_y[1], np.linalg.norm(Yp - Y)) < 1e-13 and relerr(f._E_train[1], np.linalg.norm(Yp[:T] - Y[:T])) < 1e-13
+    f.log(1, 1, 0.5, verbose=False)
+    assert f._logs[0].startswith("[001/1] ||y - Cx||^2 = ") and f._logs[0].endswith("Δt = 0.500") and f._tracking_on_device == 0
 
 
 def test_inverse_innovation_operator_matches_dense():
