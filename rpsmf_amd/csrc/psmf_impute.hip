@@ -18,6 +18,7 @@
 // column loop order LDS only (solve_barrier<true>): the prefetch and the per-column stores (X, bands) stay in flight across them.
 #include "../../include/psmf_hip.h"
 #include "psmf_kernels.hip"
+#include "psmf_blk3.hip"      // DPP row sums, readlane helpers
 
 #include <cmath>
 #include <cstring>
@@ -26,6 +27,17 @@
 namespace psmf {
 
 constexpr int IR = 16;   // largest rank of the masked engine (experiments use r = 10)
+
+// per-phase cycle accumulation for tools/impute_prof.hip (PSMF_IMPUTE_STAMPS); no-ops in the product
+#ifdef PSMF_IMPUTE_STAMPS
+#define IMP_T0() unsigned long long it_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, il_, in_; { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(il_) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+#define IMP_T(n) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(in_) :: "memory"); __builtin_amdgcn_sched_barrier(0); it_[n] += in_ - il_; il_ = in_; }
+#define IMP_TOUT() if ((threadIdx.x & 63) == 0 && p.prof) for (int q_ = 0; q_ < 8; ++q_) p.prof[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + q_] = it_[q_];
+#else
+#define IMP_T0()
+#define IMP_T(n)
+#define IMP_TOUT()
+#endif
 
 struct ImputeParams {
   int d, n, r, n_iter, robust, want_bands;
@@ -46,6 +58,8 @@ struct ImputeParams {
   double* YrecL;
   double* YrecH;
   int* err;                // batch
+  int q_iso;               // Q0 = q I with q > 0: the two r x r inversions of a column run in parallel on two waves
+  unsigned long long* prof;   // diagnostics (tools/impute_prof.hip) or nullptr
 };
 
 __global__ __launch_bounds__(WG) void psmf_impute_kernel(ImputeParams p) {
@@ -111,6 +125,7 @@ __global__ __launch_bounds__(WG) void psmf_impute_kernel(ImputeParams p) {
   unsigned long long nmiss_l = 0;   // per-thread counts, rows tid, tid + 256, ...
   const bool sgd = p.method >= 2;     // MLE-SMF / TMF: gradient step on C along x_p, no V
   const bool tmf = p.method == 3;
+  IMP_T0();
   for (int it = 0; it < p.n_iter; ++it) {
     const double gam = 1e-6 / pow((double)(it + 1), 0.7);     // MLESMF.py:59-60, TMF.py:46-48
     if (p.robust) {                 // rPSMF.py:77-79: Q, R, lambda restart every pass; V, P, C carry over
@@ -133,6 +148,7 @@ __global__ __launch_bounds__(WG) void psmf_impute_kernel(ImputeParams p) {
     }
     __syncthreads();
     for (int t = 0; t < n; ++t) {
+      IMP_T(7);
       double yv[2];
       uint8_t mv[2], mmv[2];
 #pragma unroll
@@ -171,6 +187,7 @@ __global__ __launch_bounds__(WG) void psmf_impute_kernel(ImputeParams p) {
         sw[i] = a;
       }
       solve_barrier<true>();
+      IMP_T(0);
       double s = 0.0;
       for (int l = 0; l < r; ++l) s += sx[l] * sw[l];
       // weights of the observed rows: PSMF / rPSMF 1 / (rho + s) (PSMF.py:71-72), MLE-SMF 1 / rho (MLESMF.py:70), TMF 1
@@ -201,6 +218,7 @@ __global__ __launch_bounds__(WG) void psmf_impute_kernel(ImputeParams p) {
         else sred[1] = g;                    // e^T e
       }
       solve_barrier<true>();
+      IMP_T(1);
       const double msum = sred[0], ee = sred[1];
       // ---- C: PP = P + Q, <G, PP>, P+ = (PP^-1 + kappa G)^-1 ----
       double A1[1], G1[1];
@@ -214,6 +232,7 @@ __global__ __launch_bounds__(WG) void psmf_impute_kernel(ImputeParams p) {
       spd_update_solve<16, true>(A1, G1, r2, ec, ei, rowbuf, errflag);   // contains barriers
       if (ein) sPp[ei * r + ec] = A1[0];
       solve_barrier<true>();
+      IMP_T(2);
       const double trGP = (sred[4] + sred[5]) + (sred[6] + sred[7]);
       const double eta = (rho * msum + trGP) / dd;      // divide by d, not by #observed (PSMF.py:77)
       const double N = s + eta;
@@ -238,6 +257,7 @@ __global__ __launch_bounds__(WG) void psmf_impute_kernel(ImputeParams p) {
         phi = (lam + ee / N) / (lam + dd);              // rPSMF.py:112-114 (e = 0 on unobserved rows)
       }
       const double wsc = 1.0 / N;
+      IMP_T(3);
       // ---- E: C, V, P, bands, metrics ----
       const double csc = tmf ? gam : gam / eta;        // MLESMF.py:79, TMF.py:63
       for (int idx = tid; idx < d * r; idx += WG) {
@@ -265,6 +285,7 @@ __global__ __launch_bounds__(WG) void psmf_impute_kernel(ImputeParams p) {
         }
       }
       solve_barrier<true>();   // all reads of sV, sx, sP, sQ, sPp of this column are done
+      IMP_T(4);
       if (ein) {
         if (!sgd) sV[ei * r + ec] = phi * (sV[ei * r + ec] - sw[ei] * sw[ec] * wsc);
         sP[ei * r + ec] = omega * 0.5 * (sPp[ei * r + ec] + sPp[ec * r + ei]);
@@ -273,6 +294,7 @@ __global__ __launch_bounds__(WG) void psmf_impute_kernel(ImputeParams p) {
       if (tid < r) sx[tid] = xnew;
       if (p.robust) { rho *= omega; lam += dd; }
       solve_barrier<true>();
+      IMP_T(5);
     }
     // ---- end of pass: RMSE of the one-step predictions, RMSE of C @ X, coverage ----
     double nm_d = (double)nmiss_l;
@@ -308,6 +330,462 @@ __global__ __launch_bounds__(WG) void psmf_impute_kernel(ImputeParams p) {
   }
   for (int idx = tid; idx < d * r; idx += WG) Cg[idx] = sC[idx];
   if (tid == 0) p.err[rep] = *errflag;
+  IMP_TOUT();
+}
+
+
+// ------------------------------------------------------------------------------------------------------------
+// Version 2 of the column loop (the default): FOUR workgroup barriers per column instead of ~15.
+//   P1  row owners (waves 1.., so that wave 0 stays free): masked residual rows; wave 3: w = V x          | barrier 1
+//   P2  waves 1-3: augmented masked Gram [C | e]^T diag(m) [C | e] on the float64 matrix cores, every wave its share
+//       of the 4-row groups (v_mfma_f64_16x16x4_f64; r = 16: a second tile for C^T e); wave 0: P + Q, kappa      | barrier 2
+//   P3a wave 0: sums the three partial tiles -- which leaves G in the MFMA output layout (lane = column, 4 rows per
+//       lane) -- <G, P + Q>, eta, N, phi                                                                  | barrier 3
+//   P3b wave 0 alone, NO barrier: the two symmetric sweep inversions of the reference's Woodbury form (PSMF.py:30-36)
+//       with the 16 x 16 matrix in its registers -- pivot row and column travel by lane shuffles, the pivot by
+//       v_readlane -- then x_t = x_p + kappa P+ C^T e, omega, P, Q
+//   P4  meanwhile waves 1-3: rank-1 updates of C and V (they need N, phi only); then every row owner: bands, metrics | barrier 4
+// P, Q, rho, lambda live in wave 0's registers for the whole run; x is double-buffered in LDS.
+// Measured on the config-D shape (d = 19, r = 10): tools/impute_prof.hip.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double shfl_f64(double v, int src) { return __shfl(v, src, 64); }
+
+// symmetric sweep of the leading r2 x r2 block (r2 even; identity padding beyond r) of the 16 x 16 matrix held by ONE wave
+// (lane: column lr = l & 15, rows lk + 4 q, lk = l >> 4):  A <- -A^-1, by 2 x 2 SPD block pivots as sweep_all
+// (psmf_kernels.hip) -- half as many dependent rounds as single pivots, and a round here costs lane shuffles (the two pivot
+// rows by column, and by symmetry the two pivot columns by row) plus three v_readlane for the block: no LDS memory, no
+// barrier.  Bitwise symmetric in, bitwise symmetric out (every pair term is a product of the same two numbers).
+__device__ __forceinline__ void wave_sweep16(double (&A)[4], const int r2, const int lk, const int lr, bool& bad) {
+#pragma unroll
+  for (int k = 0; k < 16; k += 2) {
+    if (k < r2) {                                  // uniform
+      const int b0 = (k & 3) << 4, b1 = ((k + 1) & 3) << 4, kq = k >> 2;    // rows k, k + 1 share the register (k even)
+      const double rk = A[kq];
+      const double uc = shfl_f64(rk, b0 | lr), wc = shfl_f64(rk, b1 | lr);
+      double ui[4], wi[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        ui[q] = shfl_f64(rk, b0 | (lk + 4 * q));
+        wi[q] = shfl_f64(rk, b1 | (lk + 4 * q));
+      }
+      const double ka = readlane_f64(rk, b0 | k), kb = readlane_f64(rk, b0 | (k + 1)), ke = readlane_f64(rk, b1 | (k + 1));
+      const double det = ka * ke - kb * kb;
+      bad |= !(ka > 0.0) | !(det > 0.0);
+      const double dinv = fast_rcp(det);
+      const double kp = ke * dinv, kq2 = -kb * dinv, ks = ka * dinv;       // Ki = [[kp, kq2], [kq2, ks]]
+      const bool c0 = (lr == k), c1 = (lr == k + 1);
+      // this lane's column: generic t = Ki [u_c; w_c]; pivot columns: -row of Ki
+      const double t1 = kp * uc + kq2 * wc, t2 = kq2 * uc + ks * wc;
+      const double g1 = c0 ? -kp : (c1 ? -kq2 : t1);
+      const double g2 = c0 ? -kq2 : (c1 ? -ks : t2);
+      const double keep = (c0 | c1) ? 0.0 : 1.0;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = lk + 4 * q;
+        const double upd = fma(-wi[q], g2, fma(-ui[q], g1, keep * A[q]));
+        A[q] = (i == k) ? g1 : ((i == k + 1) ? g2 : upd);
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(WG) void psmf_impute_kernel2(ImputeParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* sm = reinterpret_cast<double*>(smem_raw);
+  const int d = p.d, n = p.n, r = p.r, tid = threadIdx.x, rep = blockIdx.x;
+  const int lane = tid & 63, wv = tid >> 6, lk = lane >> 4, lr = lane & 15;
+  // ---- LDS carve (doubles) ----
+  // Rows of C, V and the r-vectors are padded to IR = 16 entries with ZEROS (and C, e, m to a multiple of 4 rows): every
+  // read below is an unconditional 16-wide row -- no index clamps, no selects (with runtime-r indexing this phase was
+  // ~800 instructions per column, a quarter of them selects and clamps)
+  const int d4 = (d + 3) & ~3;
+  double* sC = sm;                            // d4 x IR
+  double* sV = sC + (size_t)d4 * IR;          // IR x IR
+  double* sx = sV + IR * IR;                  // 2 x IR: prior mean of the current / next column
+  double* sw = sx + 2 * IR;                   // V x
+  double* se = sw + IR;                       // d4: masked residual
+  double* smk = se + d4;                      // d4: mask as 0/1 double
+  double* sgp = smk + d4;                     // 3 waves x 2 tiles x 256: Gram partials in MFMA output layout
+  double* spart = sgp + 4 * 2 * 256;          // 4 x 2: per-wave sum(m), sum(e^2)
+  double* ssc = spart + 8;                    // 8 scalars: 0 s, 1 eta, 2 N, 3 phi, 4 1 / omega_{t-1}, 5 q_{t-1} (the q W was formed with), 6 q_t, 7 kappa
+  double* sW = ssc + 8;                       // 256: W_{t-1} = (M_{t-1} + I / q_{t-1})^-1 in MFMA output layout (parallel inversions)
+  double* sred = sW + 256;                    // 16: end-of-pass reductions
+  int* errflag = reinterpret_cast<int*>(sred + 16);
+
+  const double* Yorg = p.Yorg;
+  const uint8_t* Mk = p.M + (size_t)rep * n * d;
+  const uint8_t* Mm = p.Mmiss + (size_t)rep * n * d;
+  double* Cg = p.C + (size_t)rep * d * r;
+  double* Xg = p.X + (size_t)rep * n * r;
+
+  for (int idx = tid; idx < d4 * IR; idx += WG) { const int i = idx >> 4, l = idx & 15; sC[idx] = (i < d && l < r) ? Cg[i * r + l] : 0.0; }
+  for (int idx = tid; idx < IR * IR; idx += WG) { const int i = idx >> 4, l = idx & 15; sV[idx] = (i < r && l < r) ? p.V0[i * r + l] : 0.0; }
+  if (tid < 2 * IR) sx[tid] = (tid < r) ? Xg[(size_t)(n - 1) * r + tid] : 0.0;   // t = 0 wraps to the last column (PSMF.py:65)
+  if (tid < IR) sw[tid] = 0.0;
+  for (int idx = tid; idx < d4; idx += WG) { se[idx] = 0.0; smk[idx] = 0.0; }
+  if (tid == 0) *errflag = 0;
+  const double dd = (double)d, idd = 1.0 / dd;
+  const bool sgd = p.method >= 2;     // MLE-SMF / TMF: gradient step on C along x_p, no V
+  const bool tmf = p.method == 3;
+  const bool one_tile = r < 16;       // the augmented column e fits the 16 x 16 tile
+  // Q = q I (every experiment): the two inversions of a column are made independent, as in the blocked engine (psmf_block.hip):
+  //   P+_t = M_t^-1,  M_t = Lbar_t + kappa_t G_t                                   (wave 0)
+  //   Lbar_{t+1} = (P_t + q_{t+1} I)^-1 = (1 / omega_t) [ I / q_t - W_t / q_t^2 ],  W_t = (M_t + I / q_t)^-1      (wave 1)
+  // (Woodbury on P_t + Q_{t+1} = omega_t (M_t^-1 + q_t I)); otherwise wave 0 inverts P + Q and then (P + Q)^-1 + kappa G in turn.
+  const bool par = p.q_iso && !tmf;
+  const int r2 = r + (r & 1);         // sweep size: even, identity-padded
+  // rows of this thread: waves 1, 2, 3 first (wave 0 owns the r x r work), wave 0 only when d > 192
+  const int ro = (tid + 192) & 255;
+  // wave 0: P, Q in the MFMA output layout (element (lk + 4 q, lr)), rho, lambda
+  double Pm[4], Qm[4];
+  bool inq[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int i = lk + 4 * q;
+    inq[q] = i < r && lr < r;
+    const int a = inq[q] ? i * r + lr : 0, b = inq[q] ? lr * r + i : 0;
+    Pm[q] = inq[q] ? 0.5 * (p.P0[a] + p.P0[b]) : 0.0;
+    Qm[q] = inq[q] ? 0.5 * (p.Q0[a] + p.Q0[b]) : 0.0;
+  }
+  double rho = p.rho0, lam = p.lambda0;
+  double qv = p.Q0[0];                // running q of Q = q I (parallel inversions)
+  bool bad = false;
+  unsigned long long nmiss_l = 0;
+  int cur = 0;
+  __syncthreads();
+  IMP_T0();
+  for (int it = 0; it < p.n_iter; ++it) {
+    const double gam = 1e-6 / pow((double)(it + 1), 0.7);     // MLESMF.py:59-60, TMF.py:46-48
+    if (p.robust) {                 // rPSMF.py:77-79: Q, R, lambda restart every pass; V, P, C carry over
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = lk + 4 * q;
+        const int a = inq[q] ? i * r + lr : 0, b = inq[q] ? lr * r + i : 0;
+        Qm[q] = inq[q] ? 0.5 * (p.Q0[a] + p.Q0[b]) : 0.0;
+      }
+      rho = p.rho0;
+      lam = p.lambda0;
+      qv = p.Q0[0];
+    }
+    if (par && (it == 0 || p.robust)) {
+      // Lbar_0 = (P + q I)^-1 by one sweep, handed over as the W that reproduces it: W = q I - q^2 Lbar (omega = 1)
+      if (wv == 0) {
+        double A[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) A[q] = inq[q] ? Pm[q] + ((lk + 4 * q) == lr ? qv : 0.0) : (((lk + 4 * q) == lr) ? 1.0 : 0.0);
+        wave_sweep16(A, r2, lk, lr, bad);          // -(P + q I)^-1
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sW[q * 64 + lane] = inq[q] ? ((lk + 4 * q) == lr ? qv : 0.0) + qv * qv * A[q] : 0.0;
+        if (lane == 0) { ssc[4] = 1.0; ssc[5] = qv; ssc[6] = qv; }
+      }
+      __syncthreads();
+    }
+    double sse_pred = 0.0;
+    unsigned long long inside_l = 0;
+    nmiss_l = 0;
+    // prefetch column 0.  The loads are UNCONDITIONAL (row index clamped, value masked where it is used): a load under a
+    // runtime predicate is branched around and waited for on the spot -- a full memory latency per column
+    double ny[2];
+    uint8_t nm[2], nmm[2];
+    int rowc[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      rowc[u] = min(ro + u * WG, d - 1);
+      ny[u] = Yorg[rowc[u]];
+      nm[u] = Mk[rowc[u]];
+      nmm[u] = Mm[rowc[u]];
+    }
+    for (int t = 0; t < n; ++t) {
+      const double* sxc = sx + cur * IR;
+      double* sxn = sx + (cur ^ 1) * IR;
+      double yv[2];
+      uint8_t mv[2], mmv[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) { yv[u] = ny[u]; mv[u] = nm[u]; mmv[u] = nmm[u]; }
+      {
+        const size_t cbase = (size_t)min(t + 1, n - 1) * d;      // (the last column is simply loaded twice)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          ny[u] = Yorg[cbase + rowc[u]];
+          nm[u] = Mk[cbase + rowc[u]];
+          nmm[u] = Mm[cbase + rowc[u]];
+        }
+      }
+      // ---- P1: residual rows; w = V x; per-wave sum(m), sum(e^2) ----
+      double yh[2], mloc = 0.0, eloc = 0.0;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int i = ro + u * WG;
+        yh[u] = 0.0;
+        if (i < d) {
+          // every LDS read of the row is issued before the first use (a loop over the runtime r waits for each pair in turn)
+          double cr[IR], xr[IR];
+#pragma unroll
+          for (int l = 0; l < IR; ++l) { cr[l] = sC[i * IR + l]; xr[l] = sxc[l]; }
+          double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+          for (int l = 0; l < IR; l += 2) { d0 = fma(cr[l], xr[l], d0); d1 = fma(cr[l + 1], xr[l + 1], d1); }
+          const double dot = d0 + d1;
+          const double mi = mv[u] ? 1.0 : 0.0;
+          const double yi = mv[u] ? yv[u] : 0.0;     // Y is 0 where unobserved (PSMF.py:147-148)
+          const double ei = mi * (yi - dot);
+          se[i] = ei;
+          smk[i] = mi;
+          yh[u] = dot;
+          mloc += mi;
+          eloc += ei * ei;
+        }
+      }
+      if (wv != 0 || d > 192) {          // (wave 0 owns rows only when d > 192)
+        mloc = wave_sum_f64_dpp(mloc);
+        eloc = wave_sum_f64_dpp(eloc);
+      }
+      if (lane == 0) { spart[2 * wv] = mloc; spart[2 * wv + 1] = eloc; }
+      if (wv == 3) {                     // w = V x and s = x^T V x (rows 192.. of a large d share the wave: after its rows)
+        double vr[IR], xr[IR];
+        const int li = lane & 15;
+#pragma unroll
+        for (int l = 0; l < IR; ++l) { vr[l] = sV[li * IR + l]; xr[l] = sxc[l]; }
+        double a0 = 0.0, a1 = 0.0;
+#pragma unroll
+        for (int l = 0; l < IR; l += 2) { a0 = fma(vr[l], xr[l], a0); a1 = fma(vr[l + 1], xr[l + 1], a1); }
+        const double a = a0 + a1;                                      // rows >= r of V are zero: a = 0 there
+        if (lane < IR) sw[lane] = a;
+        const double sv = wave_sum_f64_dpp(lane < IR ? a * sxc[li] : 0.0);
+        if (lane == 0) ssc[0] = sv;
+      }
+      IMP_T(0);
+      solve_barrier<true>();                                          // ---- barrier 1
+      IMP_T(1);
+      // ---- P2: augmented masked Gram on the matrix cores, wave w: 4-row groups w, w + 4, ... ----
+      double G[4], Bq[4], PP[4], kappa = 0.0, N = 0.0, eta = 0.0, s = 0.0, ee = 0.0, phi = 1.0, msum = 0.0, ild = 0.0;
+      double Lb[4] = {0.0, 0.0, 0.0, 0.0};
+      if (wv == 0) {
+        // wave 0 meanwhile: everything of P3a that does not need the Gram
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const double qd = par ? ((lk + 4 * q) == lr ? qv : 0.0) : Qm[q];
+          PP[q] = inq[q] ? (tmf ? ((lk + 4 * q) == lr ? 0.5 : 0.0) : Pm[q] + qd) : 0.0;     // TMF: P + Q := I / nu, nu = 2 (TMF.py:47,60)
+        }
+        s = ssc[0];
+        msum = (spart[0] + spart[2]) + (spart[4] + spart[6]);
+        ee = (spart[1] + spart[3]) + (spart[5] + spart[7]);
+        // weights of the observed rows: PSMF / rPSMF 1 / (rho + s) (PSMF.py:71-72), MLE-SMF 1 / rho (MLESMF.py:70), TMF 1
+        kappa = tmf ? 1.0 : fast_rcp(sgd ? rho : rho + s);
+        ild = fast_rcp(lam + dd);
+        if (lane == 0) ssc[7] = kappa;
+      } else {
+        f64x4 acc1 = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+        const int ngrp = (d + 3) >> 2;
+        for (int g = wv - 1; g < ngrp; g += 3) {
+          const int k = 4 * g + lk;                                     // < d4: padding rows hold zeros
+          const double cval = sC[k * IR + lr], ek = se[k], mk = smk[k];
+          const bool kin = true;
+          const double eaug = (one_tile && lr == r) ? ek : 0.0;         // augmented row / column r: e (already masked)
+          const double a = mk * cval + eaug;                           // (m is 0 / 1: exact; cval = 0 where eaug != 0)
+          const double b1 = cval + eaug;
+          acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b1, acc1, 0, 0, 0);
+          if (!one_tile) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a, (lr == 0 && kin) ? ek : 0.0, acc2, 0, 0, 0);
+        }
+        double* o = sgp + (size_t)(wv - 1) * 512;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[q * 64 + lane] = acc1[q];
+        if (!one_tile) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) o[256 + q * 64 + lane] = acc2[q];
+        }
+      }
+      IMP_T(2);
+      solve_barrier<true>();                                          // ---- barrier 2
+      IMP_T(3);
+      // ---- P3a (wave 0; wave 1 too when it inverts beside it): G, b, Lbar, <G, P + Q>, eta, N, phi ----
+      if (wv == 0 || (par && wv == 1)) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const double g0 = (sgp[q * 64 + lane] + sgp[512 + q * 64 + lane]) + sgp[1024 + q * 64 + lane];
+          double g1 = 0.0;
+          if (!one_tile) g1 = (sgp[256 + q * 64 + lane] + sgp[768 + q * 64 + lane]) + sgp[1280 + q * 64 + lane];
+          G[q] = inq[q] ? g0 : 0.0;
+          Bq[q] = one_tile ? g0 : g1;      // b_i = (C^T e)_i sits in column r (one tile) / column 0 (second tile) of rows i
+        }
+        if (par) {
+          const double iom = ssc[4], iq = fast_rcp(ssc[5]);
+          const double c1 = iom * iq, c2 = c1 * iq;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) Lb[q] = inq[q] ? ((lk + 4 * q) == lr ? c1 : 0.0) - c2 * sW[q * 64 + lane] : 0.0;
+        }
+      }
+      if (wv == 0) {
+        double tr = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) tr += G[q] * PP[q];
+        const double trGP = wave_sum_f64_dpp(tr);
+        eta = (rho * msum + trGP) * idd;     // divide by d, not by #observed (PSMF.py:77)
+        N = s + eta;
+        if (p.robust) phi = (lam + ee * fast_rcp(N)) * ild;           // rPSMF.py:112-114 (e = 0 on unobserved rows)
+        if (lane == 0) { ssc[1] = eta; ssc[2] = N; ssc[3] = phi; }
+      }
+      IMP_T(4);
+      solve_barrier<true>();                                          // ---- barrier 3
+      IMP_T(5);
+      if (par && wv == 1) {
+        // ---- P3b, wave 1: W_t = (M_t + I / q_t)^-1 for the next column's Lbar, beside wave 0's inversion of M_t ----
+        const double kap = ssc[7], iqt = fast_rcp(ssc[6]);
+        double A[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) A[q] = inq[q] ? Lb[q] + kap * G[q] + ((lk + 4 * q) == lr ? iqt : 0.0) : (((lk + 4 * q) == lr) ? 1.0 : 0.0);
+        wave_sweep16(A, r2, lk, lr, bad);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sW[q * 64 + lane] = inq[q] ? -A[q] : 0.0;      // read after barrier 4 + barrier 2 of the next column
+      } else if (wv == 0) {
+        // ---- P3b: P+ = ((P + Q)^-1 + kappa G)^-1, x_t, omega, P, Q: wave 0 alone, no barrier ----
+        double A[4];
+        if (par) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) A[q] = inq[q] ? Lb[q] + kappa * G[q] : (((lk + 4 * q) == lr) ? 1.0 : 0.0);
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) A[q] = inq[q] ? PP[q] : (((lk + 4 * q) == lr) ? 1.0 : 0.0);
+          wave_sweep16(A, r2, lk, lr, bad);                // -(P + Q)^-1
+#pragma unroll
+          for (int q = 0; q < 4; ++q) A[q] = inq[q] ? kappa * G[q] - A[q] : (((lk + 4 * q) == lr) ? 1.0 : 0.0);
+        }
+        wave_sweep16(A, r2, lk, lr, bad);                // -P+
+        // b by column: element (row r, column lr) of the augmented tile / (row lr, column 0) of the second tile
+        double bc;
+        if (one_tile) {
+          double t4[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) t4[q] = shfl_f64(Bq[q], ((r & 3) << 4) | lr);
+          bc = t4[0];
+#pragma unroll
+          for (int q = 1; q < 4; ++q) bc = ((r >> 2) == q) ? t4[q] : bc;
+        } else {
+          double t4[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) t4[q] = shfl_f64(Bq[q], (lr & 3) << 4);
+          bc = t4[0];
+#pragma unroll
+          for (int q = 1; q < 4; ++q) bc = ((lr >> 2) == q) ? t4[q] : bc;
+        }
+        if (lr >= r) bc = 0.0;
+        double z[4], part = 0.0;
+        const int lb = one_tile ? r : 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          z[q] = row_sum_f64_dpp(inq[q] ? -A[q] * bc : 0.0);          // (P+ C^T e)_i, i = lk + 4 q, in every lane of the row
+          part += ((lk + 4 * q) < r) ? Bq[q] * z[q] : 0.0;            // b_i z_i on the lanes that hold b_i (lr == lb)
+        }
+        const double bPb = (readlane_f64(part, lb) + readlane_f64(part, 16 + lb)) + (readlane_f64(part, 32 + lb) + readlane_f64(part, 48 + lb));
+        if (lr == 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int i = lk + 4 * q;
+            if (i < r) {
+              const double xn = sxc[i] + kappa * z[q];
+              sxn[i] = xn;                                // (entries >= r of both buffers stay zero)
+              Xg[(size_t)t * r + i] = xn;                 // the reference overwrites X[:, t] in place
+            }
+          }
+        }
+        double omega = 1.0;
+        if (p.robust) omega = (lam + kappa * ee - kappa * kappa * bPb) * ild;   // rPSMF.py:105
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          Pm[q] = inq[q] ? omega * -A[q] : 0.0;
+          if (p.robust) Qm[q] *= omega;
+        }
+        if (par && lane == 0) { ssc[4] = fast_rcp(omega); ssc[5] = qv; ssc[6] = qv * omega; }     // for the next column's Lbar
+        if (p.robust) { rho *= omega; lam += dd; qv *= omega; }
+      } else {
+        // ---- P4a (the other waves): rank-1 updates of C and V with N, phi of this column ----
+        const double Nn = ssc[2], ph = ssc[3], et = ssc[1];
+        const double wsc = fast_rcp(Nn);
+        const double csc = tmf ? gam : gam * fast_rcp(et);        // MLESMF.py:79, TMF.py:63
+        const int t0 = par ? 128 : 64;          // first thread of the updating waves
+        for (int idx = tid - t0; idx < d * IR; idx += WG - t0) {       // (padding columns: x, w are zero there)
+          const int i = idx >> 4, l = idx & 15;
+          sC[idx] += sgd ? se[i] * sxc[l] * csc : se[i] * sw[l] * wsc;
+        }
+        if (!sgd)
+          for (int idx = tid - t0; idx < r * IR; idx += WG - t0) {
+            const int i = idx >> 4, c = idx & 15;
+            sV[idx] = ph * (sV[idx] - sw[i] * sw[c] * wsc);
+          }
+      }
+      // ---- P4b: bands, metrics of the rows this thread owns ----
+      {
+        const double ss = ssc[0], et = ssc[1], Nn = ssc[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int i = ro + u * WG;
+          if (i < d) {
+            const double band = p.sig * sqrt(p.robust ? (ss * (mv[u] ? 1.0 : 0.0) + et) : (sgd ? et : Nn));   // rPSMF.py:121-123 / PSMF.py:83-84 / MLESMF.py:81-82
+            const double lo = yh[u] - band, hi = yh[u] + band;
+            if (mmv[u]) {
+              const double dl = yh[u] - yv[u];
+              sse_pred += dl * dl;
+              nmiss_l += 1;
+              if (it == p.n_iter - 1 && !tmf && yv[u] < hi && lo < yv[u]) inside_l += 1;
+            }
+            if (p.want_bands) {
+              const size_t off = ((size_t)rep * n + t) * d + i;
+              p.Yrec[off] = yh[u];
+              p.YrecL[off] = lo;
+              p.YrecH[off] = hi;
+            }
+          }
+        }
+      }
+      cur ^= 1;
+      IMP_T(6);
+      solve_barrier<true>();                                          // ---- barrier 4
+      IMP_T(7);
+    }
+    // ---- end of pass: RMSE of the one-step predictions, RMSE of C @ X, coverage ----
+    __syncthreads();                 // (drains the X stores of wave 0)
+    double nm_d = (double)nmiss_l;
+    double sse_full = 0.0;
+    for (int u = 0; u < 2; ++u) {
+      const int i = ro + u * WG;
+      if (i < d) {
+        for (int t = 0; t < n; ++t) {
+          if (Mm[(size_t)t * d + i]) {
+            double dot = 0.0;
+            // X was written by other threads of this workgroup: read around this CU's L1
+            for (int l = 0; l < r; ++l) dot += sC[i * IR + l] * __builtin_nontemporal_load(&Xg[(size_t)t * r + l]);
+            const double dl = dot - Yorg[(size_t)t * d + i];
+            sse_full += dl * dl;
+          }
+        }
+      }
+    }
+    double v0 = wave_sum(sse_pred), v1 = wave_sum(sse_full), v2 = wave_sum(nm_d), v3 = wave_sum((double)inside_l);
+    __syncthreads();
+    if (lane == 0) { sred[wv * 4 + 0] = v0; sred[wv * 4 + 1] = v1; sred[wv * 4 + 2] = v2; sred[wv * 4 + 3] = v3; }
+    __syncthreads();
+    if (tid == 0) {
+      const double tp = (sred[0] + sred[4]) + (sred[8] + sred[12]);
+      const double tf = (sred[1] + sred[5]) + (sred[9] + sred[13]);
+      const double tn = (sred[2] + sred[6]) + (sred[10] + sred[14]);
+      const double ti = (sred[3] + sred[7]) + (sred[11] + sred[15]);
+      p.Epred[(size_t)rep * p.n_iter + it] = sqrt(tp / tn);
+      p.Efull[(size_t)rep * p.n_iter + it] = sqrt(tf / tn);
+      if (it == p.n_iter - 1) p.inside[rep] = ti / tn;
+    }
+    __syncthreads();
+  }
+  for (int idx = tid; idx < d * r; idx += WG) { const int i = idx / r, l = idx - i * r; Cg[idx] = sC[i * IR + l]; }
+  if (wv < 2 && bad) *errflag = 1;           // (benign race: every writer stores 1)
+  __syncthreads();
+  if (tid == 0) p.err[rep] = *errflag;
+  IMP_TOUT();
+}
+
+inline size_t impute2_lds_bytes(int d, int r) {
+  const size_t d4 = ((size_t)d + 3) & ~(size_t)3;
+  const size_t doubles = d4 * IR + IR * IR + 3 * IR + 2 * d4 + 4 * 2 * 256 + 8 + 8 + 256 + 16 + 2;
+  return (doubles * 8 + 15) & ~(size_t)15;
 }
 
 inline size_t impute_lds_bytes(int d, int r) {
@@ -317,6 +795,7 @@ inline size_t impute_lds_bytes(int d, int r) {
 
 }  // namespace psmf
 
+#ifndef PSMF_IMPUTE_KERNEL_ONLY
 extern "C" int psmf_impute_run(const psmf_impute_config* cfg, const double* YorgInt, const uint8_t* M,
                                const uint8_t* Mmiss, double* C, double* X, const double* V, const double* P,
                                const double* Q, double rho, double* Epred, double* Efull, double* inside,
@@ -332,7 +811,8 @@ extern "C" int psmf_impute_run(const psmf_impute_config* cfg, const double* Yorg
   if (n < 2 || B < 1 || cfg->n_iter < 1) return fail(PSMF_ERR_ARG, "bad n / batch / n_iter");
   if (cfg->method < 0 || cfg->method > 3) return fail(PSMF_ERR_ARG, "method must be 0 (PSMF), 1 (rPSMF), 2 (MLE-SMF) or 3 (TMF)");
   if (cfg->want_bands && (!Yrec || !YrecL || !YrecH)) return fail(PSMF_ERR_ARG, "want_bands needs Yrec, YrecL, YrecH");
-  const size_t lds = impute_lds_bytes(d, r);
+  const bool v1 = getenv("PSMF_IMPUTE_V1") && atoi(getenv("PSMF_IMPUTE_V1")) != 0;     // the previous column loop (LDS sweeps, ~15 barriers per column)
+  const size_t lds = v1 ? impute_lds_bytes(d, r) : impute2_lds_bytes(d, r);
   if (lds > 160 * 1024) return fail(PSMF_ERR_ARG, "d * r does not fit one workgroup's LDS");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(PSMF_ERR_NO_DEVICE, "no HIP device visible");
@@ -382,13 +862,21 @@ extern "C" int psmf_impute_run(const psmf_impute_config* cfg, const double* Yorg
   ip.d = d; ip.n = n; ip.r = r; ip.n_iter = cfg->n_iter; ip.robust = cfg->method == 1; ip.method = cfg->method; ip.want_bands = cfg->want_bands;
   ip.sig = cfg->sig; ip.lambda0 = cfg->lambda0; ip.rho0 = rho;
   ip.Yorg = dY; ip.M = dM; ip.Mmiss = dMm; ip.C = dC; ip.X = dX; ip.V0 = dV; ip.P0 = dP; ip.Q0 = dQ;
-  ip.Epred = dEp; ip.Efull = dEf; ip.inside = dIn; ip.Yrec = dYr; ip.YrecL = dYl; ip.YrecH = dYh; ip.err = dErr;
+  ip.Epred = dEp; ip.Efull = dEf; ip.inside = dIn; ip.Yrec = dYr; ip.YrecL = dYl; ip.YrecH = dYh; ip.err = dErr; ip.prof = nullptr;
+  {
+    bool iso = Q[0] > 0.0 && !(getenv("PSMF_IMPUTE_PAR") && atoi(getenv("PSMF_IMPUTE_PAR")) == 0);
+    for (int i = 0; i < r && iso; ++i)
+      for (int c = 0; c < r; ++c)
+        if (Q[i * r + c] != (i == c ? Q[0] : 0.0)) { iso = false; break; }
+    ip.q_iso = iso ? 1 : 0;
+  }
   if (lds > 48 * 1024)
-    I_TRY(hipFuncSetAttribute((const void*)psmf_impute_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    I_TRY(hipFuncSetAttribute(v1 ? (const void*)psmf_impute_kernel : (const void*)psmf_impute_kernel2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   I_TRY(hipEventCreate(&e0));
   I_TRY(hipEventCreate(&e1));
   I_TRY(hipEventRecord(e0, 0));
-  hipLaunchKernelGGL(psmf_impute_kernel, dim3(B), dim3(WG), lds, 0, ip);
+  if (v1) hipLaunchKernelGGL(psmf_impute_kernel, dim3(B), dim3(WG), lds, 0, ip);
+  else hipLaunchKernelGGL(psmf_impute_kernel2, dim3(B), dim3(WG), lds, 0, ip);
   I_TRY(hipGetLastError());
   I_TRY(hipEventRecord(e1, 0));
   I_TRY(hipEventSynchronize(e1));
@@ -414,3 +902,4 @@ done:
 #undef I_TRY
   return rc;
 }
+#endif  // PSMF_IMPUTE_KERNEL_ONLY
