@@ -870,7 +870,10 @@ __device__ __forceinline__ void f3_v_program(const BlockParams& b, const F3Blk& 
 #undef F3_V0_FINISH_PREV
 }
 
-__global__ __launch_bounds__(F3_NT) void psmf_blk_filter3(BlockParams b0) {
+// SMALL = true: the r <= 16 instantiation, a kernel of its own -- compiled into the same kernel as the two r > 16 programs it
+// cost the r = 32 path 2 % (register allocation over the larger kernel: 111 spilled registers against 96; measured A / B on one box)
+template <bool SMALL>
+__device__ __forceinline__ void blk_filter3_body(const BlockParams& b0) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* sm = reinterpret_cast<double*>(smem_raw);
   const StepParams& p = b0.sp;
@@ -986,15 +989,15 @@ __global__ __launch_bounds__(F3_NT) void psmf_blk_filter3(BlockParams b0) {
   }
   if (role < 4) {
     const int inv = role >> 1;
-    if (r == 32) {
-      if (role & 1) f3_ns_program<1, 0>(b, k, L, inv, role, lane, carried);
-      else f3_ns_program<0, 0>(b, k, L, inv, role, lane, carried);
-    } else if (r > 16) {
-      if (role & 1) f3_ns_program<1, 1>(b, k, L, inv, role, lane, carried);
-      else f3_ns_program<0, 1>(b, k, L, inv, role, lane, carried);
-    } else {
+    if (SMALL) {
       if (role & 1) f3_ns_program<1, 2>(b, k, L, inv, role, lane, carried);
       else f3_ns_program<0, 2>(b, k, L, inv, role, lane, carried);
+    } else if (r == 32) {
+      if (role & 1) f3_ns_program<1, 0>(b, k, L, inv, role, lane, carried);
+      else f3_ns_program<0, 0>(b, k, L, inv, role, lane, carried);
+    } else if (r > 16) {       // (always true here; the test keeps the code placement of the build this kernel was tuned at: +-1.5 %)
+      if (role & 1) f3_ns_program<1, 1>(b, k, L, inv, role, lane, carried);
+      else f3_ns_program<0, 1>(b, k, L, inv, role, lane, carried);
     }
   } else {
     f3_v_program(b, k, L, role, lane, carried);
@@ -1017,5 +1020,8 @@ __global__ __launch_bounds__(F3_NT) void psmf_blk_filter3(BlockParams b0) {
     if (tid0 == 0) flag_store(b0.flags + 1, b0.seq + nchain);
   }
 }
+
+__global__ __launch_bounds__(F3_NT) void psmf_blk_filter3(BlockParams b0) { blk_filter3_body<false>(b0); }     // 16 < r <= 32
+__global__ __launch_bounds__(F3_NT) void psmf_blk_filter3s(BlockParams b0) { blk_filter3_body<true>(b0); }     // r <= 16
 
 }  // namespace psmf

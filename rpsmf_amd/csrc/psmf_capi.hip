@@ -226,7 +226,7 @@ void fill_block_params(psmf_filter* h, psmf::BlockParams& b, int64_t k0, int nb,
 }
 
 bool blk_use_mfma() {
-  static const bool off = getenv("PSMF_BLOCK_MFMA") && atoi(getenv("PSMF_BLOCK_MFMA")) == 0;
+  const bool off = getenv("PSMF_BLOCK_MFMA") && atoi(getenv("PSMF_BLOCK_MFMA")) == 0;     // (read per call: tests switch it inside one process)
   return !off;
 }
 
@@ -247,7 +247,7 @@ void launch_blk_gram(psmf_filter* h, const psmf::BlockParams& b, hipStream_t str
 
 // streaming bulk kernels (psmf_bulk.hip): float32 storage, d_local a multiple of 4, 16 <= r <= 32
 bool blk_bulk2_ok(const psmf_filter* h) {
-  static const bool off = getenv("PSMF_BULK2") && atoi(getenv("PSMF_BULK2")) == 0;
+  const bool off = getenv("PSMF_BULK2") && atoi(getenv("PSMF_BULK2")) == 0;     // (read per call: tests switch it inside one process)
   return !off && blk_use_mfma() && h->cfg.storage == PSMF_F32 && (h->cfg.d_local % 4) == 0 && h->cfg.r <= 32 && (h->geo.rp % 4) == 0;
 }
 
@@ -273,12 +273,12 @@ void launch_blk_xgram(psmf_filter* h, const psmf::BlockParams& x, double* xg, hi
 }
 
 bool blk_use_filter3() {
-  static const bool off = getenv("PSMF_FILTER3") && atoi(getenv("PSMF_FILTER3")) == 0;
+  const bool off = getenv("PSMF_FILTER3") && atoi(getenv("PSMF_FILTER3")) == 0;     // (read per call: tests switch it inside one process)
   return !off;
 }
 
 bool blk_dual_ok(const psmf_filter* h) {
-  static const bool off = getenv("PSMF_BLOCK_DUAL") && atoi(getenv("PSMF_BLOCK_DUAL")) == 0;
+  const bool off = getenv("PSMF_BLOCK_DUAL") && atoi(getenv("PSMF_BLOCK_DUAL")) == 0;     // (read per call: tests switch it inside one process)
   return !off && h->q_iso && h->cfg.coef_update && h->cfg.pbar_predict && h->cfg.eta_full &&
          h->cfg.dyn_kind == PSMF_DYN_RANDOM_WALK;
 }
@@ -286,7 +286,8 @@ bool blk_dual_ok(const psmf_filter* h) {
 void launch_blk_filter(psmf_filter* h, const psmf::BlockParams& b, hipStream_t stream = nullptr) {
   if (!stream) stream = h->stream;
   if (blk_dual_ok(h) && blk_use_filter3()) {
-    hipLaunchKernelGGL(psmf::psmf_blk_filter3, dim3(1), dim3(psmf::F3_NT), psmf::blk_filter3_lds_bytes(), stream, b);
+    if (h->cfg.r > 16) hipLaunchKernelGGL(psmf::psmf_blk_filter3, dim3(1), dim3(psmf::F3_NT), psmf::blk_filter3_lds_bytes(), stream, b);
+    else hipLaunchKernelGGL(psmf::psmf_blk_filter3s, dim3(1), dim3(psmf::F3_NT), psmf::blk_filter3_lds_bytes(), stream, b);
     return;
   }
   if (blk_dual_ok(h)) {
@@ -372,7 +373,10 @@ int enqueue_blocks_pipelined(psmf_filter* h, int64_t k_begin, int64_t k_end) {
   psmf::BlockParams b;
   // hand-off by device flags when the filter chain has a stream (hardware queue) of its own; by events otherwise
   const bool flags_off = getenv("PSMF_BLOCK_FLAGS") && atoi(getenv("PSMF_BLOCK_FLAGS")) == 0;
-  const bool use_flags = h->fstream != nullptr && h->flags != nullptr && !flags_off && h->streams_concurrent;   // (a tool that serialises dispatches: events)
+  // (a tool that serialises dispatches: events.  A host-mediated communicator synchronises the bulk stream at every exchange
+  //  anyway, and several such handles usually share one process and one GPU -- shards of a test -- where kernels that spin on
+  //  flags could end up behind each other in a shared hardware queue: events there, too)
+  const bool use_flags = h->fstream != nullptr && h->flags != nullptr && !flags_off && h->streams_concurrent && !h->host_fn;
   const long long s0 = h->seq_next;
   h->seq_next += nblk;
   // chain: the filter kernels of the whole run as ONE launch (psmf_blk_filter3; the bulk stream is driven as before)
@@ -726,6 +730,7 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_apply_mfma<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)alds));
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_apply_mfma<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)alds));
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_filter3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psmf::blk_filter3_lds_bytes()));
+    CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_filter3s, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psmf::blk_filter3_lds_bytes()));
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_xgram2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psmf::blk_xgram2_lds_bytes()));
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_xgram2<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psmf::blk_xgram2_lds_bytes()));
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_apply2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psmf::blk_apply2_lds_bytes()));

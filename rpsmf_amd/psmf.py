@@ -618,23 +618,32 @@ class PSMFIter:
         return self._dev.sq_error(0, T)
 
 
-def _recursive_kwargs(obj, kw):
-    """Adds the in-loop Adam configuration (psmf.py:224-242,299-304) to the device options."""
+def _device_optimiser(obj):
+    """Keyword arguments of the in-loop optimiser the device implements -- Adam (psmf.py:224-242) with a constant or an
+    exponentially decaying learning rate (learning_rate.py:13-27) -- or None: SGD (psmf.py:244-248) and custom
+    learning-rate schedules keep theta and its optimiser on the host (host-stepped device loop)."""
+    if obj.optim != "adam":
+        return None
     gam = getattr(obj, "adam_gam", ConstantLearningRate(1e-3))
     if isinstance(gam, ConstantLearningRate):
-        lr = dict(adam_lr=gam.lr)
-    elif hasattr(gam, "lr_start"):
-        lr = dict(adam_lr=gam.lr_start, adam_lr_end=gam.lr_end, adam_lr_steps=gam.steps)
-    else:
-        raise NotImplementedError("custom learning-rate schedules need backend='numpy'")
+        return dict(adam_lr=gam.lr)
+    if hasattr(gam, "lr_start") and hasattr(gam, "lr_end") and hasattr(gam, "steps"):
+        return dict(adam_lr=gam.lr_start, adam_lr_end=gam.lr_end, adam_lr_steps=gam.steps)
+    return None
+
+
+def _recursive_kwargs(obj, kw):
+    """Adds the in-loop Adam configuration (psmf.py:224-242,299-304) to the device options."""
     if kw.get("dyn_kind") == _capi.DYN_HOST:
         return kw               # host-stepped: theta and its optimiser (Adam or SGD, any schedule) stay on the host
-    if obj.optim != "adam":
-        raise NotImplementedError("the in-loop optimiser on the device is Adam; SGD runs host-stepped (construct with engine='step' "
-                                  "and a plain-callable nonlinearity) or with backend='numpy'")
     kw.update(recursive=True, update_every=getattr(obj, "_update_every", 1),
-              adam_b1=getattr(obj, "adam_b1", 0.9), adam_b2=getattr(obj, "adam_b2", 0.999), **lr)
+              adam_b1=getattr(obj, "adam_b1", 0.9), adam_b2=getattr(obj, "adam_b2", 0.999), **_device_optimiser(obj))
     return kw
+
+
+def _recursive_host_stepped(obj, base):
+    """Recursive classes: also host-stepped when the in-loop optimiser is not one the device implements."""
+    return base or (np.asarray(obj.theta0).size > 0 and _device_optimiser(obj) is None)
 
 
 class PSMFIterMissing(PSMFIter):
@@ -691,14 +700,17 @@ class PSMFRecursive(PSMFIter):
 
     def predict(self, T, n_pred):
         if self.backend == "hip" and self._dev is not None and isinstance(self._y_pred, _YPred):
-            return self._predict_hip(T, T, n_pred)
+            return self._predict_hip(T + 1, T, n_pred)        # rolls forward with theta_T (psmf.py:324-331)
         last_theta = self._theta[T]
         self._mu_pred = {T: self._mu[T]}
         for k in range(T + 1, T + n_pred + 1):
             self._mu_pred[k] = self._nl(last_theta, self._mu_pred[k - 1], k)
             self._y_pred[k] = self._C[T] @ self._mu_pred[k]
 
-    # device: Adam runs inside the serial stage of every step
+    # device: Adam runs inside the time loop of either engine; SGD / custom schedules: host-stepped
+    def _host_stepped(self):
+        return _recursive_host_stepped(self, super()._host_stepped())
+
     def _device_kwargs(self):
         return _recursive_kwargs(self, super()._device_kwargs())
 

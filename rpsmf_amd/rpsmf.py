@@ -131,6 +131,9 @@ class rPSMFRecursive(rPSMFIter):
     _carry_theta = _psmf.PSMFRecursive._carry_theta
     _step_hip_recursive = _psmf.PSMFRecursive._step_hip_recursive
 
+    def _host_stepped(self):
+        return _psmf._recursive_host_stepped(self, rPSMFIter._host_stepped(self))
+
     def _device_kwargs(self):
         return _psmf._recursive_kwargs(self, rPSMFIter._device_kwargs(self))
 

@@ -320,3 +320,30 @@ def test_tracking_error_norms_on_device():
         assert relerr(f._E_train[i], np.linalg.norm(Yp[:T] - Y[:T])) < 1e-10
         assert relerr(f._E_pred[i], np.linalg.norm(Yp[T:] - Y[T:])) < 1e-10
     assert f._tracking_on_device == 2 and len(f._logs) == 2
+
+
+@pytest.mark.parametrize("robust", [False, True], ids=["PSMF", "rPSMF"])
+def test_recursive_sgd_runs_host_stepped(robust):
+    """SGD inside the recursive loop (psmf.py:244-248,299-304) is not an optimiser the device kernels carry: theta and the
+    optimiser stay on the host, the device advances one step at a time -- same numbers as the numpy back end."""
+    g = load_golden("rpsmf_recursive" if robust else "psmf_recursive")
+    T, n_pred, ue = int(g["T"]), int(g["n_pred"]), int(g["update_every"])
+    d, r = g["C0"].shape
+    theta0, mu0 = g["theta0"].reshape(-1, 1), g["mu0"].reshape(-1, 1)
+    out = []
+    for kw in (dict(storage="f64"), dict(backend="numpy")):
+        nl = psmf.CosPhase(r)
+        if robust:
+            f = psmf.rPSMFRecursive(theta0, g["C0"], g["V0"], mu0, g["P0"], g["Q"], np.eye(d), 1.8, nl, optim="sgd", **kw)
+        else:
+            f = psmf.PSMFRecursive(theta0, g["C0"], g["V0"], mu0, g["P0"], {k: g["Q"] for k in range(T + 1)},
+                                   {k: np.eye(d) for k in range(T + 1)}, nl, optim="sgd", **kw)
+        f._update_every = ue                 # run() with a small step size: plain SGD at the default 1e-3 moves theta by O(1)
+        f.optim_init(gam=1e-7)               # per observation here (gradients of O(10^3)) and the comparison turns chaotic
+        f.step(ydict(g["Y"]), T)
+        f.predict(T, n_pred)
+        out.append((f._theta[T].reshape(-1), f._C[T], np.array([f._y_pred[k].reshape(-1) for k in range(1, T + n_pred + 1)])))
+        if "storage" in kw:
+            assert f._dev.dyn_kind == _capi().DYN_HOST
+    for a, b in zip(*out):
+        assert relerr(a, b) < 1e-9
