@@ -20,6 +20,13 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "timeout: per-test limit (pytest-timeout, when installed)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """A hung GPU test must fail, not stall the whole run: default per-test limit (inert without pytest-timeout)."""
+    for it in items:
+        if it.get_closest_marker("gpu") is not None and it.get_closest_marker("timeout") is None:
+            it.add_marker(pytest.mark.timeout(480))
+
+
 def load_golden(name):
     with np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False) as z:
         return {k: z[k] for k in z.files}
