@@ -87,6 +87,8 @@ typedef struct {
                             the steps in coefficient space; needs r <= 32)                      */
   int32_t dyn_flags;     /* see psmf_dyn_kind                                                  */
   int32_t dyn_terms;     /* PSMF_DYN_FOURIER: N                                                */
+  int32_t nonuniform_R;  /* 1: R = rho * diag(rho_rows) with per-row values uploaded by psmf_set_row_noise
+                            (psmf.py:140-153 takes any diagonal R); per-step engine, weighted Gram every step */
   double alpha, beta;    /* rPSMF scaling factors (rpsmf.py:45-51), 1.0 unless use_scaling     */
   double adam_lr, adam_lr_end, adam_lr_steps; /* lr (Constant) or lr_start/lr_end/steps
                             (ExponentialLearningRate, learning_rate.py:20-27; steps = 0 ->
@@ -120,6 +122,11 @@ int psmf_set_adam(psmf_handle h, const double* m, const double* v);
  * step k = 1 .. n - 1 (entry 0 unused; steps beyond n - 1 are refused by psmf_run).  NULL = constant (rho / Q of
  * psmf_set_state).  Not with robust = 1 (rPSMF runs on its own omega-scaled Q_{k-1}, R_{k-1}, rpsmf.py:123,128,141). */
 int psmf_set_schedules(psmf_handle h, const double* rho_k, const double* q_k, int64_t n);
+
+/* Non-uniform diagonal R (cfg.nonuniform_R = 1): rho_rows[d_local] = diag(R) of this handle's rows, rho_mean = sum of diag(R)
+ * over ALL rows / d (tr(R) / d of psmf.py:121-125; the same value on every shard).  The `rho` of psmf_set_state is then the
+ * scalar in front (1 to start with; rPSMF multiplies it by omega_k, rpsmf.py:169). */
+int psmf_set_row_noise(psmf_handle h, const double* rho_rows, double rho_mean);
 
 /* ---- series ---------------------------------------------------------------------------- */
 /* Y: nt x d_local time-major block holding y_{t0+1} .. y_{t0+nt}; T_total sizes the device

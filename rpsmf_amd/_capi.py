@@ -29,7 +29,7 @@ class PsmfConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "abi_version", "d", "r", "row0", "d_local", "robust", "coef_update", "eta_full", "pbar_predict",
         "fixed_lambda", "dyn_kind", "n_theta", "storage", "store_y_pred", "recursive", "update_every",
-        "gram_refresh", "device", "use_graph", "n_workgroups", "engine", "dyn_flags", "dyn_terms")] + [(n, C.c_double) for n in (
+        "gram_refresh", "device", "use_graph", "n_workgroups", "engine", "dyn_flags", "dyn_terms", "nonuniform_R")] + [(n, C.c_double) for n in (
         "alpha", "beta", "adam_lr", "adam_lr_end", "adam_lr_steps", "adam_b1", "adam_b2")]
 
 
@@ -54,6 +54,7 @@ SIGNATURES = {
     "psmf_get_state": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
     "psmf_set_adam": (C.c_int, [C.c_void_p, _dp, _dp]),
     "psmf_set_schedules": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int64]),
+    "psmf_set_row_noise": (C.c_int, [C.c_void_p, _dp, C.c_double]),
     "psmf_step_host": (C.c_int, [C.c_void_p, C.c_int64, _dp, _dp, _dp, _dp, _dp, _dp]),
     "psmf_project": (C.c_int, [C.c_void_p, _dp, C.c_int64, _dp]),
     "psmf_predict_sq_error": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, _dp, _dp]),
@@ -131,7 +132,7 @@ class DeviceFilter:
                  fixed_lambda=False, dyn_kind=DYN_RANDOM_WALK, storage="f32", store_y_pred=True,
                  recursive=False, update_every=1, gram_refresh=0, device=0, use_graph=True,
                  n_workgroups=0, engine="auto", alpha=1.0, beta=1.0, adam_lr=1e-3, adam_lr_end=0.0, adam_lr_steps=0.0,
-                 adam_b1=0.9, adam_b2=0.999, row0=0, d_local=None, dyn_flags=0, dyn_terms=0):
+                 adam_b1=0.9, adam_b2=0.999, row0=0, d_local=None, dyn_flags=0, dyn_terms=0, nonuniform_R=False):
         self._lib = load_library()
         self._h = C.c_void_p()
         self.d, self.r = int(d), int(r)
@@ -143,7 +144,8 @@ class DeviceFilter:
             # f32 where the blocked engine runs (C is rounded once per block of 64 - r timesteps: errors ~1e-6);
             # f64 where the per-step engine runs (one rounding of C per timestep would breach the 1e-5 bar around
             # k = 300)
-            blocked = engine in ("auto", "block", 0, 2) and self.r <= 32 and self.dyn_kind != DYN_HOST and os.environ.get("PSMF_ENGINE") != "1"
+            blocked = (engine in ("auto", "block", 0, 2) and self.r <= 32 and self.dyn_kind != DYN_HOST and not nonuniform_R
+                       and os.environ.get("PSMF_ENGINE") != "1")
             storage = "f32" if blocked else "f64"
         self.storage = F64 if storage in ("f64", F64, np.float64) else F32
         self.store_y_pred = bool(store_y_pred)
@@ -154,7 +156,7 @@ class DeviceFilter:
             n_theta=self.n_theta, storage=self.storage, store_y_pred=int(store_y_pred),
             recursive=int(recursive), update_every=int(update_every), gram_refresh=int(gram_refresh),
             device=int(device), use_graph=int(use_graph), n_workgroups=int(n_workgroups),
-            engine={"auto": 0, "step": 1, "block": 2}.get(engine, engine), dyn_flags=int(dyn_flags), dyn_terms=int(dyn_terms),
+            engine={"auto": 0, "step": 1, "block": 2}.get(engine, engine), dyn_flags=int(dyn_flags), dyn_terms=int(dyn_terms), nonuniform_R=int(bool(nonuniform_R)),
             alpha=float(alpha), beta=float(beta), adam_lr=float(adam_lr), adam_lr_end=float(adam_lr_end),
             adam_lr_steps=float(adam_lr_steps), adam_b1=float(adam_b1), adam_b2=float(adam_b2))
         rc = self._lib.psmf_create(C.byref(self._h), C.byref(cfg))
@@ -233,6 +235,13 @@ class DeviceFilter:
         T_total = t0 + nt if T_total is None else int(T_total)
         self._check(self._lib.psmf_upload_series(self._h, Y.ctypes.data_as(C.c_void_p), dt, t0, nt, T_total))
         self.T = max(self.T, T_total)
+
+    def set_row_noise(self, rho_rows, rho_mean=None):
+        """diag(R) of this handle's rows (nonuniform_R handles); rho_mean = sum(diag R) over ALL rows / d (default: these rows')"""
+        rho_rows = _f64(rho_rows, (self.d_local,))
+        if rho_mean is None:
+            rho_mean = float(rho_rows.sum()) / self.d
+        self._check(self._lib.psmf_set_row_noise(self._h, _ptr(rho_rows), float(rho_mean)))
 
     def set_schedules(self, rho_k=None, q_k=None):
         """R_k = rho_k[k] I, Q_k = q_k[k] Q for the 1-based step k (entry 0 unused); None = constant."""

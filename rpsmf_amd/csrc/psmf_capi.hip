@@ -48,6 +48,7 @@ struct psmf_filter {
   double* gpart = nullptr;
   double* thbuf = nullptr;     // theta | gradsum | adam_m | adam_v, th_cap doubles each
   size_t th_cap = 0;
+  double* rho_rows = nullptr;  // d_local per-row diag(R) (cfg.nonuniform_R)
   double* sched = nullptr;     // rho_k | q_k schedules, sched_n doubles each (psmf_set_schedules)
   int64_t sched_n = 0;
   double* mu_hist = nullptr;   // (T_cap + 1) x r
@@ -201,11 +202,17 @@ void launch_serial(psmf_filter* h, int first) {
 }
 
 // one filter step on the stream (captured into the graph or launched eagerly)
+int enqueue_weighted_gram(psmf_filter* h);
+
 int enqueue_step(psmf_filter* h) {
+  if (h->sp.rho_rows && h->cfg.coef_update) {      // non-uniform diagonal R: this step's weighted Gram, before the sweep rewrites C
+    const int rc = enqueue_weighted_gram(h);
+    if (rc) return rc;
+  }
   launch_sweep(h);
   if (h->use_coll) {
     hipLaunchKernelGGL(psmf::psmf_reduce_partials, dim3(1), dim3(psmf::WG), 0, h->stream, h->sp);
-    const int rc = all_reduce_sum(h, h->st->red, h->cfg.r + 1, h->stream);
+    const int rc = all_reduce_sum(h, h->st->red, h->geo.ps, h->stream);
     if (rc) return rc;
   }
   launch_serial(h, 0);
@@ -460,20 +467,22 @@ int enqueue_blocks_pipelined(psmf_filter* h, int64_t k_begin, int64_t k_end) {
   return PSMF_OK;
 }
 
-int enqueue_gram(psmf_filter* h) {
+int enqueue_gram_into(psmf_filter* h, double* Gout, const DevState* wst, const double* rho_rows) {
   const int r = h->cfg.r;
   const int rows = (h->cfg.d_local + kGramWG - 1) / kGramWG;
   if (h->cfg.storage == PSMF_F64)
     hipLaunchKernelGGL(psmf::psmf_gram_partial<double>, dim3(kGramWG), dim3(psmf::WG), 0, h->stream,
-                       (const double*)h->C, h->cfg.d_local, r, h->geo.rp, rows, h->gpart);
+                       (const double*)h->C, h->cfg.d_local, r, h->geo.rp, rows, h->gpart, wst, rho_rows);
   else
     hipLaunchKernelGGL(psmf::psmf_gram_partial<float>, dim3(kGramWG), dim3(psmf::WG), 0, h->stream,
-                       (const float*)h->C, h->cfg.d_local, r, h->geo.rp, rows, h->gpart);
+                       (const float*)h->C, h->cfg.d_local, r, h->geo.rp, rows, h->gpart, wst, rho_rows);
   hipLaunchKernelGGL(psmf::psmf_gram_reduce, dim3((r * r + 255) / 256), dim3(256), 0, h->stream,
-                     (const double*)h->gpart, kGramWG, r * r, h->st->G);
-  if (h->use_coll) { const int rc = all_reduce_sum(h, h->st->G, (size_t)r * r, h->stream); if (rc) return rc; }
+                     (const double*)h->gpart, kGramWG, r * r, Gout);
+  if (h->use_coll) { const int rc = all_reduce_sum(h, Gout, (size_t)r * r, h->stream); if (rc) return rc; }
   return PSMF_OK;
 }
+int enqueue_gram(psmf_filter* h) { return enqueue_gram_into(h, h->st->G, nullptr, nullptr); }
+int enqueue_weighted_gram(psmf_filter* h) { return enqueue_gram_into(h, h->st->GR, h->st, h->sp.rho_rows); }
 
 void destroy_graph(psmf_filter* h) {
   if (h->gexec) { hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
@@ -523,7 +532,7 @@ void compute_geometry(const psmf_config& c, Geometry& g) {
   if (rows < g.rpp) rows = g.rpp;
   g.rows_per_wg = rows;
   g.n_sweep_wg = (c.d_local + rows - 1) / rows;
-  g.ps = c.r + 1;
+  g.ps = c.nonuniform_R ? 2 * (c.r + 1) : c.r + 1;      // partial row: h, ee (+ the weighted b, q)
 }
 
 int set_device(psmf_handle h) {
@@ -645,8 +654,8 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
   CREATE_TRY(hipMalloc((void**)&h->partials, (size_t)h->geo.n_sweep_wg * h->geo.ps * sizeof(double)));
   CREATE_TRY(hipMalloc((void**)&h->gpart, (size_t)kGramWG * cfg->r * cfg->r * sizeof(double)));
   {
-    const bool can_block = cfg->r <= psmf::RM / 2 && cfg->dyn_kind != PSMF_DYN_HOST;
-    if (cfg->engine == 2 && !can_block) { h->err = "psmf_create: the blocked engine needs r <= 32 and device-evaluated dynamics"; return bail(PSMF_ERR_ARG); }
+    const bool can_block = cfg->r <= psmf::RM / 2 && cfg->dyn_kind != PSMF_DYN_HOST && !cfg->nonuniform_R;
+    if (cfg->engine == 2 && !can_block) { h->err = "psmf_create: the blocked engine needs r <= 32, device-evaluated dynamics and a uniform diagonal R"; return bail(PSMF_ERR_ARG); }
     if (cfg->engine < 0 || cfg->engine > 2) { h->err = "psmf_create: engine must be 0 (auto), 1 (per-step) or 2 (blocked)"; return bail(PSMF_ERR_ARG); }
     // auto: blocked whenever it applies -- it is exact and removes the per-step launches and row sweeps
     h->engine = cfg->engine == 0 ? (can_block ? 2 : 1) : cfg->engine;
@@ -757,6 +766,7 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
   sp.dyn_flags = cfg->dyn_flags; sp.dyn_terms = cfg->dyn_terms;
   sp.theta = h->thbuf; sp.gradsum = h->thbuf + h->th_cap; sp.adam_m = h->thbuf + 2 * h->th_cap; sp.adam_v = h->thbuf + 3 * h->th_cap;
   sp.rho_sched = nullptr; sp.q_sched = nullptr;
+  sp.rho_rows = nullptr; sp.rho_mean = 1.0;
   sp.recursive = cfg->recursive; sp.update_every = cfg->update_every > 0 ? cfg->update_every : 1;
   sp.track_g = (cfg->eta_full || cfg->coef_update) ? 1 : 0;
   sp.external_reduce = 0;
@@ -790,6 +800,7 @@ void psmf_destroy(psmf_handle h) {
   if (h->mu_hist) hipFree(h->mu_hist);
   if (h->thbuf) hipFree(h->thbuf);
   if (h->sched) hipFree(h->sched);
+  if (h->rho_rows) hipFree(h->rho_rows);
   if (h->Kpart) hipFree(h->Kpart);
   if (h->Kmat) hipFree(h->Kmat);
   if (h->Acoef) hipFree(h->Acoef);
@@ -968,6 +979,7 @@ int psmf_run(psmf_handle h, int64_t k_begin, int64_t k_end) {
   if (k_begin < 0 || k_end < k_begin || k_end > h->T_cap) return fail(h, PSMF_ERR_ARG, "psmf_run: step range outside the uploaded series");
   if (h->cfg.dyn_kind == PSMF_DYN_HOST) return fail(h, PSMF_ERR_STATE, "psmf_run: host-stepped dynamics advance with psmf_step_host");
   if (h->sched && k_end >= h->sched_n) return fail(h, PSMF_ERR_ARG, "psmf_run: step range beyond the R / Q schedules");
+  if (h->cfg.nonuniform_R && !h->sp.rho_rows) return fail(h, PSMF_ERR_STATE, "psmf_run: psmf_set_row_noise first (nonuniform_R = 1)");
   int rc = set_device(h);
   if (rc) return rc;
   if (h->need_prep || h->k_done != k_begin) {
@@ -1367,6 +1379,23 @@ int psmf_comm_init(psmf_handle h, int nranks, int rank, const void* unique_id) {
   }
   h->use_coll = nranks > 1 || getenv("PSMF_FORCE_COLLECTIVE") != nullptr;
   h->sp.external_reduce = h->use_coll ? 1 : 0;
+  destroy_graph(h);
+  h->need_prep = true;
+  return PSMF_OK;
+}
+
+int psmf_set_row_noise(psmf_handle h, const double* rho_rows, double rho_mean) {
+  if (!h || !rho_rows || !(rho_mean > 0.0)) return fail(h, PSMF_ERR_ARG, "psmf_set_row_noise: bad argument");
+  if (!h->cfg.nonuniform_R) return fail(h, PSMF_ERR_STATE, "psmf_set_row_noise: the handle was created with nonuniform_R = 0");
+  for (int i = 0; i < h->cfg.d_local; ++i)
+    if (!(rho_rows[i] >= 0.0)) return fail(h, PSMF_ERR_ARG, "psmf_set_row_noise: diag(R) must be non-negative");
+  int rc = set_device(h);
+  if (rc) return rc;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (!h->rho_rows) HIP_TRY(h, hipMalloc((void**)&h->rho_rows, (size_t)h->cfg.d_local * sizeof(double)));
+  HIP_TRY(h, hipMemcpy(h->rho_rows, rho_rows, (size_t)h->cfg.d_local * sizeof(double), hipMemcpyHostToDevice));
+  h->sp.rho_rows = h->rho_rows;
+  h->sp.rho_mean = rho_mean;
   destroy_graph(h);
   h->need_prep = true;
   return PSMF_OK;

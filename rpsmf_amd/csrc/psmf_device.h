@@ -18,6 +18,7 @@ struct DevState {
   double Pbar[RM * RM];   // predictive covariance of the current step
   double Q[RM * RM];      // running Q (scaled by omega in rPSMF)
   double G[RM * RM];      // Gram matrix C^T C of the current C (tracked algebraically)
+  double GR[RM * RM];     // non-uniform diagonal R: weighted Gram sum_i c_i c_i^T / (rho_i + s) of the CURRENT step (psmf_gram_partial)
   // carried across the blocks of the blocked engine (valid while ns_valid != 0):
   double Lbar[RM * RM / 4];   // r x r (r <= 32): Pbar^-1 of the next step
   double XpX[RM * RM / 4];    // last P+ (Newton-Schulz start of half X)
@@ -27,7 +28,7 @@ struct DevState {
   double w[RM];           // V mu_bar
   double wN[RM];          // w / N   (rank-1 update direction used by the row sweep)
   double gf[RM];          // d(incremental likelihood)/d f of the last finished step (host-stepped dynamics: the host forms J_theta^T gf)
-  double red[RM + 8];     // h[0..r), ee at [r]: all-reduced partial sums (multi-GPU path)
+  double red[2 * (RM + 1) + 6];   // h[0..r), ee at [r] (+ b, q of a non-uniform R behind them): all-reduced partial sums (multi-GPU path)
   double rho, lam;        // running diag(R) (uniform) and Student-t dof
   double s, eta, N, kappa;  // scalars of the current step
   double phi, omega, ee;  // scalars of the last finished step
@@ -69,6 +70,10 @@ struct StepParams {
   // step; nullptr = constant
   const double* rho_sched;
   const double* q_sched;
+  // non-uniform diagonal R (per-step engine): R = st->rho * diag(rho_rows), st->rho starting at 1 (rPSMF scales it by omega);
+  // rho_mean = sum(rho_rows over ALL shards) / d, so that tr(R) / d = st->rho * rho_mean.  nullptr / 1.0: uniform R = st->rho I
+  const double* rho_rows;
+  double rho_mean;
   int external_reduce;  // 1: partial sums were reduced into st->red (multi-GPU)
   int use_ns;           // 1: Newton-Schulz refinement of the r x r inverses (f64 MFMA), sweep as fallback
   double alpha, beta, lr, lr_end, lr_steps, b1, b2;

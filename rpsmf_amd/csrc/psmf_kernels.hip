@@ -207,7 +207,7 @@ __device__ __forceinline__ void solve_block_t(const StepParams& p, double* sm) {
     const bool in = (i < r && c < r);
     const double pv = in ? 0.5 * (st->Pbar[i * r + c] + st->Pbar[c * r + i]) : 0.0;
     A[m] = in ? pv : ((i == c && i < r2) ? 1.0 : 0.0);
-    Gk[m] = in ? kappa * st->G[i * r + c] : 0.0;
+    Gk[m] = in ? (p.rho_rows ? st->GR[i * r + c] : kappa * st->G[i * r + c]) : 0.0;   // non-uniform R: sum_i c_i c_i^T / (rho_i + s), this step's
   }
   spd_update_solve<RPAD>(A, Gk, r2, c, rg, rowbuf, errflag);
 #pragma unroll
@@ -268,6 +268,14 @@ __global__ __launch_bounds__(NT) void psmf_sweep_solve(StepParams p) {
 #pragma unroll
   for (int v = 0; v < VEC; ++v) hacc[v] = 0.0;
   double eacc = 0.0;
+  // non-uniform diagonal R: also the weighted sums b = sum_i kappa_i c_i e_i, q = sum_i kappa_i e_i^2, kappa_i = 1 / (rho_i + s)
+  // (psmf.py:140-159 with a diagonal R: SURVEY App. A); rows of partials then hold 2 (r + 1) values
+  const double* __restrict__ rrow = p.rho_rows;
+  const double rsc = st->rho, sk = st->s;
+  double hacc2[VEC];
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) hacc2[v] = 0.0;
+  double eacc2 = 0.0;
 
   const int row_begin = wgid * p.rows_per_wg;
   const int row_end = min(row_begin + p.rows_per_wg, p.d_local);
@@ -285,6 +293,9 @@ __global__ __launch_bounds__(NT) void psmf_sweep_solve(StepParams p) {
       cv[u] = *reinterpret_cast<const VT*>(C + (size_t)row * rp + jl * VEC);
       yv[u] = y[row];
     }
+    double kr[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) kr[u] = rrow ? rrow[min(base + u * RPP + g, row_end - 1)] : 0.0;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int row = base + u * RPP + g;
@@ -304,6 +315,12 @@ __global__ __launch_bounds__(NT) void psmf_sweep_solve(StepParams p) {
       for (int v = 0; v < VEC; ++v) {
         cn[v] = (T)(cd[v] + e * wn[v]);      // one rounding to the storage type per step
         hacc[v] += cd[v] * e;
+      }
+      if (rrow) {
+        const double ke = e * fast_rcp(rsc * kr[u] + sk);     // kappa_i e_i  (0 on rows beyond the end: e = 0)
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) hacc2[v] += cd[v] * ke;
+        if (j == 0) eacc2 += e * ke;
       }
       if (ok && lane_on) *reinterpret_cast<VT*>(C + (size_t)row * rp + j * VEC) = cn;
       if (ok && j == 0) {
@@ -335,6 +352,28 @@ __global__ __launch_bounds__(NT) void psmf_sweep_solve(StepParams p) {
     for (int w = 0; w < NW; ++w) s4 += sm[w * (NE + 1) + tid];   // fixed order
     if (tid < r) out[tid] = s4;
     if (tid == NE) out[r] = s4;
+  }
+  if (rrow) {          // the weighted sums the same way (second half of the partial row)
+    __syncthreads();
+#pragma unroll
+    for (int m = 32; m >= GS; m >>= 1) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) hacc2[v] += __shfl_xor(hacc2[v], m, 64);
+      eacc2 += __shfl_xor(eacc2, m, 64);
+    }
+    if (lane < GS) {
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) sm[wv * (NE + 1) + lane * VEC + v] = hacc2[v];
+      if (lane == 0) sm[wv * (NE + 1) + NE] = eacc2;
+    }
+    __syncthreads();
+    if (tid <= NE) {
+      double s4 = 0.0;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) s4 += sm[w * (NE + 1) + tid];
+      if (tid < r) out[r + 1 + tid] = s4;
+      if (tid == NE) out[2 * r + 1] = s4;
+    }
   }
 }
 
@@ -386,14 +425,15 @@ __device__ __forceinline__ void serial_body(const StepParams& p, const int first
   const double dd = (double)p.d;
 
   __shared__ double s_red[WG];
-  __shared__ double s_he[RM + 1];   // h[0..r), ee at [r]
+  __shared__ double s_he[2 * (RM + 1)];   // h[0..r), ee at [r]; non-uniform R: b[r+1 .. 2r], q at [2r+1]
   __shared__ double s_w[RM], s_mub[RM], s_f[RM], s_vec[RM];
-  __shared__ double s_part[NSEG][RM + 1];
+  __shared__ double s_part[NSEG][2 * (RM + 1)];
   __shared__ double s4[4];
 
   PSMF_STAMP(0);
   // ---------------- every global load of the stage, issued up front ----------------
-  const int ne = r + 1;
+  const bool wR = p.rho_rows != nullptr;     // non-uniform diagonal R: the partial rows carry the weighted sums too
+  const int ne = wR ? 2 * (r + 1) : r + 1;
   int nseg = (int)blockDim.x / ne;
   if (nseg > NSEG) nseg = NSEG;
   const int pe = tid % ne, psg = tid / ne;
@@ -444,7 +484,7 @@ __device__ __forceinline__ void serial_body(const StepParams& p, const int first
 
   asm volatile("" :: "v"(psum), "v"(Vv[0]), "v"(Pv[0]));
   PSMF_STAMP(1);
-  if (tid <= RM) s_he[tid] = 0.0;
+  if (tid < 2 * (RM + 1)) s_he[tid] = 0.0;
   if (tid < RM) { s_mub[tid] = 0.0; s_w[tid] = 0.0; }
   if (!first) {
     // ---- fixed-order reduction of the per-workgroup partials ----
@@ -479,17 +519,20 @@ __device__ __forceinline__ void serial_body(const StepParams& p, const int first
     const double wj = j < r ? s_w[j] : 0.0;
 
     // ---- coefficient mean / covariance   psmf.py:155-165 ----
-    double quad = kappa * ee;
+    // uniform R: b = kappa h, q = kappa ee; non-uniform diagonal R: the sweep's weighted sums
+    const double* s_b = wR ? s_he + (r + 1) : s_he;
+    const double bsc = wR ? 1.0 : kappa;
+    double quad = wR ? s_he[2 * r + 1] : kappa * ee;
     if (p.coef_update) {
       double part = 0.0;
 #pragma unroll
-      for (int m = 0; m < M; ++m) part += val[m] ? Pv[m] * s_he[min(ii[m], r)] : 0.0;
-      col_reduce<RPAD>(part, s_red, s_vec);   // s_vec = Pplus h
+      for (int m = 0; m < M; ++m) part += val[m] ? Pv[m] * s_b[min(ii[m], r - 1)] : 0.0;
+      col_reduce<RPAD>(part, s_red, s_vec);   // s_vec = Pplus b / bsc
       double bPb = 0.0;
 #pragma unroll
-      for (int l = 0; l < RPAD; ++l) bPb += s_he[l] * s_vec[l];   // s_vec[l >= r] = 0
-      quad -= kappa * kappa * bPb;
-      if (vl) mu_new = mub_t + kappa * s_vec[tid];
+      for (int l = 0; l < RPAD; ++l) bPb += (l < r ? s_b[l] : 0.0) * s_vec[l];   // s_vec[l >= r] = 0
+      quad -= bsc * bsc * bPb;
+      if (vl) mu_new = mub_t + bsc * s_vec[tid];
     } else {
       if (vl) mu_new = mub_t;
     }
@@ -626,8 +669,8 @@ __device__ __forceinline__ void serial_body(const StepParams& p, const int first
   double s = 0.0;
 #pragma unroll
   for (int l = 0; l < RPAD; ++l) s += s_mub[l] * s_vec[l];       // both are 0 beyond r
-  double eta = rho;
-  if (p.eta_full) eta += block_sum(gp, s4) / dd;   // (d rho + <G, Pbar>) / d   psmf.py:121-125
+  double eta = rho * p.rho_mean;                   // tr(R) / d  (rho_mean = 1 unless R is a non-uniform diagonal)
+  if (p.eta_full) eta += block_sum(gp, s4) / dd;   // (tr R + <G, Pbar>) / d   psmf.py:121-125
   const double N = s + eta;
   if (vl) {
     st->w[tid] = s_vec[tid];
@@ -649,8 +692,8 @@ __global__ __launch_bounds__(serial_threads(RPAD)) void psmf_serial(StepParams p
 
 // local reduction of the per-workgroup partials into st->red (multi-GPU: input of the all-reduce)
 __global__ __launch_bounds__(WG) void psmf_reduce_partials(StepParams p) {
-  __shared__ double s_part[8][RM + 1];
-  const int tid = threadIdx.x, ne = p.r + 1;
+  __shared__ double s_part[8][2 * (RM + 1)];
+  const int tid = threadIdx.x, ne = p.rho_rows ? 2 * (p.r + 1) : p.r + 1;
   int nseg = WG / ne;
   if (nseg > 8) nseg = 8;
   if (tid < ne * nseg) {
@@ -669,9 +712,11 @@ __global__ __launch_bounds__(WG) void psmf_reduce_partials(StepParams p) {
 // Exact Gram matrix G = C^T C of the local rows (float64 accumulation), used at set_state and
 // at the optional periodic refresh.  gpart: n_wg x r*r partials, reduced in fixed order.
 // ------------------------------------------------------------------------------------------
+// `wst` != nullptr: the weighted Gram of the current step for a non-uniform diagonal R, row weights 1 / (wst->rho * rho_rows[i] + wst->s)
 template <typename T>
 __global__ __launch_bounds__(WG) void psmf_gram_partial(const T* __restrict__ C, int d_local, int r, int rp,
-                                                        int rows_per_wg, double* __restrict__ gpart) {
+                                                        int rows_per_wg, double* __restrict__ gpart,
+                                                        const DevState* __restrict__ wst = nullptr, const double* __restrict__ rho_rows = nullptr) {
   constexpr int TR = 32;   // rows per LDS tile
   __shared__ double tile[TR][RM + 1];
   const int tid = threadIdx.x;
@@ -692,7 +737,9 @@ __global__ __launch_bounds__(WG) void psmf_gram_partial(const T* __restrict__ C,
     for (int idx = tid; idx < TR * r; idx += WG) {
       const int rr = idx / r, c = idx - rr * r;
       const int row = base + rr;
-      tile[rr][c] = row < row_end ? (double)C[(size_t)row * rp + c] : 0.0;
+      double v = row < row_end ? (double)C[(size_t)row * rp + c] : 0.0;
+      if (wst && row < row_end) v *= sqrt(fast_rcp(wst->rho * rho_rows[row] + wst->s));      // both factors of a pair carry sqrt(kappa_i)
+      tile[rr][c] = v;
     }
     __syncthreads();
 #pragma unroll

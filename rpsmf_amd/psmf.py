@@ -401,8 +401,22 @@ class PSMFIter:
         dg = _diag_of(Rk, self._d)
         rho = None if dg is None else _as_scalar_if_uniform(dg)
         if rho is None:
-            raise NotImplementedError("the device path needs R_k = rho_k * I (uniform diagonal); use backend='numpy'")
+            if dg is not None and np.array_equal(dg, self._row_noise()):
+                return 1.0          # the scalar in front of diag(rho_rows) (psmf_set_row_noise)
+            raise NotImplementedError("the device path needs a diagonal R: R_k = rho_k * I, or one constant non-uniform diagonal; "
+                                      "use backend='numpy'")
         return rho
+
+    def _first_R(self):
+        R = self._R
+        return R[1 if 1 in R else min(R.keys())] if isinstance(R, dict) else R
+
+    def _row_noise(self):
+        """diag(R) as a (d,) vector when R is a NON-uniform diagonal (the device then weights every row, per-step engine), else None."""
+        if not hasattr(self, "_row_noise_cache"):
+            dg = _diag_of(self._first_R(), self._d)
+            self._row_noise_cache = None if (dg is None or np.ndim(dg) == 0 or _as_scalar_if_uniform(dg) is not None) else np.asarray(dg, dtype=float)
+        return self._row_noise_cache
 
     def _q_matrix(self, Qk):
         Q = np.asarray(Qk, dtype=float)
@@ -461,7 +475,7 @@ class PSMFIter:
         if kind is None or getattr(self, "_force_host_stepped", False):
             return True
         general = kind in (_capi.DYN_SCALED_WALK, _capi.DYN_SINUSOID, _capi.DYN_FOURIER)
-        return general and (self._r > 32 or self._dev_opts.get("engine") == "step")
+        return general and (self._r > 32 or self._dev_opts.get("engine") == "step" or self._row_noise() is not None)
 
     def _device_kwargs(self):
         coef, eta_full, pbar = HIP_MODES[self.hip_mode]
@@ -470,11 +484,15 @@ class PSMFIter:
             kw.update(dyn_kind=_capi.DYN_HOST, engine="step")
         else:
             kw.update(dyn_kind=self._nl.device_kind, dyn_flags=self._nl.device_flags, dyn_terms=self._nl.device_terms)
+        if self._row_noise() is not None:
+            kw.update(nonuniform_R=True, engine="step")
         return kw
 
     def _ensure_device(self):
         if self._dev is None:
             self._dev = _capi.DeviceFilter(self._d, self._r, **self._device_kwargs())
+            if self._row_noise() is not None:
+                self._dev.set_row_noise(self._row_noise())
         return self._dev
 
     def _fetch_device(self, name, epoch):

@@ -95,6 +95,9 @@ class rPSMFIter(PSMFIter):
         return self._d * u / N + 0.5 * (self._d + lam) * (-2.0 * (C.T @ e) / D - 2.0 * lam * ee * u / D**2) / (1.0 + ee / D)
 
     # ---- device
+    def _first_R(self):
+        return self.R0
+
     def _device_lambda0(self):
         return float(self.lambda0)
 

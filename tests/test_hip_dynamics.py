@@ -347,3 +347,33 @@ def test_recursive_sgd_runs_host_stepped(robust):
             assert f._dev.dyn_kind == _capi().DYN_HOST
     for a, b in zip(*out):
         assert relerr(a, b) < 1e-9
+
+
+@pytest.mark.parametrize("robust", [False, True], ids=["PSMF", "rPSMF"])
+def test_nonuniform_diagonal_R_on_device(robust):
+    """R = diag(rho_i) with different rho_i (psmf.py:140-153 takes any diagonal R): row weights 1 / (rho_i + s_k) change with every
+    step, so the per-step engine recomputes the weighted Gram each step and the sweep carries the weighted sums; through the
+    class surface (a (d,) vector where the reference wants a dense d x d matrix), against the oracle."""
+    d, r, T = 1500, 7, 70
+    Y, C0 = _problem(d, r, T, 41)
+    rng = np.random.default_rng(12)
+    rho = 0.3 + 2.0 * rng.random(d)
+    V0, P0, Q = 0.1 * np.eye(r), np.eye(r), 0.1 * np.eye(r)
+    if robust:
+        f = psmf.rPSMFIter(np.zeros((0, 1)), C0, V0, np.zeros((r, 1)), P0, Q, rho, 1.8, psmf.RandomWalk(), storage="f64")
+    else:
+        f = psmf.PSMFIter(np.zeros((0, 1)), C0, V0, np.zeros((r, 1)), P0, {k: Q for k in range(T + 1)}, {k: rho for k in range(T + 1)},
+                          psmf.RandomWalk(), storage="f64")
+    f.optim_init()
+    st = O.State(C=C0, V=V0, mu=np.zeros(r), P=P0, Q=Q, rho=rho.copy(), lam=1.8)
+    for i in (1, 2):
+        f.step(ydict(Y), i, T)
+        assert f._dev.geometry()["engine"] == "step"
+        if robust:
+            st.Q, st.rho, st.lam = Q, rho.copy(), 1.8
+        st, Yp, _ = O.run_epoch(st, Y, O.Mode(robust=robust), O.RandomWalkDyn(), want_grad=False)
+        assert relerr(f._C[T], st.C) < 1e-9 and relerr(f._V[T], st.V) < 1e-9 and relerr(f._P[T], st.P) < 1e-9
+        assert relerr(f._mu[T], st.mu.reshape(-1, 1)) < 1e-9
+        yp = np.array([f._y_pred[k].reshape(-1) for k in range(1, T + 1)])
+        assert relerr(yp, Yp) < 1e-9
+        f.optim_update(i)          # theta is empty; creates _theta[i] for the next epoch as the reference's run() does
