@@ -280,12 +280,22 @@ __global__ __launch_bounds__(BK_NT) void psmf_blk_apply2(BlockParams b) {
   int t = slab_of(0);
   if (t < nslab) load_slab(t);
   // the coefficient matrix and the LDS images, behind the first slab's loads
-  for (int idx = tid; idx < RB * RB; idx += BK_NT) {
-    const int m = idx / RB, c = idx - m * RB;
-    double v = 0.0;
-    if (c < r) v = b.Acoef[m * r + c];
-    else if (c < r + nb) v = b.Bcoef[(size_t)(c - r) * RB + m];
-    sW[m * GZ_S + c] = v;
+  {
+    // all eight loads of a thread in flight at once: unconditional, clamped addresses, selected afterwards (under a runtime
+    // predicate each load is branched around and waited for on its own: eight dependent L2 round trips, 3 us of prologue)
+    constexpr int NL = RB * RB / BK_NT;
+    double va[NL], vb[NL];
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+      const int idx = tid + u * BK_NT, m = idx / RB, c = idx - m * RB;
+      va[u] = b.Acoef[m * r + min(c, r - 1)];
+      vb[u] = b.Bcoef[(size_t)min(max(c - r, 0), RB - 1) * RB + m];
+    }
+#pragma unroll
+    for (int u = 0; u < NL; ++u) {
+      const int idx = tid + u * BK_NT, m = idx / RB, c = idx - m * RB;
+      sW[m * GZ_S + c] = c < r ? va[u] : (c < r + nb ? vb[u] : 0.0);
+    }
   }
   for (int i = lane; i < BK_TR * AP_S; i += 64) sZ[i] = 0.0;
   for (int i = lane; i < BK_TR * AP2_SC; i += 64) sC[i] = 0.f;
