@@ -56,9 +56,10 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--d", type=int, default=100_000)
-    ap.add_argument("--r", type=int, default=32)
-    ap.add_argument("--T", type=int, default=10_000)
+    # (long aliases: under `python -m torch.distributed.run` a bare --d / --r is ambiguous with the launcher's own options)
+    ap.add_argument("--d", "--rows", type=int, default=100_000, dest="d")
+    ap.add_argument("--r", "--latent-rank", type=int, default=32, dest="r")
+    ap.add_argument("--T", "--timesteps", type=int, default=10_000, dest="T")
     ap.add_argument("--robust", type=int, default=0)
     ap.add_argument("--storage", default="f32")
     ap.add_argument("--cpu-steps", type=int, default=300, help="timesteps of the CPU baseline sample (0 = skip)")
@@ -66,6 +67,10 @@ def parse():
     ap.add_argument("--workgroups", type=int, default=0)
     ap.add_argument("--engine", default="auto", choices=["auto", "step", "block"])
     ap.add_argument("--no-extras", action="store_true", help="skip other_configs / literal baseline / copy peak (profiling runs)")
+    ap.add_argument("--comm", default="rccl", choices=["rccl", "gloo"],
+                    help="N > 1: RCCL all-reduce on the device streams (default), or the host-mediated communicator over gloo "
+                         "(psmf_comm_init_host) -- the transport for rehearsing the N > 1 path with all ranks on ONE GPU")
+    ap.add_argument("--one-device", action="store_true", help="every rank uses HIP device 0 (rehearsal on a one-GPU box; needs --comm gloo)")
     return ap.parse_args()
 
 
@@ -275,9 +280,22 @@ def main():
     series = Series(d, r, T, seed, row0, d_local, bool(args.robust))
     st0 = init_state(d, r, seed)
 
+    if args.one_device:
+        if args.comm != "gloo":
+            raise SystemExit("--one-device needs --comm gloo (RCCL refuses two ranks on one GPU)")
+        local_rank = 0
     f = _capi.DeviceFilter(d, r, robust=bool(args.robust), storage=args.storage, store_y_pred=not args.no_y_pred,
                            device=local_rank, row0=row0, d_local=d_local, n_workgroups=args.workgroups, engine=args.engine)
-    if world > 1:
+    if world > 1 and args.comm == "gloo":
+        import torch
+
+        def host_allreduce(v):          # same bits on every rank (gloo reduces in a fixed order)
+            t = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float64))
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            return t.numpy()
+
+        f.comm_init_host(world, rank, host_allreduce)
+    elif world > 1:
         import torch
 
         if rank == 0:
@@ -316,6 +334,26 @@ def main():
         reset()
         f.run(0, n_cpu)
         parity = parity_of(f, st_cpu, n_cpu)
+    elif world > 1 and args.cpu_steps > 0 and d * r <= 1_000_000:
+        # sharded parity (small problems: rehearsals, tests): every rank runs the oracle on the WHOLE problem -- the series is the
+        # concatenation of the shards' series -- and checks its own rows of C and the replicated V, mu, P; worst over the ranks
+        from oracle import psmf_oracle as O
+
+        n_cpu = min(args.cpu_steps, T)
+        parts = [Series(d, r, T, seed, *shard_rows(d, world, q), bool(args.robust)) for q in range(world)]
+        Yfull = np.hstack([np.vstack([Yc for _, Yc in p_.chunks(chunk=n_cpu)][:1])[:n_cpu] for p_ in parts]).astype(np.float64)
+        st = O.State(C=st0["C"].copy(), V=st0["V"].copy(), mu=st0["mu"].copy(), P=st0["P"].copy(), Q=st0["Q"].copy(), rho=st0["rho"], lam=st0["lam"])
+        st, _, _ = O.run_epoch(st, Yfull, O.Mode(robust=bool(args.robust)), O.RandomWalkDyn(), want_grad=False)
+        reset()
+        f.run(0, n_cpu)
+        sdev = f.get_state()
+        rel = lambda a, b_: float(np.max(np.abs(a - b_)) / np.max(np.abs(b_)))
+        mine = np.array([rel(sdev["C"], st.C[row0:row0 + d_local]), rel(sdev["V"], st.V), rel(sdev["mu"], st.mu), rel(sdev["P"], st.P)])
+        import torch
+
+        tm = torch.from_numpy(mine)
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        parity = dict(steps=n_cpu, ranks=world, C=float(tm[0]), V=float(tm[1]), mu=float(tm[2]), P=float(tm[3]))
 
     # ---- untimed pre-warm: the HIP runtime grows its signal / kernel-argument pools the first time a whole pass worth of
     # launches is queued ahead of the GPU (a one-off ~80 ms stall in the second pass, tools/probe_stall.py)
@@ -433,6 +471,7 @@ def main():
             "config": {"workload": f"{'rPSMF' if args.robust else 'PSMF'} full filter, random-walk dynamics, d={d} r={r} "
                                    f"T={T} synthetic Gaussian series, rows sharded over {world} GPU(s)",
                        "d": d, "r": r, "T": T, "timesteps_per_pass": T, "store_y_pred": not args.no_y_pred,
+                       "exchange": None if world == 1 else ("RCCL all-reduce on the bulk stream" if args.comm == "rccl" else "host-mediated all-reduce over gloo (rehearsal transport)"),
                        "us_per_timestep": 1e6 * elapsed / (args.steps * T), "engine": geo["engine"], "geometry": geo},
             "cold_pass_steps_per_s": T / cold_elapsed,
             "roofline": dict({"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
