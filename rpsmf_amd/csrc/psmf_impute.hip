@@ -338,7 +338,8 @@ __global__ __launch_bounds__(WG) void psmf_impute_kernel(ImputeParams p) {
 // Version 2 of the column loop (the default): FOUR workgroup barriers per column instead of ~15.
 //   P1  row owners (waves 1.., so that wave 0 stays free): masked residual rows; wave 3: w = V x          | barrier 1
 //   P2  waves 1-3: augmented masked Gram [C | e]^T diag(m) [C | e] on the float64 matrix cores, every wave its share
-//       of the 4-row groups (v_mfma_f64_16x16x4_f64; r = 16: a second tile for C^T e); wave 0: P + Q, kappa      | barrier 2
+//       of the 4-row groups (v_mfma_f64_16x16x4_f64; r = 16: a second tile for C^T e); wave 0: sum(m), sum(e^2), s,
+//       P + Q, kappa                                                                                       | barrier 2
 //   P3a wave 0: sums the three partial tiles -- which leaves G in the MFMA output layout (lane = column, 4 rows per
 //       lane) -- <G, P + Q>, eta, N, phi                                                                  | barrier 3
 //   P3b wave 0 alone, NO barrier: the two symmetric sweep inversions of the reference's Woodbury form (PSMF.py:30-36)
@@ -406,8 +407,7 @@ __global__ __launch_bounds__(WG) void psmf_impute_kernel2(ImputeParams p) {
   double* se = sw + IR;                       // d4: masked residual
   double* smk = se + d4;                      // d4: mask as 0/1 double
   double* sgp = smk + d4;                     // 3 waves x 2 tiles x 256: Gram partials in MFMA output layout
-  double* spart = sgp + 4 * 2 * 256;          // 4 x 2: per-wave sum(m), sum(e^2)
-  double* ssc = spart + 8;                    // 8 scalars: 0 s, 1 eta, 2 N, 3 phi, 4 1 / omega_{t-1}, 5 q_{t-1} (the q W was formed with), 6 q_t, 7 kappa
+  double* ssc = sgp + 4 * 2 * 256;            // 8 scalars: 0 s, 1 eta, 2 N, 3 phi, 4 1 / omega_{t-1}, 5 1 / q_{t-1} (the q W was formed with), 6 1 / q_t, 7 kappa
   double* sW = ssc + 8;                       // 256: W_{t-1} = (M_{t-1} + I / q_{t-1})^-1 in MFMA output layout (parallel inversions)
   double* sred = sW + 256;                    // 16: end-of-pass reductions
   int* errflag = reinterpret_cast<int*>(sred + 16);
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(WG) void psmf_impute_kernel2(ImputeParams p) {
     Qm[q] = inq[q] ? 0.5 * (p.Q0[a] + p.Q0[b]) : 0.0;
   }
   double rho = p.rho0, lam = p.lambda0;
-  double qv = p.Q0[0];                // running q of Q = q I (parallel inversions)
+  double qv = p.Q0[0], iqv = 1.0;     // running q of Q = q I and its reciprocal (parallel inversions)
   bool bad = false;
   unsigned long long nmiss_l = 0;
   int cur = 0;
@@ -476,7 +476,8 @@ __global__ __launch_bounds__(WG) void psmf_impute_kernel2(ImputeParams p) {
         wave_sweep16(A, r2, lk, lr, bad);          // -(P + q I)^-1
 #pragma unroll
         for (int q = 0; q < 4; ++q) sW[q * 64 + lane] = inq[q] ? ((lk + 4 * q) == lr ? qv : 0.0) + qv * qv * A[q] : 0.0;
-        if (lane == 0) { ssc[4] = 1.0; ssc[5] = qv; ssc[6] = qv; }
+        iqv = 1.0 / qv;
+        if (lane == 0) { ssc[4] = 1.0; ssc[5] = iqv; ssc[6] = iqv; }
       }
       __syncthreads();
     }
@@ -511,8 +512,9 @@ __global__ __launch_bounds__(WG) void psmf_impute_kernel2(ImputeParams p) {
           nmm[u] = Mm[cbase + rowc[u]];
         }
       }
-      // ---- P1: residual rows; w = V x; per-wave sum(m), sum(e^2) ----
-      double yh[2], mloc = 0.0, eloc = 0.0;
+      // ---- P1: residual rows (row owners), w = V x (wave 3).  Nothing else: sum(m), sum(e^2), s are formed by the idle wave 0
+      //      in P2 from what this phase leaves in LDS ----
+      double yh[2];
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int i = ro + u * WG;
@@ -528,38 +530,26 @@ __global__ __launch_bounds__(WG) void psmf_impute_kernel2(ImputeParams p) {
           const double dot = d0 + d1;
           const double mi = mv[u] ? 1.0 : 0.0;
           const double yi = mv[u] ? yv[u] : 0.0;     // Y is 0 where unobserved (PSMF.py:147-148)
-          const double ei = mi * (yi - dot);
-          se[i] = ei;
+          se[i] = mi * (yi - dot);
           smk[i] = mi;
           yh[u] = dot;
-          mloc += mi;
-          eloc += ei * ei;
         }
       }
-      if (wv != 0 || d > 192) {          // (wave 0 owns rows only when d > 192)
-        mloc = wave_sum_f64_dpp(mloc);
-        eloc = wave_sum_f64_dpp(eloc);
-      }
-      if (lane == 0) { spart[2 * wv] = mloc; spart[2 * wv + 1] = eloc; }
-      if (wv == 3) {                     // w = V x and s = x^T V x (rows 192.. of a large d share the wave: after its rows)
+      if (wv == 3 && lane < IR) {        // w = V x (rows >= r of V are zero)
         double vr[IR], xr[IR];
-        const int li = lane & 15;
 #pragma unroll
-        for (int l = 0; l < IR; ++l) { vr[l] = sV[li * IR + l]; xr[l] = sxc[l]; }
+        for (int l = 0; l < IR; ++l) { vr[l] = sV[lane * IR + l]; xr[l] = sxc[l]; }
         double a0 = 0.0, a1 = 0.0;
 #pragma unroll
         for (int l = 0; l < IR; l += 2) { a0 = fma(vr[l], xr[l], a0); a1 = fma(vr[l + 1], xr[l + 1], a1); }
-        const double a = a0 + a1;                                      // rows >= r of V are zero: a = 0 there
-        if (lane < IR) sw[lane] = a;
-        const double sv = wave_sum_f64_dpp(lane < IR ? a * sxc[li] : 0.0);
-        if (lane == 0) ssc[0] = sv;
+        sw[lane] = a0 + a1;
       }
       IMP_T(0);
       solve_barrier<true>();                                          // ---- barrier 1
       IMP_T(1);
       // ---- P2: augmented masked Gram on the matrix cores, wave w: 4-row groups w, w + 4, ... ----
       double G[4], Bq[4], PP[4], kappa = 0.0, N = 0.0, eta = 0.0, s = 0.0, ee = 0.0, phi = 1.0, msum = 0.0, ild = 0.0;
-      double Lb[4] = {0.0, 0.0, 0.0, 0.0};
+      double Lb[4] = {0.0, 0.0, 0.0, 0.0}, iqt_w1 = 0.0, kap_w1 = 0.0;
       if (wv == 0) {
         // wave 0 meanwhile: everything of P3a that does not need the Gram
 #pragma unroll
@@ -567,9 +557,12 @@ __global__ __launch_bounds__(WG) void psmf_impute_kernel2(ImputeParams p) {
           const double qd = par ? ((lk + 4 * q) == lr ? qv : 0.0) : Qm[q];
           PP[q] = inq[q] ? (tmf ? ((lk + 4 * q) == lr ? 0.5 : 0.0) : Pm[q] + qd) : 0.0;     // TMF: P + Q := I / nu, nu = 2 (TMF.py:47,60)
         }
-        s = ssc[0];
-        msum = (spart[0] + spart[2]) + (spart[4] + spart[6]);
-        ee = (spart[1] + spart[3]) + (spart[5] + spart[7]);
+        double ms = 0.0, es = 0.0;
+        for (int i = lane; i < d4; i += 64) { const double ev = se[i]; ms += smk[i]; es = fma(ev, ev, es); }   // (padding rows are zero)
+        msum = wave_sum_f64_dpp(ms);
+        ee = wave_sum_f64_dpp(es);
+        s = wave_sum_f64_dpp(lane < IR ? sxc[lane & 15] * sw[lane & 15] : 0.0);                              // s = x^T V x
+        if (lane == 0) ssc[0] = s;
         // weights of the observed rows: PSMF / rPSMF 1 / (rho + s) (PSMF.py:71-72), MLE-SMF 1 / rho (MLESMF.py:70), TMF 1
         kappa = tmf ? 1.0 : fast_rcp(sgd ? rho : rho + s);
         ild = fast_rcp(lam + dd);
@@ -609,7 +602,9 @@ __global__ __launch_bounds__(WG) void psmf_impute_kernel2(ImputeParams p) {
           Bq[q] = one_tile ? g0 : g1;      // b_i = (C^T e)_i sits in column r (one tile) / column 0 (second tile) of rows i
         }
         if (par) {
-          const double iom = ssc[4], iq = fast_rcp(ssc[5]);
+          const double iom = ssc[4], iq = ssc[5];
+          iqt_w1 = ssc[6];                 // read HERE, before barrier 3: wave 0 rewrites these slots at the end of its P3b
+          kap_w1 = ssc[7];
           const double c1 = iom * iq, c2 = c1 * iq;
 #pragma unroll
           for (int q = 0; q < 4; ++q) Lb[q] = inq[q] ? ((lk + 4 * q) == lr ? c1 : 0.0) - c2 * sW[q * 64 + lane] : 0.0;
@@ -630,7 +625,7 @@ __global__ __launch_bounds__(WG) void psmf_impute_kernel2(ImputeParams p) {
       IMP_T(5);
       if (par && wv == 1) {
         // ---- P3b, wave 1: W_t = (M_t + I / q_t)^-1 for the next column's Lbar, beside wave 0's inversion of M_t ----
-        const double kap = ssc[7], iqt = fast_rcp(ssc[6]);
+        const double kap = kap_w1, iqt = iqt_w1;
         double A[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) A[q] = inq[q] ? Lb[q] + kap * G[q] + ((lk + 4 * q) == lr ? iqt : 0.0) : (((lk + 4 * q) == lr) ? 1.0 : 0.0);
@@ -695,7 +690,11 @@ __global__ __launch_bounds__(WG) void psmf_impute_kernel2(ImputeParams p) {
           Pm[q] = inq[q] ? omega * -A[q] : 0.0;
           if (p.robust) Qm[q] *= omega;
         }
-        if (par && lane == 0) { ssc[4] = fast_rcp(omega); ssc[5] = qv; ssc[6] = qv * omega; }     // for the next column's Lbar
+        if (par) {          // for the next column: 1 / omega_t, 1 / q_t (the q W_t is formed with), 1 / q_{t+1}
+          const double iom = p.robust ? fast_rcp(omega) : 1.0;
+          if (lane == 0) { ssc[4] = iom; ssc[5] = iqv; ssc[6] = iqv * iom; }
+          iqv *= iom;
+        }
         if (p.robust) { rho *= omega; lam += dd; qv *= omega; }
       } else {
         // ---- P4a (the other waves): rank-1 updates of C and V with N, phi of this column ----
@@ -784,7 +783,7 @@ __global__ __launch_bounds__(WG) void psmf_impute_kernel2(ImputeParams p) {
 
 inline size_t impute2_lds_bytes(int d, int r) {
   const size_t d4 = ((size_t)d + 3) & ~(size_t)3;
-  const size_t doubles = d4 * IR + IR * IR + 3 * IR + 2 * d4 + 4 * 2 * 256 + 8 + 8 + 256 + 16 + 2;
+  const size_t doubles = d4 * IR + IR * IR + 3 * IR + 2 * d4 + 4 * 2 * 256 + 8 + 256 + 16 + 2;
   return (doubles * 8 + 15) & ~(size_t)15;
 }
 
