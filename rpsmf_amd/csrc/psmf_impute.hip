@@ -62,6 +62,38 @@ struct ImputeParams {
   unsigned long long* prof;   // diagnostics (tools/impute_prof.hip) or nullptr
 };
 
+// End of a pass: sum over the held-out entries of (C x_t - y_t)^2 with the pass's final C (ExperimentImpute/PSMF.py:86-89, the RMSE of C @ X).
+// One COLUMN per thread: 256 independent chains of loads in flight.  (A row per thread leaves d threads walking the n
+// columns one memory latency at a time -- 0.75 us per column, an eighth of the whole run at the ExperimentImpute shape.)
+// X was written by other threads of this workgroup: read around this CU's L1.  sC: the dictionary in LDS, row stride ldc.
+__device__ __forceinline__ double held_out_sse(const double* sC, const int ldc, const double* Xg, const double* Yorg,
+                                               const uint8_t* Mm, const int d, const int n, const int r, const int tid) {
+  double sse = 0.0;
+  for (int t = tid; t < n; t += WG) {
+    double xr[IR];
+#pragma unroll
+    for (int l = 0; l < IR; ++l) {           // unconditional loads (index clamped, value masked): all r in flight at once
+      const double v = __builtin_nontemporal_load(&Xg[(size_t)t * r + min(l, r - 1)]);
+      xr[l] = l < r ? v : 0.0;
+    }
+    const size_t base = (size_t)t * d;
+#pragma unroll 4
+    for (int i = 0; i < d; ++i) {
+      const uint8_t m = Mm[base + i];
+      const double y = Yorg[base + i];
+      double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+      for (int l = 0; l < IR; l += 2) {
+        d0 = fma(sC[i * ldc + min(l, r - 1)], xr[l], d0);
+        d1 = fma(sC[i * ldc + min(l + 1, r - 1)], xr[l + 1], d1);
+      }
+      const double dl = (d0 + d1) - y;
+      sse += m ? dl * dl : 0.0;
+    }
+  }
+  return sse;
+}
+
 __global__ __launch_bounds__(WG) void psmf_impute_kernel(ImputeParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* sm = reinterpret_cast<double*>(smem_raw);
@@ -298,21 +330,7 @@ __global__ __launch_bounds__(WG) void psmf_impute_kernel(ImputeParams p) {
     }
     // ---- end of pass: RMSE of the one-step predictions, RMSE of C @ X, coverage ----
     double nm_d = (double)nmiss_l;
-    double sse_full = 0.0;
-    for (int u = 0; u < 2; ++u) {
-      const int i = tid + u * WG;
-      if (i < d) {
-        for (int t = 0; t < n; ++t) {
-          if (Mm[(size_t)t * d + i]) {
-            double dot = 0.0;
-            // X was written by other threads of this workgroup: read around this CU's L1
-            for (int l = 0; l < r; ++l) dot += sC[i * r + l] * __builtin_nontemporal_load(&Xg[(size_t)t * r + l]);
-            const double dl = dot - Yorg[(size_t)t * d + i];
-            sse_full += dl * dl;
-          }
-        }
-      }
-    }
+    const double sse_full = held_out_sse(sC, r, Xg, Yorg, Mm, d, n, r, tid);
     double v0 = wave_sum(sse_pred), v1 = wave_sum(sse_full), v2 = wave_sum(nm_d), v3 = wave_sum((double)inside_l);
     __syncthreads();
     if ((tid & 63) == 0) { sgp[(tid >> 6) * 4 + 0] = v0; sgp[(tid >> 6) * 4 + 1] = v1; sgp[(tid >> 6) * 4 + 2] = v2; sgp[(tid >> 6) * 4 + 3] = v3; }
@@ -744,21 +762,7 @@ __global__ __launch_bounds__(WG) void psmf_impute_kernel2(ImputeParams p) {
     // ---- end of pass: RMSE of the one-step predictions, RMSE of C @ X, coverage ----
     __syncthreads();                 // (drains the X stores of wave 0)
     double nm_d = (double)nmiss_l;
-    double sse_full = 0.0;
-    for (int u = 0; u < 2; ++u) {
-      const int i = ro + u * WG;
-      if (i < d) {
-        for (int t = 0; t < n; ++t) {
-          if (Mm[(size_t)t * d + i]) {
-            double dot = 0.0;
-            // X was written by other threads of this workgroup: read around this CU's L1
-            for (int l = 0; l < r; ++l) dot += sC[i * IR + l] * __builtin_nontemporal_load(&Xg[(size_t)t * r + l]);
-            const double dl = dot - Yorg[(size_t)t * d + i];
-            sse_full += dl * dl;
-          }
-        }
-      }
-    }
+    const double sse_full = held_out_sse(sC, IR, Xg, Yorg, Mm, d, n, r, tid);
     double v0 = wave_sum(sse_pred), v1 = wave_sum(sse_full), v2 = wave_sum(nm_d), v3 = wave_sum((double)inside_l);
     __syncthreads();
     if (lane == 0) { sred[wv * 4 + 0] = v0; sred[wv * 4 + 1] = v1; sred[wv * 4 + 2] = v2; sred[wv * 4 + 3] = v3; }
