@@ -34,6 +34,7 @@ namespace psmf {
 
 typedef double f64x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4s __attribute__((ext_vector_type(4)));
+typedef float f32x2s __attribute__((ext_vector_type(2)));
 
 constexpr int F3_NT = 512;
 constexpr int F3_S = 34;            // row stride of the row-major 32 x 32 LDS images
@@ -118,6 +119,11 @@ struct F3Lds {
   double* hv;       // 2
   double* gp;       // 2
   double* tr;       // 2
+  // start predictor of the two inversions (f3_ns_program phase 1; Z = P+ / W):
+  double* sab;      // [2 inversions][32][2]  (a_j, b_j) = ((Z h)_j, (Z w)_j) of the step that just ended, by the wave that owns column j
+  double* sal;      // [2][32]  alpha = T11 a + T12 b (wave 7, phase 0), ROW-PERMUTED: row 16 ti + lrow + 4 q at 8 lrow + 4 ti + q,
+  double* sbe;      // [2][32]  beta  = T12 a + T22 b                    so that a lane's eight rows are 64 contiguous bytes
+  float* s32;       // [2][128] the same in float32 for the A operands: alpha (32, permuted) | beta (32, permuted) | (a_j, b_j) pairs (64)
   double* rowbufX;  // 4 RM
   double* rowbufY;  // 4 RM
   int* errflag;
@@ -437,6 +443,8 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Blk&
   int w_par = 0;
   bool w_from_img = false, fetch_late = false;
   double iq_w = carried ? st->f3_sc[0] : 1.0 / q0;          // 1 / q that Wf was formed with
+  double kap_prev = 1.0;                                    // kappa of the step that just ended (start predictor)
+  bool smw_ok = false;                                      // that step left a = Z h, b = Z w behind (not the first step of a block)
   BLK_T0();
   for (int jb = 0; jb < k.nb; ++jb) {
     // phase 0 (wave 4 forms w, s, kappa meanwhile): what the step that just ended left to do off the critical path
@@ -449,7 +457,7 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Blk&
     const bool try_ns = ctl.have_prev && p.use_ns && ctl.ns_skip == 0;
     if (!try_ns && ctl.ns_skip > 0) --ctl.ns_skip;
     double Mf[16], Xn[8];
-    double hrow[8], h_j = 0.0, mub_j = 0.0, kap_k = 0.0;     // X waves: operands of phase F, loaded in phase 2
+    double hrow[8], h_j = 0.0, mub_j = 0.0, kap_k = 0.0;     // operands of phase F, loaded in phase 2
     int par = 0;
     {
       const double kap = L.sc[F3_KAPPA], iom = L.sc[F3_IOM], iq = L.sc[F3_IQ];
@@ -471,6 +479,44 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Blk&
             else Mf[e] = m;
           }
     }
+    if (try_ns && smw_ok && (p.ns_predict & 4)) {
+      // Start of the iteration ("start predictor"): M_k differs from M_{k-1} by the rank-2 change of G
+      // (h w^T + w h^T) / N + (ee / N^2) w w^T  -- downdated exactly, Sherman-Morrison-Woodbury with a = Z h, b = Z w left by
+      // phase F and the 2 x 2 core folded into alpha, beta by wave 7 in phase 0 --  and, to first order, by the factor
+      // kappa_k / kappa_{k-1} on everything (kappa G dominates M):  Z_0 = (kappa_{k-1} / kappa_k) (Z - alpha a^T - beta b^T).
+      // Leaves ||I - M Z_0|| ~ 1e-4 .. 1e-3 where the plain start Z leaves 1e-2 .. 1e-1 (and > 1 through the first ~400 steps).
+      const double sc = kap_prev * fast_rcp(kap_k);
+      const f64x2 ab = *reinterpret_cast<const f64x2*>(L.sab + 2 * (32 * inv + 16 * C + lcol));
+      const double aj = ab[0], bj = ab[1];
+      const float* f32b = L.s32 + 128 * inv;
+      const f32x4s al32[2] = {*reinterpret_cast<const f32x4s*>(f32b + 8 * lrow), *reinterpret_cast<const f32x4s*>(f32b + 8 * lrow + 4)};
+      const f32x4s be32[2] = {*reinterpret_cast<const f32x4s*>(f32b + 32 + 8 * lrow), *reinterpret_cast<const f32x4s*>(f32b + 32 + 8 * lrow + 4)};
+      const f32x2s abp0 = *reinterpret_cast<const f32x2s*>(f32b + 64 + 2 * pcol), abp1 = *reinterpret_cast<const f32x2s*>(f32b + 64 + 2 * (16 + pcol));
+      const f64x2* alp = reinterpret_cast<const f64x2*>(L.sal + 32 * inv + 8 * lrow);
+      const f64x2* bep = reinterpret_cast<const f64x2*>(L.sbe + 32 * inv + 8 * lrow);
+      f64x2 al64[4], be64[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { al64[e] = alp[e]; be64[e] = bep[e]; }
+      const float scf = (float)sc;
+      // (the identity padding of r < 32 keeps its ones: alpha, a vanish there, only the scale has to be kept off it)
+      const bool pc0 = FULL == 0 || (FULL == 2 ? pcol < rt : true), pc1 = FULL == 0 || (FULL == 2 ? false : pcol < rt);
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+          const int e = ti * 4 + qq;
+          const double al = al64[e >> 1][e & 1], be = be64[e >> 1][e & 1];
+          const bool rok = FULL == 0 || (FULL == 2 ? (ti == 0 && mk.r1[qq]) : (ti == 0 || mk.r1[qq]));
+          const double xc = sc * fma(-be, bj, fma(-al, aj, Xc[e]));
+          Xc[e] = F3_VALID(mk, ti, C, qq) ? xc : Xc[e];
+          const float alf = al32[ti][qq], bef = be32[ti][qq];
+          const float x0 = scf * fmaf(-bef, abp0[1], fmaf(-alf, abp0[0], Xa[e]));
+          const float x1 = scf * fmaf(-bef, abp1[1], fmaf(-alf, abp1[0], Xa[8 + e]));
+          Xa[e] = (rok && pc0) ? x0 : Xa[e];
+          Xa[8 + e] = (rok && pc1) ? x1 : Xa[8 + e];
+        }
+    }
+    kap_prev = kap_k;
     if (try_ns) F3_ITERATE(0);
     BLK_T(2);
     f3_barrier();                                                     // ---- B2
@@ -557,22 +603,36 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Blk&
     // =============================== phase F: v = P+ h, mu (the only work between the inversion and the next step) ===============================
     w_par = par;
     w_from_img = from_img;
-    if (isX && !(F3_KNOCK & 8)) {
-      // v = P+ h (own column, by symmetry), mu_k = mu_bar + kappa v (psmf.py:155-159); h.v for omega (rPSMF only)
-      double vp0 = 0.0, vp1 = 0.0;
+    if (!(F3_KNOCK & 8)) {
+      // a = Z h, b = Z w of the own column (by symmetry) for the next step's start predictor; X waves: a is v = P+ h,
+      // mu_k = mu_bar + kappa v (psmf.py:155-159); h.v for omega (rPSMF only)
+      double vp0 = 0.0, vp1 = 0.0, vq0 = 0.0, vq1 = 0.0;
+      double wrow[8];                      // (L.w is not rewritten before the next step's phase 1)
 #pragma unroll
-      for (int qq = 0; qq < 4; ++qq) { vp0 += Xc[qq] * hrow[qq]; vp1 += Xc[4 + qq] * hrow[4 + qq]; }
+      for (int e = 0; e < 8; ++e) wrow[e] = L.w[16 * (e >> 2) + lrow + 4 * (e & 3)];
+#pragma unroll
+      for (int qq = 0; qq < 4; ++qq) {
+        vp0 += Xc[qq] * hrow[qq]; vp1 += Xc[4 + qq] * hrow[4 + qq];
+        vq0 += Xc[qq] * wrow[qq]; vq1 += Xc[4 + qq] * wrow[4 + qq];
+      }
       const double vp = xor32_sum_f64(xor16_sum_f64(vp0 + vp1));
       const int j = 16 * C + lcol;
-      const double mu_new = mub_j + kap_k * vp;
-      if (lrow == 0 && j < r) {
-        L.mub[j] = mu_new;                    // random walk: mu_bar_{k+1} = mu_k
-        if (p.mu_hist) p.mu_hist[(size_t)(k.k0 + jb + 1 - p.series_t0) * r + j] = mu_new;
+      if (isX) {
+        const double mu_new = mub_j + kap_k * vp;
+        if (lrow == 0 && j < r) {
+          L.mub[j] = mu_new;                    // random walk: mu_bar_{k+1} = mu_k
+          if (p.mu_hist) p.mu_hist[(size_t)(k.k0 + jb + 1 - p.series_t0) * r + j] = mu_new;
+        }
+        if (p.robust) {
+          const double hvp = wave_sum_f64_dpp((lrow == 0) ? h_j * vp : 0.0);
+          if (lane == 0) L.hv[C] = hvp;
+        }
       }
-      if (p.robust) {
-        const double hvp = wave_sum_f64_dpp((lrow == 0) ? h_j * vp : 0.0);
-        if (lane == 0) L.hv[C] = hvp;
+      if (p.ns_predict & 1) {
+        const double vq = xor32_sum_f64(xor16_sum_f64(vq0 + vq1));
+        if (lrow == 0) *reinterpret_cast<f64x2*>(L.sab + 2 * (32 * inv + j)) = f64x2{vp, vq};
       }
+      smw_ok = true;
     }
     BLK_T(5);
     f3_barrier();                                                     // ---- BF
@@ -645,6 +705,7 @@ __device__ __forceinline__ void f3_v_program(const BlockParams& b, const F3Blk& 
   double q = st->Q[0];                  // Q = q I (checked by the host)
   double rho = st->rho, lam = st->lam;
   double iom0 = 1.0;                    // 1 / omega of the last step of the previous block (carried W is not yet divided by it)
+  double kap7 = 1.0;                    // wave 7: kappa of the step that just ended
   if (isV0) {
     const int j = lane & 31, hf = lane >> 5;
     if (carried) {
@@ -730,6 +791,34 @@ __device__ __forceinline__ void f3_v_program(const BlockParams& b, const F3Blk& 
         L.Ka[lane] = cm;
       }
     }
+    else if (isV3 && (p.ns_predict & 2)) {
+      // Start predictor of the two inversions (f3_ns_program, phase 1): the 2 x 2 core of the rank-2 downdate.  With a = Z h,
+      // b = Z w (left by the inversion waves in phase F), U = [h w] and G_k - G_{k-1} = U K U^T, K = [[0, 1/N], [1/N, ee/N^2]]:
+      //   (M + kappa U K U^T)^-1 = Z - [a b] T [a b]^T,   T = ((kappa K)^-1 + U^T Z U)^-1,   (kappa K)^-1 = [[-ee, N], [N, 0]] / kappa
+      // (W: M / beta, so kappa / beta).  Published as alpha = T11 a + T12 b, beta = T12 a + T22 b; lanes 0-31: P+, 32-63: W.
+      const int j = lane & 31, hf = lane >> 5;
+      double al = 0.0, be = 0.0;
+      f64x2 ab7 = {0.0, 0.0};
+      if (jb > 0) {
+        ab7 = *reinterpret_cast<const f64x2*>(L.sab + 2 * lane);
+        const double a = ab7[0], bb = ab7[1], hj = L.h[j], wv = L.w[j];
+        const double ha = xor16_sum_f64(row_sum_f64_dpp(hj * a)), hb = xor16_sum_f64(row_sum_f64_dpp(hj * bb));
+        const double wb = xor16_sum_f64(row_sum_f64_dpp(wv * bb));
+        const double ik = (hf ? p.beta : 1.0) * fast_rcp(kap7);
+        const double s11 = ha - L.sc[F3_EE] * ik, s12 = hb + L.sc[F3_N] * ik;
+        const double idet = fast_rcp(s11 * wb - s12 * s12);
+        const double t11 = wb * idet, t12 = -s12 * idet, t22 = s11 * idet;
+        al = t11 * a + t12 * bb;
+        be = t12 * a + t22 * bb;
+      }
+      const int pj = 32 * hf + 8 * (j & 3) + 4 * (j >> 4) + ((j >> 2) & 3);
+      L.sal[pj] = al;
+      L.sbe[pj] = be;
+      float* f32b = L.s32 + 128 * hf;
+      f32b[pj - 32 * hf] = (float)al;
+      f32b[32 + pj - 32 * hf] = (float)be;
+      *reinterpret_cast<f32x2s*>(f32b + 64 + 2 * j) = f32x2s{(float)ab7[0], (float)ab7[1]};
+    }
     BLK_T(0);
     f3_barrier();                                                     // ---- B1
     BLK_T(1);
@@ -737,6 +826,7 @@ __device__ __forceinline__ void f3_v_program(const BlockParams& b, const F3Blk& 
     const bool try_ns = ctl.have_prev && p.use_ns && ctl.ns_skip == 0;
     if (!try_ns && ctl.ns_skip > 0) --ctl.ns_skip;
     int par = 0;
+    if (isV3) kap7 = L.sc[F3_KAPPA];                                    // (stable from B1 to the next step's phase 0)
     if (isV3 && !(F3_KNOCK & 64)) {
       const int c = lane & 31, hf = lane >> 5;
       double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
@@ -884,7 +974,7 @@ __device__ __forceinline__ void blk_filter3_body(const BlockParams& b0) {
   // Everything a step touches sits in STATIC LDS: its addresses are compile-time constants that fold into the ds
   // instructions' immediate offsets.  (Off the dynamic-LDS base the compiler formed (lane part + constant) + base for
   // every row / column it reads and kept each sum in a VGPR of its own across the loop: 136 spilled registers.)
-  __shared__ __attribute__((aligned(16))) double hot[2 * 4 * 8 * 64 + 3 * RM + 2 * RB + F3_NSC + 8 + 6];
+  __shared__ __attribute__((aligned(16))) double hot[2 * 4 * 8 * 64 + 3 * RM + 2 * RB + F3_NSC + 8 + 6 + 12 * 32];
   __shared__ __attribute__((aligned(16))) float hotP[2 * 4 * 2 * 64 * 4];
   F3Lds L;
   L.sK = sm;
@@ -906,6 +996,10 @@ __device__ __forceinline__ void blk_filter3_body(const BlockParams& b0) {
   L.hv = L.nrm + 8;
   L.gp = L.hv + 2;
   L.tr = L.gp + 2;
+  L.sab = L.tr + 2;
+  L.sal = L.sab + 128;
+  L.sbe = L.sal + 64;
+  L.s32 = reinterpret_cast<float*>(L.sbe + 64);
   __shared__ long long s_tick[2];
   L.tick = s_tick;
 

@@ -771,10 +771,11 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
   sp.track_g = (cfg->eta_full || cfg->coef_update) ? 1 : 0;
   sp.external_reduce = 0;
   sp.use_ns = (getenv("PSMF_NS") && atoi(getenv("PSMF_NS")) == 0) ? 0 : 1;
+  sp.ns_predict = getenv("PSMF_NS_PREDICT") ? atoi(getenv("PSMF_NS_PREDICT")) : 7;      // bits: 1 a / b (phase F), 2 core (wave 7), 4 applied
   // Newton-Schulz acceptance: ||I - M X||_F below the tolerance BEFORE the last update (which squares it).  float64
   // storage: 3e-7 (-> 1e-13).  float32 storage: 1e-4 (-> 1e-8, far below the rounding of C and y to float32; measured
   // effect on the error against the float64 oracle: none).  PSMF_NS_TOL overrides.
-  const double ns_tol = getenv("PSMF_NS_TOL") ? atof(getenv("PSMF_NS_TOL")) : (cfg->storage == PSMF_F64 ? 3e-7 : 1e-4);
+  const double ns_tol = getenv("PSMF_NS_TOL") ? atof(getenv("PSMF_NS_TOL")) : (cfg->storage == PSMF_F64 ? 3e-7 : 3e-4);
   sp.ns_tol2 = ns_tol * ns_tol;
   const double ns_far = getenv("PSMF_NS_FAR") ? atof(getenv("PSMF_NS_FAR")) : 0.3;
   sp.ns_far2 = ns_far * ns_far;

@@ -76,6 +76,7 @@ struct StepParams {
   double rho_mean;
   int external_reduce;  // 1: partial sums were reduced into st->red (multi-GPU)
   int use_ns;           // 1: Newton-Schulz refinement of the r x r inverses (f64 MFMA), sweep as fallback
+  int ns_predict;       // 1: filter3 starts the iteration from the rank-2 downdated, kappa-rescaled previous inverse
   double alpha, beta, lr, lr_end, lr_steps, b1, b2;
   double ns_tol2;       // Newton-Schulz: squared Frobenius residual accepted BEFORE the last update (the update squares it)
   double ns_far2;       // Newton-Schulz: squared residual beyond which the start is given up for the direct sweep (filter3)

@@ -26,7 +26,7 @@ int main() {
   double *dK, *dA, *dB, *dKp; hipMalloc((void**)&dK, RB * RB * 8); hipMalloc((void**)&dA, RB * RM * 8); hipMalloc((void**)&dB, RB * RB * 8); hipMalloc((void**)&dKp, 1 << 20);
   hipMemcpy(dK, K.data(), RB * RB * 8, hipMemcpyHostToDevice);
   BlockParams b{}; b.sp.st = st; b.sp.r = r; b.sp.d = 4096; b.sp.d_local = 4096; b.sp.use_ns = 1; b.sp.coef_update = 1; b.sp.eta_full = 1; b.sp.pbar_predict = 1;
-  b.sp.alpha = b.sp.beta = 1.0; b.sp.ns_far2 = 0.09; b.sp.ns_tol2 = getenv("TOL") ? atof(getenv("TOL")) * atof(getenv("TOL")) : 9e-14; b.K = dK; b.Acoef = dA; b.Bcoef = dB; b.Kpart = dKp; b.k0 = 0; b.nb = nb;
+  b.sp.alpha = b.sp.beta = 1.0; b.sp.ns_predict = getenv("PRED") ? atoi(getenv("PRED")) : 7; b.sp.ns_far2 = 0.09; b.sp.ns_tol2 = getenv("TOL") ? atof(getenv("TOL")) * atof(getenv("TOL")) : 9e-14; b.K = dK; b.Acoef = dA; b.Bcoef = dB; b.Kpart = dKp; b.k0 = 0; b.nb = nb;
   const size_t lds = blk_filter3_lds_bytes();
   hipFuncSetAttribute((const void*)psmf_blk_filter3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   for (int it = 0; it < 2; ++it) { psmf_blk_filter3<<<1, F3_NT, lds>>>(b); hipDeviceSynchronize(); }
