@@ -401,16 +401,18 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Blk&
       }                                                                                                    \
     BLK_T(6);                                                                                              \
     if (isX && !(F3_KNOCK & 2)) {                                                                          \
-      double g1_ = 0.0, t1_ = 0.0;                                                                         \
+      double g1_ = 0.0;                                                                                    \
       _Pragma("unroll") for (int ti_ = 0; ti_ < 2; ++ti_)                                                  \
-        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                                 \
-          const double g_ = G[(ti_ * 2 + C) * 4 + q_];                                                     \
-          g1_ += g_ * Xc[ti_ * 4 + q_];                      /* G is zero outside r x r */                 \
-          t1_ += F3_DIAG(mk, ti_, C, q_) ? g_ : 0.0;                                                       \
-        }                                                                                                  \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                                                   \
+          g1_ += G[(ti_ * 2 + C) * 4 + q_] * Xc[ti_ * 4 + q_];     /* G is zero outside r x r */           \
       g1_ = wave_sum_f64_dpp(g1_);                                                                         \
+      if (lane == 0) L.gp[C] = g1_;                                                                        \
+    } else if (isY && !(F3_KNOCK & 2)) {                                                                   \
+      /* tr G of the own column tile: every inversion wave holds all of G, the W waves have the shorter phase 0 */ \
+      double t1_ = 0.0;                                                                                    \
+      _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) t1_ += F3_DIAG(mk, C, C, q_) ? G[(C * 2 + C) * 4 + q_] : 0.0; \
       t1_ = wave_sum_f64_dpp(t1_);                                                                         \
-      if (lane == 0) { L.gp[C] = g1_; L.tr[C] = t1_; }                                                     \
+      if (lane == 0) L.tr[C] = t1_;                                                                        \
     }                                                                                                      \
   } while (0)
 
@@ -457,7 +459,7 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Blk&
     const bool try_ns = ctl.have_prev && p.use_ns && ctl.ns_skip == 0;
     if (!try_ns && ctl.ns_skip > 0) --ctl.ns_skip;
     double Mf[16], Xn[8];
-    double hrow[8], h_j = 0.0, mub_j = 0.0, kap_k = 0.0;     // operands of phase F, loaded in phase 2
+    double hrow[8], wrow[8], h_j = 0.0, mub_j = 0.0, kap_k = 0.0;     // operands of phase F, loaded in phase 2
     int par = 0;
     {
       const double kap = L.sc[F3_KAPPA], iom = L.sc[F3_IOM], iq = L.sc[F3_IQ];
@@ -553,6 +555,7 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Blk&
           for (int tj = 0; tj < 2; ++tj)
             if (!(F3_KNOCK & 16)) G[(ti * 2 + tj) * 4 + qq] += ui * wcol[tj] + wi * hn[tj];
           hrow[ti * 4 + qq] = hi;
+          wrow[ti * 4 + qq] = wi;
         }
       h_j = hcol[C];
       mub_j = L.mub[16 * C + lcol];
@@ -607,9 +610,6 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Blk&
       // a = Z h, b = Z w of the own column (by symmetry) for the next step's start predictor; X waves: a is v = P+ h,
       // mu_k = mu_bar + kappa v (psmf.py:155-159); h.v for omega (rPSMF only)
       double vp0 = 0.0, vp1 = 0.0, vq0 = 0.0, vq1 = 0.0;
-      double wrow[8];                      // (L.w is not rewritten before the next step's phase 1)
-#pragma unroll
-      for (int e = 0; e < 8; ++e) wrow[e] = L.w[16 * (e >> 2) + lrow + 4 * (e & 3)];
 #pragma unroll
       for (int qq = 0; qq < 4; ++qq) {
         vp0 += Xc[qq] * hrow[qq]; vp1 += Xc[4 + qq] * hrow[4 + qq];
