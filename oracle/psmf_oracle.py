@@ -276,8 +276,14 @@ def lowrank_step(st: State, y, k, mode: Mode, dyn: Dynamics, Qk=None, rhok=None,
     q = float(kap @ (e * e))
 
     if mode.coef_update:
-        G_R = (C * kap[:, None]).T @ C
-        b = C.T @ (kap * e)
+        rho_in = st.rho if rhok is None else rhok
+        if mask is None and np.ndim(rho_in) == 0 and mode.eta_full:
+            # R = rho I and nothing masked: the weights are one number, C^T diag(kap) C = kap C^T C (the Gram formed above)
+            G_R = kap[0] * G
+            b = kap[0] * h
+        else:
+            G_R = (C * kap[:, None]).T @ C
+            b = C.T @ (kap * e)
         P_plus = np.linalg.solve(np.eye(r) + P_bar @ G_R, P_bar)
         P_plus = 0.5 * (P_plus + P_plus.T)
         mu_new = mu_bar + P_plus @ b
