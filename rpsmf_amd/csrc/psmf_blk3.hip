@@ -215,6 +215,11 @@ __device__ __forceinline__ void f3_assemble_K(const BlockParams& b, const F3Blk&
 #ifndef F3_KNOCK
 #define F3_KNOCK 0
 #endif
+// 0 compiles the start predictor out (tools/blk3_knock.hip times the fixed two-iteration schedule; with the predictor in,
+// some knock-out masks run into a back-end error of this compiler: "Illegal instruction detected ... $src_shared_base")
+#ifndef F3_PREDICT
+#define F3_PREDICT 1
+#endif
 
 // One Newton-Schulz iteration of tile column C:  R = I - M X_c,  Xn = X_c + X^T R  (see the header).
 // Mf: the step's matrix, T-layout, tile (kt, ti) at [(kt * 2 + ti) * 4 + kk]; Xc: own column (T-layout, float64).
@@ -481,7 +486,7 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Blk&
             else Mf[e] = m;
           }
     }
-    if (try_ns && smw_ok && (p.ns_predict & 4)) {
+    if (F3_PREDICT && try_ns && smw_ok && (p.ns_predict & 4)) {
       // Start of the iteration ("start predictor"): M_k differs from M_{k-1} by the rank-2 change of G
       // (h w^T + w h^T) / N + (ee / N^2) w w^T  -- downdated exactly, Sherman-Morrison-Woodbury with a = Z h, b = Z w left by
       // phase F and the 2 x 2 core folded into alpha, beta by wave 7 in phase 0 --  and, to first order, by the factor
@@ -628,7 +633,7 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Blk&
           if (lane == 0) L.hv[C] = hvp;
         }
       }
-      if (p.ns_predict & 1) {
+      if (F3_PREDICT && (p.ns_predict & 1)) {
         const double vq = xor32_sum_f64(xor16_sum_f64(vq0 + vq1));
         if (lrow == 0) *reinterpret_cast<f64x2*>(L.sab + 2 * (32 * inv + j)) = f64x2{vp, vq};
       }
@@ -791,7 +796,7 @@ __device__ __forceinline__ void f3_v_program(const BlockParams& b, const F3Blk& 
         L.Ka[lane] = cm;
       }
     }
-    else if (isV3 && (p.ns_predict & 2)) {
+    else if (F3_PREDICT && isV3 && (p.ns_predict & 2)) {
       // Start predictor of the two inversions (f3_ns_program, phase 1): the 2 x 2 core of the rank-2 downdate.  With a = Z h,
       // b = Z w (left by the inversion waves in phase F), U = [h w] and G_k - G_{k-1} = U K U^T, K = [[0, 1/N], [1/N, ee/N^2]]:
       //   (M + kappa U K U^T)^-1 = Z - [a b] T [a b]^T,   T = ((kappa K)^-1 + U^T Z U)^-1,   (kappa K)^-1 = [[-ee, N], [N, 0]] / kappa
@@ -974,8 +979,9 @@ __device__ __forceinline__ void blk_filter3_body(const BlockParams& b0) {
   // Everything a step touches sits in STATIC LDS: its addresses are compile-time constants that fold into the ds
   // instructions' immediate offsets.  (Off the dynamic-LDS base the compiler formed (lane part + constant) + base for
   // every row / column it reads and kept each sum in a VGPR of its own across the loop: 136 spilled registers.)
-  __shared__ __attribute__((aligned(16))) double hot[2 * 4 * 8 * 64 + 3 * RM + 2 * RB + F3_NSC + 8 + 6 + 12 * 32];
+  __shared__ __attribute__((aligned(16))) double hot[2 * 4 * 8 * 64 + 3 * RM + 2 * RB + F3_NSC + 8 + 6 + 8 * 32];
   __shared__ __attribute__((aligned(16))) float hotP[2 * 4 * 2 * 64 * 4];
+  __shared__ __attribute__((aligned(16))) float hotS[2 * 128];
   F3Lds L;
   L.sK = sm;
   L.sA = L.sK + RB * RB;
@@ -999,7 +1005,7 @@ __device__ __forceinline__ void blk_filter3_body(const BlockParams& b0) {
   L.sab = L.tr + 2;
   L.sal = L.sab + 128;
   L.sbe = L.sal + 64;
-  L.s32 = reinterpret_cast<float*>(L.sbe + 64);
+  L.s32 = hotS;
   __shared__ long long s_tick[2];
   L.tick = s_tick;
 

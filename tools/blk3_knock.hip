@@ -1,5 +1,6 @@
 // GPU-box diagnostic: time of a steady block of psmf_blk_filter3 with pieces knocked out (-DF3_KNOCK=mask, see psmf_blk3.hip):
 // what each piece costs on the critical path.  tools/knock.sh runs the set.
+#define F3_PREDICT 0
 #include "../rpsmf_amd/csrc/psmf_blk3.hip"
 #include <cstdio>
 #include <vector>
