@@ -374,7 +374,48 @@ __device__ __forceinline__ double shfl_f64(double v, int src) { return __shfl(v,
 // (psmf_kernels.hip) -- half as many dependent rounds as single pivots, and a round here costs lane shuffles (the two pivot
 // rows by column, and by symmetry the two pivot columns by row) plus three v_readlane for the block: no LDS memory, no
 // barrier.  Bitwise symmetric in, bitwise symmetric out (every pair term is a product of the same two numbers).
+// The same sweep with the rank-2 update of a pivot round on the matrix cores (one v_mfma_f64_16x16x4_f64 instead of 16 lane
+// shuffles and 8 FMAs; a lone wave issues one instruction per 4+ cycles, so a round costs what it has instructions).
+// Rows k, k + 1 of the matrix are the register A[k >> 2] of the lanes lk = k & 3, (k + 1) & 3 -- which is exactly where the
+// A operand of the MFMA wants the two columns u, w (by symmetry) in k-slots k & 3, (k + 1) & 3; the B operand is
+// -Ki [u; w]^T in the same lanes (pivot columns: +Ki, their C input zeroed), formed from u_j, w_j that one
+// v_permlane16_swap pair brings into both rows.  D = keep o A - u t1^T - w t2^T, then the pivot rows are overwritten in place.
 __device__ __forceinline__ void wave_sweep16(double (&A)[4], const int r2, const int lk, const int lr, bool& bad) {
+#pragma unroll
+  for (int k = 0; k < 16; k += 2) {
+    if (k < r2) {                                  // uniform
+      const int b0 = (k & 3) << 4, b1 = b0 + 16, kq = k >> 2;
+      const double rk = A[kq];
+      const double ka = readlane_f64(rk, b0 | k), kb = readlane_f64(rk, b0 | (k + 1)), ke = readlane_f64(rk, b1 | (k + 1));
+      const double det = ka * ke - kb * kb;
+      bad |= !(ka > 0.0) | !(det > 0.0);
+      const double dinv = fast_rcp(det);
+      const double kp = ke * dinv, kq2 = -kb * dinv, ks = ka * dinv;       // Ki = [[kp, kq2], [kq2, ks]]
+      // u_j (even row of the pair) and w_j (odd row) in both rows of each pair
+      const unsigned lo = __double2loint(rk), hi = __double2hiint(rk);
+      const auto l2 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+      const auto h2 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+      const double uj = __hiloint2double(h2[0], l2[0]), wj = __hiloint2double(h2[1], l2[1]);
+      const bool c0 = (lr == k), c1 = (lr == k + 1), piv = c0 | c1;
+      const bool in_piv = (lk >> 1) == ((k >> 1) & 1);      // the lanes that hold the two pivot rows
+      const bool is_u = (lk & 1) == 0;                      // ... row k (else row k + 1)
+      const double u1 = c0 ? 1.0 : (c1 ? 0.0 : uj), w1 = c0 ? 0.0 : (c1 ? 1.0 : wj);
+      const double cu = is_u ? kp : kq2, cw = is_u ? kq2 : ks;
+      const double sv = cu * u1 + cw * w1;                  // t1_j / t2_j; at the pivot columns the entries of Ki
+      const double aop = in_piv ? rk : 0.0;
+      const double bop = in_piv ? (piv ? sv : -sv) : 0.0;
+      const double keep = piv ? 0.0 : 1.0;
+      f64x4 acc = {keep * A[0], keep * A[1], keep * A[2], keep * A[3]};
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) A[q] = acc[q];
+      A[kq] = in_piv ? (piv ? -sv : sv) : acc[kq];          // the pivot rows: t1, t2; pivot block: -Ki
+    }
+  }
+}
+
+// (the first version of round 2: the pivot columns travel by lane shuffles, the update is 8 FMAs per lane)
+__device__ __forceinline__ void wave_sweep16_shfl(double (&A)[4], const int r2, const int lk, const int lr, bool& bad) {
 #pragma unroll
   for (int k = 0; k < 16; k += 2) {
     if (k < r2) {                                  // uniform
@@ -664,33 +705,26 @@ __global__ __launch_bounds__(WG) void psmf_impute_kernel2(ImputeParams p) {
           for (int q = 0; q < 4; ++q) A[q] = inq[q] ? kappa * G[q] - A[q] : (((lk + 4 * q) == lr) ? 1.0 : 0.0);
         }
         wave_sweep16(A, r2, lk, lr, bad);                // -P+
-        // b by column: element (row r, column lr) of the augmented tile / (row lr, column 0) of the second tile
-        double bc;
-        if (one_tile) {
-          double t4[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) t4[q] = shfl_f64(Bq[q], ((r & 3) << 4) | lr);
-          bc = t4[0];
-#pragma unroll
-          for (int q = 1; q < 4; ++q) bc = ((r >> 2) == q) ? t4[q] : bc;
-        } else {
-          double t4[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) t4[q] = shfl_f64(Bq[q], (lr & 3) << 4);
-          bc = t4[0];
-#pragma unroll
-          for (int q = 1; q < 4; ++q) bc = ((lr >> 2) == q) ? t4[q] : bc;
-        }
-        if (lr >= r) bc = 0.0;
-        double z[4], part = 0.0;
+        // z = P+ b on the matrix cores: A[q] (symmetric) is the A operand of k-block q as it stands; b_i sits in Bq[q] of the
+        // lanes lr == lb (column r of the augmented tile / column 0 of the second one): as the B operand it makes column lb
+        // of the product z -- no shuffle of b to the columns, no row sums (4 x 12 DPP instructions)
         const int lb = one_tile ? r : 0;
+        f64x4 zacc0 = {0.0, 0.0, 0.0, 0.0}, zacc1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          z[q] = row_sum_f64_dpp(inq[q] ? -A[q] * bc : 0.0);          // (P+ C^T e)_i, i = lk + 4 q, in every lane of the row
+          const double bop = (lr == lb && (lk + 4 * q) < r) ? Bq[q] : 0.0;
+          const double aop = inq[q] ? A[q] : 0.0;
+          if (q & 1) zacc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, zacc1, 0, 0, 0);
+          else zacc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, zacc0, 0, 0, 0);
+        }
+        double z[4], part = 0.0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          z[q] = -(zacc0[q] + zacc1[q]);                              // (P+ C^T e)_i, i = lk + 4 q, on the lanes lr == lb
           part += ((lk + 4 * q) < r) ? Bq[q] * z[q] : 0.0;            // b_i z_i on the lanes that hold b_i (lr == lb)
         }
         const double bPb = (readlane_f64(part, lb) + readlane_f64(part, 16 + lb)) + (readlane_f64(part, 32 + lb) + readlane_f64(part, 48 + lb));
-        if (lr == 0) {
+        if (lr == lb) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
             const int i = lk + 4 * q;
