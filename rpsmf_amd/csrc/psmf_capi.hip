@@ -62,6 +62,7 @@ struct psmf_filter {
   double kernel_ms_sum = 0.0;
   long long kernel_launches = 0;
   int reserved_cus = 0;
+  int bulk_wgs = 256;          // workgroups of the streaming bulk kernels (one per CU of the bulk stream: a 257th would wait for a whole round)
   double* scratch = nullptr;   // sq-error partials / predict staging
   // blocked engine
   int engine = 1;              // 1 per-step, 2 blocked
@@ -264,11 +265,11 @@ void launch_blk_xgram(psmf_filter* h, const psmf::BlockParams& x, double* xg, hi
     const int nct = (h->block_steps + 15) / 16;
     const size_t lds = psmf::blk_xgram2_lds_bytes();
     if (nct <= 2) {
-      hipLaunchKernelGGL(psmf::psmf_blk_xgram2<2>, dim3(psmf::BK_XG_WG), dim3(psmf::BK_NT), lds, stream, x);
-      hipLaunchKernelGGL(psmf::psmf_blk_xreduce2<2>, dim3(6 * 2 * 256 / 32), dim3(256), 0, stream, (const double*)x.XGpart, xg, (int)psmf::BK_XG_WG);
+      hipLaunchKernelGGL(psmf::psmf_blk_xgram2<2>, dim3(h->bulk_wgs), dim3(psmf::BK_NT), lds, stream, x);
+      hipLaunchKernelGGL(psmf::psmf_blk_xreduce2<2>, dim3(6 * 2 * 256 / 32), dim3(256), 0, stream, (const double*)x.XGpart, xg, h->bulk_wgs);
     } else {
-      hipLaunchKernelGGL(psmf::psmf_blk_xgram2<3>, dim3(psmf::BK_XG_WG), dim3(psmf::BK_NT), lds, stream, x);
-      hipLaunchKernelGGL(psmf::psmf_blk_xreduce2<3>, dim3(7 * 3 * 256 / 32), dim3(256), 0, stream, (const double*)x.XGpart, xg, (int)psmf::BK_XG_WG);
+      hipLaunchKernelGGL(psmf::psmf_blk_xgram2<3>, dim3(h->bulk_wgs), dim3(psmf::BK_NT), lds, stream, x);
+      hipLaunchKernelGGL(psmf::psmf_blk_xreduce2<3>, dim3(7 * 3 * 256 / 32), dim3(256), 0, stream, (const double*)x.XGpart, xg, h->bulk_wgs);
     }
     return;
   }
@@ -319,8 +320,8 @@ void launch_blk_apply(psmf_filter* h, const psmf::BlockParams& b, hipStream_t st
   if (blk_bulk2_ok(h)) {
     const int nyc = (h->block_steps + 15) / 16;
     const size_t lds = psmf::blk_apply2_lds_bytes();
-    if (nyc <= 2) hipLaunchKernelGGL(psmf::psmf_blk_apply2<2>, dim3(256), dim3(psmf::BK_NT), lds, stream, b);
-    else hipLaunchKernelGGL(psmf::psmf_blk_apply2<3>, dim3(256), dim3(psmf::BK_NT), lds, stream, b);
+    if (nyc <= 2) hipLaunchKernelGGL(psmf::psmf_blk_apply2<2>, dim3(h->bulk_wgs), dim3(psmf::BK_NT), lds, stream, b);
+    else hipLaunchKernelGGL(psmf::psmf_blk_apply2<3>, dim3(h->bulk_wgs), dim3(psmf::BK_NT), lds, stream, b);
     return;
   }
   if (blk_use_mfma()) {
@@ -700,6 +701,18 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
           h->fstream = fs;
           h->bulk = bs;
           h->reserved_cus = nres;
+          // The streaming kernels hold one 512-thread workgroup per CU (147 KB of LDS), and the dispatcher deals workgroups
+          // to the 32 shader engines (8 XCDs x 4) in equal shares whatever the mask has left each of them.  The filter's
+          // 8 CUs are CU 0 of engine 0 of every XCD (mask bit = 32 cu + 8 se + xcc, tools/xcc_probe.hip): those engines
+          // keep 7 CUs, so with more than 7 workgroups per engine one CU gets a second one and the kernel takes two
+          // rounds -- 231 / 317 us per block at d = 1e6 with 248 or 256 workgroups against 138 / 193 us with 224
+          // (tools/bulk_stream.hip; 124 / 172 us on the unmasked chip).  Hence (CUs per engine - 1) x 32.
+          {
+            const int n_engines = 32, per_engine = ncu / n_engines - (nres + n_engines - 1) / n_engines;
+            h->bulk_wgs = per_engine >= 1 ? per_engine * n_engines : 8;
+            if (h->bulk_wgs > 256) h->bulk_wgs = 256;
+            if (const char* e = getenv("PSMF_BULK_WGS")) { const int v = atoi(e); if (v >= 8 && v <= 256) h->bulk_wgs = (v / 8) * 8; }
+          }
         } else {
           (void)hipGetLastError();
           if (fs) hipStreamDestroy(fs);
