@@ -470,3 +470,44 @@ def test_rpsmf_scaling_factors_and_fixed_lambda(d, r, T, fixed_lambda, engine):
     assert relerr(f.y_pred(0, T), Yp) < TOL["f64"]
     assert relerr(s["rho"], st.rho) < TOL["f64"] and relerr(s["lam"], st.lam) < 1e-12
     f.close()
+
+
+@pytest.mark.parametrize("robust", [False, True])
+@pytest.mark.parametrize("r,storage", [(32, "f32"), (20, "f32"), (12, "f64")])
+def test_start_predictor_saves_iterations_not_accuracy(r, storage, robust):
+    """psmf_blk_filter3's start predictor (rank-2 downdate of the previous inverse, rescaled by the kappa ratio):
+    against the plain start (PSMF_NS_PREDICT=0) the same result within the engine's tolerance vs the oracle, with fewer
+    Newton-Schulz residual evaluations and no more direct sweeps."""
+    import os
+    if os.environ.get("PSMF_FILTER3") == "0" or os.environ.get("PSMF_NS") == "0":
+        pytest.skip("a fallback was selected in the environment")
+    c = _capi()
+    d, T = 3072, 400
+    Y, C0 = _problem(d, r, T, 777 + r, "normal")
+    V0, P0, Q = 0.1 * np.eye(r), np.eye(r), 0.1 * np.eye(r)
+    st = O.State(C=C0, V=V0, mu=np.zeros(r), P=P0, Q=Q, rho=1.0, lam=1.8)
+    st, _, _ = O.run_epoch(st, Y, O.Mode(robust=robust), O.RandomWalkDyn())
+    res = {}
+    old = os.environ.get("PSMF_NS_PREDICT")
+    try:
+        for mode in ("0", "7"):
+            os.environ["PSMF_NS_PREDICT"] = mode
+            f = c.DeviceFilter(d, r, robust=robust, storage=storage, engine="block")
+            f.upload_series(Y)
+            f.set_state(C0, V0, P0, Q, np.zeros(r), rho=1.0, lambda0=1.8)
+            f.counters(reset=True)
+            f.run(0, T)
+            res[mode] = (f.get_state(), f.counters())
+            f.close()
+    finally:
+        if old is None:
+            os.environ.pop("PSMF_NS_PREDICT", None)
+        else:
+            os.environ["PSMF_NS_PREDICT"] = old
+    for mode in ("0", "7"):
+        _compare(res[mode][0], st, TOL[storage])
+    plain, pred = res["0"][1], res["7"][1]
+    # one direct sweep of both matrices costs what ~10 Newton-Schulz iterations do (15 us against 0.9 + the plain step)
+    cost = lambda cn: cn["ns_iterations"] + 10 * cn["sweep_steps"]
+    assert cost(pred) < 0.8 * cost(plain), (plain, pred)
+    assert pred["sweep_steps"] <= plain["sweep_steps"]
