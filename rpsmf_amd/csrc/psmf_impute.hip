@@ -361,21 +361,19 @@ __global__ __launch_bounds__(WG) void psmf_impute_kernel(ImputeParams p) {
 //   P3a wave 0: sums the three partial tiles -- which leaves G in the MFMA output layout (lane = column, 4 rows per
 //       lane) -- <G, P + Q>, eta, N, phi                                                                  | barrier 3
 //   P3b wave 0 alone, NO barrier: the two symmetric sweep inversions of the reference's Woodbury form (PSMF.py:30-36)
-//       with the 16 x 16 matrix in its registers -- pivot row and column travel by lane shuffles, the pivot by
-//       v_readlane -- then x_t = x_p + kappa P+ C^T e, omega, P, Q
+//       with the 16 x 16 matrix in its registers -- the rank-2 update of a pivot round is one float64 MFMA, the pivot
+//       block travels by v_readlane (wave_sweep16) -- then x_t = x_p + kappa P+ C^T e (four MFMAs), omega, P, Q
 //   P4  meanwhile waves 1-3: rank-1 updates of C and V (they need N, phi only); then every row owner: bands, metrics | barrier 4
 // P, Q, rho, lambda live in wave 0's registers for the whole run; x is double-buffered in LDS.
 // Measured on the config-D shape (d = 19, r = 10): tools/impute_prof.hip.
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double shfl_f64(double v, int src) { return __shfl(v, src, 64); }
-
-// symmetric sweep of the leading r2 x r2 block (r2 even; identity padding beyond r) of the 16 x 16 matrix held by ONE wave
+// Symmetric sweep of the leading r2 x r2 block (r2 even; identity padding beyond r) of the 16 x 16 matrix held by ONE wave
 // (lane: column lr = l & 15, rows lk + 4 q, lk = l >> 4):  A <- -A^-1, by 2 x 2 SPD block pivots as sweep_all
-// (psmf_kernels.hip) -- half as many dependent rounds as single pivots, and a round here costs lane shuffles (the two pivot
-// rows by column, and by symmetry the two pivot columns by row) plus three v_readlane for the block: no LDS memory, no
-// barrier.  Bitwise symmetric in, bitwise symmetric out (every pair term is a product of the same two numbers).
-// The same sweep with the rank-2 update of a pivot round on the matrix cores (one v_mfma_f64_16x16x4_f64 instead of 16 lane
-// shuffles and 8 FMAs; a lone wave issues one instruction per 4+ cycles, so a round costs what it has instructions).
+// (psmf_kernels.hip) -- half as many dependent rounds as single pivots -- with no LDS memory and no barrier: the rank-2
+// update of a pivot round is ONE v_mfma_f64_16x16x4_f64, the pivot block travels by v_readlane.  (A lone wave issues one
+// instruction per 4+ cycles, so a round costs what it has instructions: the first version moved the pivot rows and columns
+// with 20 lane shuffles and updated with 8 FMAs per lane, 100 instructions per round against 50.)  Symmetric in, symmetric
+// out up to round-off (the two halves of a pair are different FMA chains on the matrix cores).
 // Rows k, k + 1 of the matrix are the register A[k >> 2] of the lanes lk = k & 3, (k + 1) & 3 -- which is exactly where the
 // A operand of the MFMA wants the two columns u, w (by symmetry) in k-slots k & 3, (k + 1) & 3; the B operand is
 // -Ki [u; w]^T in the same lanes (pivot columns: +Ki, their C input zeroed), formed from u_j, w_j that one
@@ -414,40 +412,6 @@ __device__ __forceinline__ void wave_sweep16(double (&A)[4], const int r2, const
   }
 }
 
-// (the first version of round 2: the pivot columns travel by lane shuffles, the update is 8 FMAs per lane)
-__device__ __forceinline__ void wave_sweep16_shfl(double (&A)[4], const int r2, const int lk, const int lr, bool& bad) {
-#pragma unroll
-  for (int k = 0; k < 16; k += 2) {
-    if (k < r2) {                                  // uniform
-      const int b0 = (k & 3) << 4, b1 = ((k + 1) & 3) << 4, kq = k >> 2;    // rows k, k + 1 share the register (k even)
-      const double rk = A[kq];
-      const double uc = shfl_f64(rk, b0 | lr), wc = shfl_f64(rk, b1 | lr);
-      double ui[4], wi[4];
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        ui[q] = shfl_f64(rk, b0 | (lk + 4 * q));
-        wi[q] = shfl_f64(rk, b1 | (lk + 4 * q));
-      }
-      const double ka = readlane_f64(rk, b0 | k), kb = readlane_f64(rk, b0 | (k + 1)), ke = readlane_f64(rk, b1 | (k + 1));
-      const double det = ka * ke - kb * kb;
-      bad |= !(ka > 0.0) | !(det > 0.0);
-      const double dinv = fast_rcp(det);
-      const double kp = ke * dinv, kq2 = -kb * dinv, ks = ka * dinv;       // Ki = [[kp, kq2], [kq2, ks]]
-      const bool c0 = (lr == k), c1 = (lr == k + 1);
-      // this lane's column: generic t = Ki [u_c; w_c]; pivot columns: -row of Ki
-      const double t1 = kp * uc + kq2 * wc, t2 = kq2 * uc + ks * wc;
-      const double g1 = c0 ? -kp : (c1 ? -kq2 : t1);
-      const double g2 = c0 ? -kq2 : (c1 ? -ks : t2);
-      const double keep = (c0 | c1) ? 0.0 : 1.0;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int i = lk + 4 * q;
-        const double upd = fma(-wi[q], g2, fma(-ui[q], g1, keep * A[q]));
-        A[q] = (i == k) ? g1 : ((i == k + 1) ? g2 : upd);
-      }
-    }
-  }
-}
 
 __global__ __launch_bounds__(WG) void psmf_impute_kernel2(ImputeParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
