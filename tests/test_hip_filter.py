@@ -511,3 +511,40 @@ def test_start_predictor_saves_iterations_not_accuracy(r, storage, robust):
     cost = lambda cn: cn["ns_iterations"] + 10 * cn["sweep_steps"]
     assert cost(pred) < 0.8 * cost(plain), (plain, pred)
     assert pred["sweep_steps"] <= plain["sweep_steps"]
+
+
+def test_bulk_kernel_grid_does_not_change_the_result_beyond_rounding():
+    """The streaming bulk kernels are grid-stride over 16-row tiles; the library sizes their grid to the CUs the bulk stream's
+    shader engines really have (224 on an MI355X with the filter's CUs reserved).  Any grid gives the same
+    filter up to the rounding of a different grouping of the cross-Gram's partial sums."""
+    import os
+    c = _capi()
+    d, r, T = 5000, 32, 130
+    Y, C0 = _problem(d, r, T, 99, "normal")
+    V0, P0, Q = 0.1 * np.eye(r), np.eye(r), 0.1 * np.eye(r)
+    st = O.State(C=C0, V=V0, mu=np.zeros(r), P=P0, Q=Q, rho=1.0, lam=1.8)
+    st, _, _ = O.run_epoch(st, Y, O.Mode(), O.RandomWalkDyn())
+    old = os.environ.get("PSMF_BULK_WGS")
+    states = []
+    try:
+        for wgs in ("8", "104", "256", None):
+            if wgs is None:
+                os.environ.pop("PSMF_BULK_WGS", None)
+            else:
+                os.environ["PSMF_BULK_WGS"] = wgs
+            f = c.DeviceFilter(d, r, storage="f32", engine="block")
+            f.upload_series(Y)
+            f.set_state(C0, V0, P0, Q, np.zeros(r), rho=1.0, lambda0=1.8)
+            f.run(0, T)
+            states.append(f.get_state())
+            f.close()
+    finally:
+        if old is None:
+            os.environ.pop("PSMF_BULK_WGS", None)
+        else:
+            os.environ["PSMF_BULK_WGS"] = old
+    for s in states:
+        _compare(s, st, TOL["f32"])
+    for s in states[:-1]:
+        for k in ("C", "V", "mu", "P"):
+            assert np.linalg.norm(s[k] - states[-1][k]) <= 1e-6 * np.linalg.norm(states[-1][k]) + 1e-300
