@@ -21,7 +21,8 @@ namespace psmf {
 
 // per-wave time stamps for tools/bulk_prof.hip (BK_STAMPS); no-ops in the product
 #ifdef BK_STAMPS
-#define BK_STAMP(i) do { if ((threadIdx.x & 63) == 0) reinterpret_cast<long long*>(b.Kpart)[(blockIdx.x * BK_WAVES + (threadIdx.x >> 6)) * 8 + (i)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+// slot i: s_memrealtime (100 MHz), slot 4 + i: s_memtime (shader clock) -- their ratio is the clock the CU really ran at
+#define BK_STAMP(i) do { if ((threadIdx.x & 63) == 0) { long long* s_ = reinterpret_cast<long long*>(b.Kpart) + (blockIdx.x * BK_WAVES + (threadIdx.x >> 6)) * 8; s_[i] = (long long)__builtin_amdgcn_s_memrealtime(); s_[4 + (i)] = (long long)__builtin_amdgcn_s_memtime(); } } while (0)
 #else
 #define BK_STAMP(i) do { } while (0)
 #endif
@@ -29,12 +30,20 @@ namespace psmf {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK_TR = 16;      // rows per wave tile
-constexpr int BK_S = 144;      // row stride (doubles) of the cross-Gram image: 128 columns + 16 (two rows 32 banks apart)
+constexpr int BK_FS = 20;      // column stride (floats) of a wave's tile image [128 columns][16 rows + 4]: a lane's four rows
+                               // of a column are one aligned 16-byte store, operand reads are 2-way bank conflicts at worst
+constexpr int BK_FIMG = 128 * BK_FS;   // floats per wave image (10 KB)
 constexpr int BK_WAVES = 8;
 constexpr int BK_NT = 64 * BK_WAVES;
 constexpr int BK_XG_WG = 256;  // workgroups (= partials) of the cross-Gram
 
-inline size_t blk_xgram2_lds_bytes() { return (size_t)BK_WAVES * BK_TR * BK_S * 8; }
+// the wave images (float32: the tile is stored as loaded and converted where the MFMA operands are read -- the store phase
+// of a tile is 12 LDS writes instead of 24 conversions + 24 writes, which is what the second wave of a SIMD could not hide)
+// or the two buffers of the tree reduction at the end (7 x 3 tiles of 256 doubles each), whichever is larger
+inline size_t blk_xgram2_lds_bytes() {
+  const size_t img = (size_t)BK_WAVES * BK_FIMG * 4, red = (size_t)2 * 7 * 3 * 256 * 8;
+  return img > red ? img : red;
+}
 
 // 16-byte load of 4 consecutive rows of one series column / 4 consecutive elements of C; the guarded form serves the
 // last (partial) tile
@@ -64,7 +73,7 @@ __global__ __launch_bounds__(BK_NT) void psmf_blk_xgram2(BlockParams b) {
   const float* __restrict__ C = reinterpret_cast<const float*>(p.C);
   const float* __restrict__ Y = reinterpret_cast<const float*>(p.Y) + (size_t)(b.k0 - p.series_t0) * dl;
   const float* __restrict__ Y1 = reinterpret_cast<const float*>(p.Y) + (size_t)(b.k1 - p.series_t0) * dl;
-  double* img = smem + (size_t)w * BK_TR * BK_S;
+  float* img = reinterpret_cast<float*>(smem_raw) + (size_t)w * BK_FIMG;      // [column][row], column stride BK_FS
   BK_STAMP(0);
   f64x4 acc[NRT * NCT];
 #pragma unroll
@@ -110,38 +119,34 @@ __global__ __launch_bounds__(BK_NT) void psmf_blk_xgram2(BlockParams b) {
   int kt = 0;
   int t = tile_of(0);
   if (t < ntile) load_tile(t);
-  for (int i = lane; i < BK_TR * BK_S; i += 64) img[i] = 0.0;       // (behind the first tile's loads)
+  for (int i = lane; i < BK_FIMG; i += 64) img[i] = 0.f;       // (behind the first tile's loads)
   BK_STAMP(1);
   while (t < ntile) {
-    // registers -> float64 image
+    // registers -> image, as loaded (float32)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       if (cok[i]) {
-        double* d = img + crow[i] * BK_S + ccol[i];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          if (ccol[i] + j < r) d[j] = (double)cv[i][j];
+          if (ccol[i] + j < r) img[(ccol[i] + j) * BK_FS + crow[i]] = cv[i][j];
       }
     }
 #pragma unroll
     for (int i = 0; i < NCT; ++i) {
       const int q = lcol + 16 * i;
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (q < nb) img[(4 * lrow + j) * BK_S + r + q] = (double)yv[i][j];
-        if (q < nb1) img[(4 * lrow + j) * BK_S + 64 + q] = (double)nv[i][j];
-      }
+      if (q < nb) *reinterpret_cast<f32x4*>(img + (r + q) * BK_FS + 4 * lrow) = yv[i];
+      if (q < nb1) *reinterpret_cast<f32x4*>(img + (64 + q) * BK_FS + 4 * lrow) = nv[i];
     }
     const int tn = tile_of(++kt);
     if (tn < ntile) load_tile(tn);                 // in flight during the MFMAs below
 #pragma unroll
     for (int kk = 0; kk < BK_TR / 4; ++kk) {
-      const double* rowp = img + (4 * kk + lrow) * BK_S + lcol;
+      const float* rowp = img + lcol * BK_FS + 4 * kk + lrow;
       double av[NRT], bv[NCT];
 #pragma unroll
-      for (int rt = 0; rt < NRT; ++rt) av[rt] = rowp[16 * rt];          // rt >= 4: columns 64 + 16 (rt - 4) = 16 rt
+      for (int rt = 0; rt < NRT; ++rt) av[rt] = (double)rowp[16 * rt * BK_FS];          // rt >= 4: columns 64 + 16 (rt - 4) = 16 rt
 #pragma unroll
-      for (int ct = 0; ct < NCT; ++ct) bv[ct] = rowp[64 + 16 * ct];
+      for (int ct = 0; ct < NCT; ++ct) bv[ct] = (double)rowp[(64 + 16 * ct) * BK_FS];
 #pragma unroll
       for (int rt = 0; rt < NRT; ++rt)
 #pragma unroll
@@ -225,7 +230,8 @@ __global__ __launch_bounds__(256) void psmf_blk_xreduce2(const double* __restric
 constexpr int AP2_SC = 36;     // staging row stride (floats) of the C part  [16 rows][rp <= 32]
 constexpr int AP2_SY = 20;     // staging stride (floats) of the series part  [column][16 rows]
 constexpr int AP2_NY = 48;     // series columns staged = the longest block (psmf_capi.hip caps blocks at 48 timesteps)
-constexpr size_t AP2_WAVE_BYTES = (size_t)BK_TR * AP_S * 8 + BK_TR * AP2_SC * 4 + AP2_NY * AP2_SY * 4;
+constexpr int AP2_FZ = 64 * BK_FS;      // floats of a wave's slab image [64 coefficient columns][16 rows + 4], float32 as loaded
+constexpr size_t AP2_WAVE_BYTES = (size_t)AP2_FZ * 4 + BK_TR * AP2_SC * 4 + AP2_NY * AP2_SY * 4;
 inline size_t blk_apply2_lds_bytes() { return (size_t)RB * GZ_S * 8 + (size_t)BK_WAVES * AP2_WAVE_BYTES; }
 
 template <int NYC>       // 16-column pieces of the series block: ceil((64 - r) / 16)
@@ -236,8 +242,8 @@ __global__ __launch_bounds__(BK_NT) void psmf_blk_apply2(BlockParams b) {
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lrow = lane >> 4, lcol = lane & 15;
   const int r = p.r, rp = p.rp, dl = p.d_local, nb = b.nb;
   char* wbase = smem_raw + (size_t)RB * GZ_S * 8 + (size_t)w * AP2_WAVE_BYTES;
-  double* sZ = reinterpret_cast<double*>(wbase);                         // 16 x AP_S
-  float* sC = reinterpret_cast<float*>(wbase + BK_TR * AP_S * 8);        // 16 x AP2_SC
+  float* sZ = reinterpret_cast<float*>(wbase);                           // [64 columns of Z][BK_FS]: column-major, float32
+  float* sC = reinterpret_cast<float*>(wbase + AP2_FZ * 4);              // 16 x AP2_SC
   float* sY = sC + BK_TR * AP2_SC;                                       // AP2_NY x AP2_SY  (index = output column - r)
   BK_STAMP(0);
   float* __restrict__ C = reinterpret_cast<float*>(p.C);
@@ -297,9 +303,18 @@ __global__ __launch_bounds__(BK_NT) void psmf_blk_apply2(BlockParams b) {
       sW[m * GZ_S + c] = c < r ? va[u] : (c < r + nb ? vb[u] : 0.0);
     }
   }
-  for (int i = lane; i < BK_TR * AP_S; i += 64) sZ[i] = 0.0;
+  for (int i = lane; i < AP2_FZ; i += 64) sZ[i] = 0.f;
   for (int i = lane; i < BK_TR * AP2_SC; i += 64) sC[i] = 0.f;
   __syncthreads();
+  // the B operands (the block's coefficient matrix) are the same for every slab: 64 doubles per lane, kept in registers
+  // (they were 64 of the 80 LDS reads of a slab, issued in two bursts that the MFMAs had to wait for)
+  double bw[2][4][8];
+#pragma unroll
+  for (int half = 0; half < 2; ++half)
+#pragma unroll
+    for (int kq = 0; kq < 8; ++kq)
+#pragma unroll
+      for (int ct = 0; ct < 4; ++ct) bw[half][ct][kq] = sW[(32 * half + 4 * kq + lrow) * GZ_S + 16 * ct + lcol];
   BK_STAMP(1);
   while (t < nslab) {
     const int row0 = t * BK_TR;
@@ -307,19 +322,15 @@ __global__ __launch_bounds__(BK_NT) void psmf_blk_apply2(BlockParams b) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       if (cok[i]) {
-        double* d = sZ + crow[i] * AP_S + ccol[i];
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-          if (ccol[i] + j < r) d[j] = (double)cv[i][j];
+          if (ccol[i] + j < r) sZ[(ccol[i] + j) * BK_FS + crow[i]] = cv[i][j];
       }
     }
 #pragma unroll
     for (int i = 0; i < NYC; ++i) {
       const int q = lcol + 16 * i;
-      if (q < nb) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) sZ[(4 * lrow + j) * AP_S + r + q] = (double)yv[i][j];
-      }
+      if (q < nb) *reinterpret_cast<f32x4*>(sZ + (r + q) * BK_FS + 4 * lrow) = yv[i];
     }
     const int tn = slab_of(++kt);
     if (tn < nslab) load_slab(tn);                 // in flight during the MFMAs below
@@ -328,18 +339,13 @@ __global__ __launch_bounds__(BK_NT) void psmf_blk_apply2(BlockParams b) {
     for (int ct = 0; ct < 4; ++ct) acc[ct] = f64x4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-      double av[8], bv[4][8];
+      double av[8];
 #pragma unroll
-      for (int kq = 0; kq < 8; ++kq) {
-        const int k = 32 * half + 4 * kq + lrow;
-        av[kq] = sZ[lcol * AP_S + k];
-#pragma unroll
-        for (int ct = 0; ct < 4; ++ct) bv[ct][kq] = sW[k * GZ_S + 16 * ct + lcol];
-      }
+      for (int kq = 0; kq < 8; ++kq) av[kq] = (double)sZ[(32 * half + 4 * kq + lrow) * BK_FS + lcol];
 #pragma unroll
       for (int kq = 0; kq < 8; ++kq)
 #pragma unroll
-        for (int ct = 0; ct < 4; ++ct) acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kq], bv[ct][kq], acc[ct], 0, 0, 0);
+        for (int ct = 0; ct < 4; ++ct) acc[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[kq], bw[half][ct][kq], acc[ct], 0, 0, 0);
     }
     // results -> staging (one rounding to float32 per block), then 16-byte stores
 #pragma unroll

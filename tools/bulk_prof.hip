@@ -2,10 +2,11 @@
 #define BK_STAMPS 1
 #include "../rpsmf_amd/csrc/psmf_bulk.hip"
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 using namespace psmf;
-int main() {
-  const int d = 100000, r = 32, nb = 32;
+int main(int argc, char** argv) {
+  const int d = argc > 1 ? atoi(argv[1]) : 100000, r = 32, nb = 32;
   float *C, *Y, *YP; double *XGpart, *A, *B; long long* stamps;
   hipMalloc(&C, (size_t)d * r * 4); hipMalloc(&Y, (size_t)3 * nb * d * 4); hipMalloc(&YP, (size_t)3 * nb * d * 4);
   hipMalloc(&XGpart, (size_t)256 * 8192 * 8); hipMalloc(&A, 64 * 64 * 8); hipMalloc(&B, 64 * 64 * 8); hipMalloc(&stamps, 256 * 8 * 8 * 8);
@@ -28,6 +29,9 @@ int main() {
     // per wave: [0] start, [1] first tile loaded/zeroed, [2] loop end, [3] after reduce / end
     double s1 = 0, s2 = 0, s3 = 0, mx = 0; long long tmin = 1LL << 62, tmax = 0;
     for (int w = 0; w < 256 * 8; ++w) { const long long* p = &h[w * 8]; s1 += p[1] - p[0]; s2 += p[2] - p[1]; s3 += p[3] - p[2]; if (p[3] - p[0] > mx) mx = p[3] - p[0]; if (p[0] < tmin) tmin = p[0]; if (p[3] > tmax) tmax = p[3]; }
+    double clk = 0;
+    for (int w = 0; w < 256 * 8; ++w) { const long long* p = &h[w * 8]; clk += (double)(p[6] - p[5]) / (double)(p[2] - p[1] > 0 ? p[2] - p[1] : 1); }
+    printf("   shader clock in the tile loop (s_memtime / s_memrealtime): %.0f MHz\n", 100.0 * clk / (256 * 8));
     const double n = 256 * 8;
     printf("%s: %.1f us by events; per wave (10 ns ticks -> us): prologue %.2f, tile loop %.2f, epilogue %.2f; slowest wave %.2f; first start -> last end %.2f\n",
            which == 0 ? "xgram2" : "apply2", best * 1e3, 0.01 * s1 / n, 0.01 * s2 / n, 0.01 * s3 / n, 0.01 * mx, 0.01 * (tmax - tmin));
