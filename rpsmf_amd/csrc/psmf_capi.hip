@@ -701,7 +701,7 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
           h->fstream = fs;
           h->bulk = bs;
           h->reserved_cus = nres;
-          // The streaming kernels hold one 512-thread workgroup per CU (147 KB of LDS), and the dispatcher deals workgroups
+          // The streaming kernels hold one 512-thread workgroup per CU (86-131 KB of LDS), and the dispatcher deals workgroups
           // to the 32 shader engines (8 XCDs x 4) in equal shares whatever the mask has left each of them.  The filter's
           // 8 CUs are CU 0 of engine 0 of every XCD (mask bit = 32 cu + 8 se + xcc, tools/xcc_probe.hip): those engines
           // keep 7 CUs, so with more than 7 workgroups per engine one CU gets a second one and the kernel takes two
