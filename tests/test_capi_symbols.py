@@ -55,3 +55,16 @@ def test_config_struct_matches_header_field_order():
     fields = re.findall(r"\b(?:int32_t|double)\s+([^;]+);", body)
     names = [n.strip() for grp in fields for n in grp.split(",")]
     assert names == [f[0] for f in _capi.PsmfConfig._fields_]
+
+
+def test_integration_stub_lists_the_config_fields_in_header_order():
+    """INTEGRATION.md shows the ctypes stub a maintainer of the reference would add: its psmf_config must be the header's."""
+    from rpsmf_amd import _capi
+
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    stub = text[text.index("class psmf_config(C.Structure)"):text.index("dp = C.POINTER(C.c_double)")]
+    ints = " ".join(re.findall(r'"([a-zA-Z_0-9 ]+)"\s*\)?\.split\(\)', stub)[:1])
+    parts = re.findall(r'"([a-zA-Z_0-9 ]+)"', stub)
+    names = " ".join(parts).split()
+    assert names == [f[0] for f in _capi.PsmfConfig._fields_], (names, ints)
+    assert f"abi_version={_capi.ABI_VERSION}" in text
