@@ -36,9 +36,23 @@ constexpr int kGramWG = 128;
 
 }  // namespace
 
+// Environment switches ("Switches"): read ONCE per handle, at psmf_create -- tests flip them between
+// handles of one process; nothing on the per-block host path calls getenv.
+struct Switches {
+  bool block_mfma = true, bulk2 = true, filter3 = true, block_dual = true, block_flags = true, block_chain = true, block_pipe = true;
+  bool force_collective = false;
+  static bool off(const char* name) { const char* e = getenv(name); return e && atoi(e) == 0; }
+  void read() {
+    block_mfma = !off("PSMF_BLOCK_MFMA"); bulk2 = !off("PSMF_BULK2"); filter3 = !off("PSMF_FILTER3"); block_dual = !off("PSMF_BLOCK_DUAL");
+    block_flags = !off("PSMF_BLOCK_FLAGS"); block_chain = !off("PSMF_BLOCK_CHAIN"); block_pipe = !off("PSMF_BLOCK_PIPE");
+    force_collective = getenv("PSMF_FORCE_COLLECTIVE") != nullptr;
+  }
+};
+
 struct psmf_filter {
   psmf_config cfg;
   Geometry geo;
+  Switches sw;
   hipStream_t stream = nullptr;
   DevState* st = nullptr;
   void* C = nullptr;
@@ -233,14 +247,11 @@ void fill_block_params(psmf_filter* h, psmf::BlockParams& b, int64_t k0, int nb,
   b.gram_rows = (h->cfg.d_local + psmf::BLK_GRAM_WG - 1) / psmf::BLK_GRAM_WG;
 }
 
-bool blk_use_mfma() {
-  const bool off = getenv("PSMF_BLOCK_MFMA") && atoi(getenv("PSMF_BLOCK_MFMA")) == 0;     // (read per call: tests switch it inside one process)
-  return !off;
-}
+bool blk_use_mfma(const psmf_filter* h) { return h->sw.block_mfma; }
 
 void launch_blk_gram(psmf_filter* h, const psmf::BlockParams& b, hipStream_t stream = nullptr) {
   if (!stream) stream = h->stream;
-  if (blk_use_mfma()) {
+  if (blk_use_mfma(h)) {
     if (h->cfg.storage == PSMF_F64)
       hipLaunchKernelGGL(psmf::psmf_blk_gram_mfma<double>, dim3(psmf::BLK_GRAM_WG), dim3(psmf::WG), 0, stream, b);
     else
@@ -255,8 +266,7 @@ void launch_blk_gram(psmf_filter* h, const psmf::BlockParams& b, hipStream_t str
 
 // streaming bulk kernels (psmf_bulk.hip): float32 storage, d_local a multiple of 4, 16 <= r <= 32
 bool blk_bulk2_ok(const psmf_filter* h) {
-  const bool off = getenv("PSMF_BULK2") && atoi(getenv("PSMF_BULK2")) == 0;     // (read per call: tests switch it inside one process)
-  return !off && blk_use_mfma() && h->cfg.storage == PSMF_F32 && (h->cfg.d_local % 4) == 0 && h->cfg.r <= 32 && (h->geo.rp % 4) == 0;
+  return h->sw.bulk2 && blk_use_mfma(h) && h->cfg.storage == PSMF_F32 && (h->cfg.d_local % 4) == 0 && h->cfg.r <= 32 && (h->geo.rp % 4) == 0;
 }
 
 void launch_blk_xgram(psmf_filter* h, const psmf::BlockParams& x, double* xg, hipStream_t stream) {
@@ -280,20 +290,18 @@ void launch_blk_xgram(psmf_filter* h, const psmf::BlockParams& x, double* xg, hi
   hipLaunchKernelGGL(psmf::psmf_blk_xreduce, dim3((int)(xg_elems / 128)), dim3(128), 0, stream, x, xg, (int)psmf::BLK_GRAM_WG);
 }
 
-bool blk_use_filter3() {
-  const bool off = getenv("PSMF_FILTER3") && atoi(getenv("PSMF_FILTER3")) == 0;     // (read per call: tests switch it inside one process)
-  return !off;
-}
+bool blk_use_filter3(const psmf_filter* h) { return h->sw.filter3; }
 
 bool blk_dual_ok(const psmf_filter* h) {
-  const bool off = getenv("PSMF_BLOCK_DUAL") && atoi(getenv("PSMF_BLOCK_DUAL")) == 0;     // (read per call: tests switch it inside one process)
-  return !off && h->q_iso && h->cfg.coef_update && h->cfg.pbar_predict && h->cfg.eta_full &&
-         h->cfg.dyn_kind == PSMF_DYN_RANDOM_WALK;
+  // The two-inversion kernels (filter3, filter3s, filter2) read rho and q ONCE per block: per-step R_k / Q_k schedules
+  // (psmf_set_schedules; the reference reads R[k], Q[k] every step, psmf.py:115,123,141) go to the general kernel.
+  return h->sw.block_dual && h->q_iso && h->cfg.coef_update && h->cfg.pbar_predict && h->cfg.eta_full &&
+         h->cfg.dyn_kind == PSMF_DYN_RANDOM_WALK && !h->sp.rho_sched && !h->sp.q_sched;
 }
 
 void launch_blk_filter(psmf_filter* h, const psmf::BlockParams& b, hipStream_t stream = nullptr) {
   if (!stream) stream = h->stream;
-  if (blk_dual_ok(h) && blk_use_filter3()) {
+  if (blk_dual_ok(h) && blk_use_filter3(h)) {
     if (h->cfg.r > 16) hipLaunchKernelGGL(psmf::psmf_blk_filter3, dim3(1), dim3(psmf::F3_NT), psmf::blk_filter3_lds_bytes(), stream, b);
     else hipLaunchKernelGGL(psmf::psmf_blk_filter3s, dim3(1), dim3(psmf::F3_NT), psmf::blk_filter3_lds_bytes(), stream, b);
     return;
@@ -324,7 +332,7 @@ void launch_blk_apply(psmf_filter* h, const psmf::BlockParams& b, hipStream_t st
     else hipLaunchKernelGGL(psmf::psmf_blk_apply2<3>, dim3(h->bulk_wgs), dim3(psmf::BK_NT), lds, stream, b);
     return;
   }
-  if (blk_use_mfma()) {
+  if (blk_use_mfma(h)) {
     const int nslab = (h->cfg.d_local + 15) / 16;
     int g = (nslab + 3) / 4;
     if (g > 1024) g = 1024;
@@ -380,7 +388,7 @@ int enqueue_blocks_pipelined(psmf_filter* h, int64_t k_begin, int64_t k_end) {
   if (h->fstream) HIP_TRY(h, hipStreamWaitEvent(fs, h->evS, 0));
   psmf::BlockParams b;
   // hand-off by device flags when the filter chain has a stream (hardware queue) of its own; by events otherwise
-  const bool flags_off = getenv("PSMF_BLOCK_FLAGS") && atoi(getenv("PSMF_BLOCK_FLAGS")) == 0;
+  const bool flags_off = !h->sw.block_flags;
   // (a tool that serialises dispatches: events.  A host-mediated communicator synchronises the bulk stream at every exchange
   //  anyway, and several such handles usually share one process and one GPU -- shards of a test -- where kernels that spin on
   //  flags could end up behind each other in a shared hardware queue: events there, too)
@@ -388,8 +396,8 @@ int enqueue_blocks_pipelined(psmf_filter* h, int64_t k_begin, int64_t k_end) {
   const long long s0 = h->seq_next;
   h->seq_next += nblk;
   // chain: the filter kernels of the whole run as ONE launch (psmf_blk_filter3; the bulk stream is driven as before)
-  const bool chain_off = getenv("PSMF_BLOCK_CHAIN") && atoi(getenv("PSMF_BLOCK_CHAIN")) == 0;
-  const bool chain = use_flags && !chain_off && nblk > 1 && blk_dual_ok(h) && blk_use_filter3();
+  const bool chain_off = !h->sw.block_chain;
+  const bool chain = use_flags && !chain_off && nblk > 1 && blk_dual_ok(h) && blk_use_filter3(h);
   // first block: plain Gram of the stored C
   fill_block_params(h, b, k0_of(0), nb_of(0), 0);
   launch_blk_gram(h, b, h->bulk);
@@ -636,6 +644,7 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
 
   psmf_filter* h = new psmf_filter();
   h->cfg = *cfg;
+  h->sw.read();
   compute_geometry(h->cfg, h->geo);
   auto bail = [&](int code) { g_create_error = h->err; psmf_destroy(h); return code; };
 #define CREATE_TRY(expr)                                                                  \
@@ -786,8 +795,8 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
   sp.use_ns = (getenv("PSMF_NS") && atoi(getenv("PSMF_NS")) == 0) ? 0 : 1;
   sp.ns_predict = getenv("PSMF_NS_PREDICT") ? atoi(getenv("PSMF_NS_PREDICT")) : 7;      // bits: 1 a / b (phase F), 2 core (wave 7), 4 applied
   // Newton-Schulz acceptance: ||I - M X||_F below the tolerance BEFORE the last update (which squares it).  float64
-  // storage: 3e-7 (-> 1e-13).  float32 storage: 1e-4 (-> 1e-8, far below the rounding of C and y to float32; measured
-  // effect on the error against the float64 oracle: none).  PSMF_NS_TOL overrides.
+  // storage: 3e-7 (-> 1e-13).  float32 storage: 3e-4 (-> ~1e-7, of the order of the rounding of C and y to float32; errors
+  // against the float64 oracle measured at 1e-4 / 3e-4 / 1e-3 in DESIGN section 5: unchanged up to 3e-4).  PSMF_NS_TOL overrides.
   const double ns_tol = getenv("PSMF_NS_TOL") ? atof(getenv("PSMF_NS_TOL")) : (cfg->storage == PSMF_F64 ? 3e-7 : 3e-4);
   sp.ns_tol2 = ns_tol * ns_tol;
   const double ns_far = getenv("PSMF_NS_FAR") ? atof(getenv("PSMF_NS_FAR")) : 0.3;
@@ -1002,7 +1011,7 @@ int psmf_run(psmf_handle h, int64_t k_begin, int64_t k_end) {
   }
   int64_t n = k_end - k_begin;
   if (h->engine == 2) {
-    const bool pipe_off = getenv("PSMF_BLOCK_PIPE") && atoi(getenv("PSMF_BLOCK_PIPE")) == 0;
+    const bool pipe_off = !h->sw.block_pipe;
     if (!pipe_off && k_end - k_begin > h->block_steps) {
       rc = enqueue_blocks_pipelined(h, k_begin, k_end);
       if (rc) return rc;
@@ -1391,7 +1400,7 @@ int psmf_comm_init(psmf_handle h, int nranks, int rank, const void* unique_id) {
     }
     hipFree(tmp);
   }
-  h->use_coll = nranks > 1 || getenv("PSMF_FORCE_COLLECTIVE") != nullptr;
+  h->use_coll = nranks > 1 || h->sw.force_collective;
   h->sp.external_reduce = h->use_coll ? 1 : 0;
   destroy_graph(h);
   h->need_prep = true;
@@ -1425,13 +1434,16 @@ int psmf_set_schedules(psmf_handle h, const double* rho_k, const double* q_k, in
   h->sched_n = 0;
   h->sp.rho_sched = h->sp.q_sched = nullptr;
   if ((rho_k || q_k) && n > 0) {
-    HIP_TRY(h, hipMalloc((void**)&h->sched, (size_t)2 * n * sizeof(double)));
-    std::vector<double> ones((size_t)n, 1.0);
-    HIP_TRY(h, hipMemcpy(h->sched, rho_k ? rho_k : ones.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice));
-    HIP_TRY(h, hipMemcpy(h->sched + n, q_k ? q_k : ones.data(), (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    // n + 1 entries each, the last one repeated: having finished step k the per-step engine's serial stage prepares step
+    // k + 1 and reads entry k + 1 -- one past the schedule on the last step of a run (the value is recomputed by the next prepare)
+    std::vector<double> buf((size_t)2 * (n + 1), 1.0);
+    if (rho_k) { memcpy(buf.data(), rho_k, (size_t)n * sizeof(double)); buf[n] = rho_k[n - 1]; }
+    if (q_k) { memcpy(buf.data() + n + 1, q_k, (size_t)n * sizeof(double)); buf[2 * n + 1] = q_k[n - 1]; }
+    HIP_TRY(h, hipMalloc((void**)&h->sched, buf.size() * sizeof(double)));
+    HIP_TRY(h, hipMemcpy(h->sched, buf.data(), buf.size() * sizeof(double), hipMemcpyHostToDevice));
     h->sched_n = n;
     if (rho_k) h->sp.rho_sched = h->sched;
-    if (q_k) h->sp.q_sched = h->sched + n;
+    if (q_k) h->sp.q_sched = h->sched + n + 1;
   }
   destroy_graph(h);      // the graph's kernel nodes carry StepParams by value
   h->need_prep = true;

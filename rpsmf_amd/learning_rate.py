@@ -3,6 +3,8 @@
 Interface of pypsmf/psmf/learning_rate.py: an object with ``get(t) -> float``.
 """
 
+__all__ = ["BaseLearningRate", "ConstantLearningRate", "ExponentialLearningRate"]
+
 
 class BaseLearningRate:
     def get(self, t):

@@ -1,0 +1,232 @@
+"""Recognising what a user's subclass computes, so that it can run on the device unchanged.
+
+The reference's plug-in API is the template method: an experiment subclasses `PSMFIter` / `rPSMFIter` and replaces hooks
+(ExperimentSynthetic/synthetic_psmf.py:78-100, synthetic_rpsmf.py:82-118) and passes a plain function as the
+nonlinearity (synthetic_psmf.py:105-106).  The device runs the whole time loop as fused kernels, so it can only execute hook
+configurations it has kernels for (`HIP_MODES`).  Instead of asking the user to annotate the class, the constructor PROBES it:
+
+* `recognise_hip_mode(obj)`: the subclass's hooks are executed, on the host, on a small random problem (a probe object of
+  the same class, a handful of rows, a few steps), and so are the library's own classes for every entry of `HIP_MODES`; the
+  mode whose C, V, mu, P, y_hat, gradient (and rPSMF's R, Q, lambda) agree to 1e-12 is the one the device runs.  No match:
+  the constructor raises, as before (or `backend="numpy"` executes the hooks themselves).
+* `recognise_nonlinearity(fn, n_params, rank)`: a plain callable is compared with the closed-form families the device
+  evaluates (nonlinearities.py) on random (theta, x, t); a match makes it run inside the device loop with analytic
+  derivatives, otherwise it stays host-stepped (psmf_step_host), which is correct for any callable.
+
+Nothing here touches the GPU or the oracle; the probes are r-sized host arithmetic, run once per construction.
+"""
+
+import numpy as np
+
+from . import nonlinearities as NL
+from .psmf import HIP_MODES, PSMFIter
+from .rpsmf import rPSMFIter
+
+__all__ = ["SimplifiedPSMF", "SimplifiedRPSMF", "recognise_hip_mode", "recognise_nonlinearity", "mode_class"]
+
+PROBE_TOL = 1e-12
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the library's own statement of the "simplified" mode (SURVEY App. A mode table), in O(d r) form
+# ---------------------------------------------------------------------------------------------------------------------
+class _SimplifiedHooks:
+    """P_bar = P_{k-1}; eta = tr(R_{k-1}) / d; no coefficient update (mu_k = mu_bar, P_k = P_bar)."""
+
+    hip_mode = "simplified"
+
+    def _noise_diag_prev(self, k):
+        from .psmf import _diag_of
+
+        dg = _diag_of(self._R[k - 1], self._d)
+        if dg is None:
+            raise NotImplementedError("simplified mode: diagonal R only")
+        return np.full(self._d, dg) if np.ndim(dg) == 0 else dg
+
+    def _predictive_covariance(self, i, k):
+        return self._P[k - 1]
+
+    def _compute_eta_k(self, k, P_bar):
+        return float(np.sum(self._noise_diag_prev(k))) / self._d
+
+    def _compute_inverse_coefficient_innovation(self, k, mu_bar, P_bar):
+        return None
+
+    def _update_coefficient_mean(self, k, yk, Skinv, mu_bar, P_bar):
+        self._mu[k] = mu_bar
+
+    def _update_coefficient_covariance(self, k, Skinv, P_bar, yk):
+        self._P[k] = P_bar
+
+
+class SimplifiedPSMF(_SimplifiedHooks, PSMFIter):
+    """PSMF with the ExperimentSynthetic simplifications (synthetic_psmf.py:82-98) as a ready-made class."""
+
+
+class SimplifiedRPSMF(_SimplifiedHooks, rPSMFIter):
+    """rPSMF with the ExperimentSynthetic simplifications (synthetic_rpsmf.py:86-114): omega from (R + s I)^-1 alone, R scaled
+    by omega, Q and P carried."""
+
+    def _update_coefficient_covariance(self, k, Skinv, P_bar, yk):
+        lam = self._lambda[k - 1]
+        mu_bar = self._mu[k]                                   # = mu_bar of this step (no coefficient update)
+        s = float(np.squeeze(mu_bar.T @ self._V[k - 1] @ mu_bar))
+        e = np.asarray(yk - self._y_pred[k]).reshape(-1)
+        quad = float(np.sum(e * e / (self._noise_diag_prev(k) + s)))
+        omega = (lam + quad) / (lam + self._d)
+        self._P[k] = P_bar
+        self._Q[k] = self._Q[k - 1]
+        self._R[k] = omega * self._R[k - 1]
+        if not self.fixed_lambda:
+            self._lambda[k] = lam + self._d
+
+
+def mode_class(mode, robust):
+    """The library class that states `mode` on the host."""
+    if mode == "full":
+        return rPSMFIter if robust else PSMFIter
+    if mode == "simplified":
+        return SimplifiedRPSMF if robust else SimplifiedPSMF
+    raise KeyError(mode)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# hook probing
+# ---------------------------------------------------------------------------------------------------------------------
+def _probe_problem(r, robust, fixed_lambda):
+    rng = np.random.default_rng(0x5EED0 + r)
+    d = 7
+    A, B = rng.standard_normal((r, r)), rng.standard_normal((r, r))
+    return dict(
+        d=d, steps=3,
+        theta0=0.05 + 0.1 * rng.random((r, 1)),
+        C0=0.3 * rng.standard_normal((d, r)),
+        V0=0.2 * np.eye(r) + 0.02 * (A @ A.T) / r,
+        mu0=0.3 * rng.standard_normal((r, 1)),
+        P0=0.5 * np.eye(r) + 0.05 * (B @ B.T) / r,
+        Q=0.07 * np.eye(r),
+        rho=[1.3, 0.9, 1.1, 0.8],                 # PSMFIter reads R[k] / R[k-1]: different every step, so the index matters
+        lambda0=2.3,
+        Y=rng.standard_normal((3, d)),
+        fixed_lambda=fixed_lambda,
+    )
+
+
+def _make_probe(cls, robust, pb, alpha, beta):
+    """An object of class `cls` initialised by the LIBRARY initialiser (numpy back end) on the probe problem."""
+    d, r = pb["C0"].shape
+    nl = NL.CosPhase(r)
+    obj = object.__new__(cls)
+    if robust:
+        rPSMFIter.__init__(obj, pb["theta0"], pb["C0"], pb["V0"], pb["mu0"], pb["P0"], pb["Q"], pb["rho"][0] * np.eye(d),
+                           pb["lambda0"], nl, fixed_lambda=pb["fixed_lambda"], backend="numpy")
+        obj._alpha, obj._beta = alpha, beta
+    else:
+        Qs = {k: (1.0 + 0.25 * k) * pb["Q"] for k in range(pb["steps"] + 1)}
+        Rs = {k: pb["rho"][k] * np.eye(d) for k in range(pb["steps"] + 1)}
+        PSMFIter.__init__(obj, pb["theta0"], pb["C0"], pb["V0"], pb["mu0"], pb["P0"], Qs, Rs, nl, backend="numpy")
+    return obj
+
+
+def _run_probe(obj, pb):
+    """The hook sequence of `inner` (psmf.py:90-102) for epoch 1, without pruning; returns everything a step produces."""
+    PSMFIter.step_reset(obj) if not obj.robust else rPSMFIter.step_reset(obj)
+    out = []
+    for k in range(1, pb["steps"] + 1):
+        yk = pb["Y"][k - 1].reshape(-1, 1)
+        mu_bar = obj._predictive_mean(1, k)
+        P_bar = obj._predictive_covariance(1, k)
+        obj._y_pred[k] = obj._predict_measurement(k, mu_bar)
+        eta = obj._compute_eta_k(k, P_bar)
+        Nk = obj._compute_dictionary_innovation(k, eta, mu_bar, P_bar)
+        obj._update_dictionary_mean(k, yk, Nk, mu_bar)
+        obj._update_dictionary_covariance(k, Nk, mu_bar, yk)
+        Sk = obj._compute_inverse_coefficient_innovation(k, mu_bar, P_bar)
+        obj._update_coefficient_mean(k, yk, Sk, mu_bar, P_bar)
+        obj._update_coefficient_covariance(k, Sk, P_bar, yk)
+        obj._store_gradient(1, k, yk, eta)
+        vals = [obj._y_pred[k], obj._C[k], obj._V[k], obj._mu[k], obj._P[k], obj._gradsum, np.asarray(eta), np.asarray(Nk)]
+        if obj.robust:
+            vals += [np.asarray(obj._R[k]), np.asarray(obj._Q[k]), np.asarray(obj._lambda[k])]
+        out.append([np.asarray(v, dtype=float) for v in vals])
+    return out
+
+
+def _agree(a, b, tol):
+    for sa, sb in zip(a, b):
+        for x, y in zip(sa, sb):
+            if x.size != y.size:
+                return False
+            x, y = x.reshape(-1), y.reshape(-1)
+            if not (np.all(np.isfinite(x)) and np.all(np.isfinite(y))):
+                return False
+            if np.max(np.abs(x - y), initial=0.0) > tol * max(1.0, float(np.max(np.abs(y), initial=0.0))):
+                return False
+    return True
+
+
+def recognise_hip_mode(obj, tol=PROBE_TOL):
+    """Name of the `HIP_MODES` entry that the hooks of type(obj) compute, or None.  See the module docstring."""
+    cls, robust = type(obj), bool(obj.robust)
+    pb = _probe_problem(obj._r, robust, bool(getattr(obj, "fixed_lambda", False)))
+    alpha, beta = getattr(obj, "_alpha", 1.0), getattr(obj, "_beta", 1.0)
+    try:
+        mine = _run_probe(_make_probe(cls, robust, pb, alpha, beta), pb)
+    except Exception:
+        return None                       # hooks that cannot run on the probe cannot be recognised
+    for mode in HIP_MODES:
+        ref = _run_probe(_make_probe(mode_class(mode, robust), robust, pb, alpha, beta), pb)
+        if _agree(mine, ref, tol):
+            return mode
+    return None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# nonlinearity probing
+# ---------------------------------------------------------------------------------------------------------------------
+def _candidates(n_params, r):
+    out = []
+    if n_params == 0:
+        out.append(NL.RandomWalk())
+    if n_params == r:
+        out += [NL.CosPhase(r), NL.Sinusoid(r, scaled=False, phased=False)]
+    if n_params == 2 * r:
+        out.append(NL.Sinusoid(r, scaled=False, phased=True))
+    if n_params == r * r:
+        out.append(NL.ScaledWalk(r, bias=False))
+    if n_params == r * r + r:
+        out += [NL.ScaledWalk(r, bias=True), NL.Sinusoid(r, scaled=True, phased=False)]
+    if n_params == r * r + 2 * r:
+        out.append(NL.Sinusoid(r, scaled=True, phased=True))
+    for N in range(1, 5):
+        if n_params == N * (2 * r * r + 4 * r):
+            out.append(NL.FourierBasis(r, N=N))
+    return out
+
+
+def recognise_nonlinearity(fn, n_params, rank, tol=1e-13):
+    """A library nonlinearity (device-evaluated, analytic derivatives) that equals the plain callable `fn` on random
+    (theta, x, t), or None."""
+    if rank is None or rank < 1:
+        return None
+    cands = _candidates(int(n_params), int(rank))
+    if not cands:
+        return None
+    rng = np.random.default_rng(0xF00D + rank)
+    probes = [(rng.random((n_params, 1)), rng.standard_normal((rank, 1)), t) for t in (1, 2, 7, 113, 1000, 4999)]
+    try:
+        vals = [np.asarray(fn(th.copy(), x.copy(), t), dtype=float).reshape(-1) for th, x, t in probes]
+    except Exception:
+        return None
+    if any(v.size != rank or not np.all(np.isfinite(v)) for v in vals):
+        return None
+    for c in cands:
+        ok = True
+        for (th, x, t), v in zip(probes, vals):
+            w = np.asarray(c(th, x, t), dtype=float).reshape(-1)
+            if np.max(np.abs(w - v)) > tol * max(1.0, float(np.max(np.abs(w)))):
+                ok = False
+                break
+        if ok:
+            return c
+    return None

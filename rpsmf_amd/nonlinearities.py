@@ -298,8 +298,18 @@ class _Wrapped(BaseNonLinearity):
         return self._fn(theta, x, t)
 
 
-def wrap_nonlinearity(fn, n_params):
-    """Give a plain callable f(theta, x, t) the derivative interface (complex step)."""
+def wrap_nonlinearity(fn, n_params, rank=None):
+    """Give a plain callable f(theta, x, t) the derivative interface.  With `rank` (the device back end passes it): a
+    callable that equals one of the closed-form families above on random probes is replaced by that family's object -- it is
+    then evaluated inside the device time loop with analytic derivatives (modes.recognise_nonlinearity); any other callable
+    is differentiated by complex step and host-stepped."""
     if isinstance(fn, BaseNonLinearity):
         return fn
+    if rank is not None:
+        from .modes import recognise_nonlinearity
+
+        known = recognise_nonlinearity(fn, n_params, rank)
+        if known is not None:
+            known.recognised_from = fn
+            return known
     return _Wrapped(fn, n_params)

@@ -174,7 +174,8 @@ class PSMFIter:
         self.P0 = P0
         self._d, self._r = C0.shape
         self.nonlinearity = nonlinearity
-        self._nl = wrap_nonlinearity(nonlinearity, np.asarray(theta0).size)
+        # (backend "hip": a plain function that IS one of the closed-form families runs inside the device loop, modes.py)
+        self._nl = wrap_nonlinearity(nonlinearity, np.asarray(theta0).size, rank=self._r if backend == "hip" else None)
         self._C = _StateDict()
         self._P = _StateDict()
         self._V = _StateDict()
@@ -377,14 +378,24 @@ class PSMFIter:
     def _check_hip_configuration(self):
         over = self._overridden_hooks()
         declared = any("hip_mode" in vars(c) for c in type(self).__mro__ if c not in _BASE_CLASSES)
+        recognised = False
         if over and not declared:
-            raise TypeError(
-                f"{type(self).__name__} overrides {over}: the device back end can only fuse recognised hook "
-                f"configurations.  Declare the class attribute hip_mode (one of {sorted(HIP_MODES)}) if the overrides "
-                "match one, or construct with backend='numpy'.")
+            # an experiment subclass written against the reference (synthetic_psmf.py:78-100): find out WHAT its hooks compute
+            # by running them on a small probe problem next to the library's statement of every device mode (modes.py)
+            from .modes import recognise_hip_mode
+
+            mode = recognise_hip_mode(self)
+            if mode is None:
+                raise TypeError(
+                    f"{type(self).__name__} overrides {over}: the device back end can only fuse recognised hook "
+                    f"configurations, and on a probe problem these hooks match none of {sorted(HIP_MODES)}.  Declare the class "
+                    "attribute hip_mode if they are meant to, or construct with backend='numpy' (which executes the hooks).")
+            self.hip_mode = mode
+            recognised = True
+        self.hip_mode_recognised = recognised
         if self.hip_mode not in HIP_MODES:
             raise ValueError(f"unknown hip_mode {self.hip_mode!r}")
-        extra = sorted(set(over) - HIP_MODE_HOOKS[self.hip_mode])
+        extra = [] if recognised else sorted(set(over) - HIP_MODE_HOOKS[self.hip_mode])
         if extra:
             raise TypeError(
                 f"{type(self).__name__} declares hip_mode={self.hip_mode!r} but also overrides {extra}, which that mode "

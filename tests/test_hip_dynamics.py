@@ -248,13 +248,16 @@ def test_recursive_sinusoid_vs_oracle():
 
 
 @pytest.mark.parametrize("engine", ["block", "step"])
-def test_per_step_R_and_Q_schedules(engine):
+@pytest.mark.parametrize("r,iso", [(12, False), (12, True), (20, True), (32, True)])
+def test_per_step_R_and_Q_schedules(engine, r, iso):
     """PSMFIter reads R[k], Q[k] of the step (psmf.py:115,123,141): R_k = rho_k I, Q_k = q_k Q as device schedules, through
-    the class surface, against the oracle with the same dictionaries."""
-    d, r, T = 700, 12, 75
+    the class surface, against the oracle with the same dictionaries.  iso: Q = q I, the usual case -- where the blocked
+    engine would otherwise pick the two-inversion kernels (filter3 / filter3s / filter2), which read rho and q once per
+    block; with schedules the library must select the general kernel."""
+    d, T = 700, 75
     Y, C0 = _problem(d, r, T, 21)
     rng = np.random.default_rng(8)
-    Q0 = 0.1 * np.eye(r) + 0.01 * np.ones((r, r))
+    Q0 = 0.1 * np.eye(r) + (0.0 if iso else 0.01) * np.ones((r, r))
     rho_k = 0.5 + rng.random(T + 1)
     q_k = 0.5 + rng.random(T + 1)
     q_k[1] = 1.0

@@ -241,8 +241,10 @@ def test_hip_backend_refuses_unrecognised_overrides_and_callables():
     args = (np.zeros((0, 1)), np.zeros((4, 2)), np.eye(2), np.zeros((2, 1)), np.eye(2), {0: np.eye(2)}, {0: 1.0})
     with pytest.raises(TypeError):
         Custom(*args, psmf.RandomWalk())                 # overrides without a declared hip_mode
-    f = psmf.PSMFIter(*args, lambda th, x, t: x)         # arbitrary callable: accepted, f is evaluated on the host, one device step
+    f = psmf.PSMFIter(*args, lambda th, x, t: np.tanh(x))    # arbitrary callable: accepted, f is evaluated on the host, one device step
     assert f._host_stepped()                             # at a time (psmf_step_host) -- the d-sized work stays on the device
+    f = psmf.PSMFIter(*args, lambda th, x, t: x)         # ... unless it IS one of the closed-form families (probed, modes.py)
+    assert not f._host_stepped() and isinstance(f._nl, psmf.RandomWalk)
     Custom(*args, psmf.RandomWalk(), backend="numpy")    # fine on the host
 
     class Declared(Custom):
