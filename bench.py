@@ -71,6 +71,10 @@ def parse():
                     help="N > 1: RCCL all-reduce on the device streams (default), or the host-mediated communicator over gloo "
                          "(psmf_comm_init_host) -- the transport for rehearsing the N > 1 path with all ranks on ONE GPU")
     ap.add_argument("--one-device", action="store_true", help="every rank uses HIP device 0 (rehearsal on a one-GPU box; needs --comm gloo)")
+    ap.add_argument("--scaling", default="strong", choices=["strong", "weak"],
+                    help="N > 1: strong = BASELINE config E as stated, the d rows sharded over the ranks (default); weak = every rank holds "
+                         "--rows rows, d = N x rows (what more GPUs buy here: rows at the same timesteps/s, DESIGN section 6)")
+    ap.add_argument("--pid-dir", default=None, help="write rank<r>.pid / rank<r>.timed marker files there (fault-injection tests)")
     return ap.parse_args()
 
 
@@ -275,6 +279,11 @@ def main():
     from rpsmf_amd.sharding import shard_rows
 
     d, r, T = args.d, args.r, args.T
+    if args.scaling == "weak":
+        d = args.d * world              # per-GPU work fixed: every rank holds args.d rows of a filter with N x as many
+    if args.pid_dir:
+        with open(os.path.join(args.pid_dir, f"rank{rank}.pid"), "w") as fp:
+            fp.write(str(os.getpid()))
     row0, d_local = shard_rows(d, world, rank)
     seed = 35833 if args.robust else 35853  # Makefile:55,64 of the reference
     series = Series(d, r, T, seed, row0, d_local, bool(args.robust))
@@ -305,6 +314,11 @@ def main():
         t = torch.from_numpy(uid)
         dist.broadcast(t, 0)
         f.comm_init(world, rank, t.numpy().tobytes())
+
+    elif os.environ.get("PSMF_FORCE_COLLECTIVE"):
+        # N = 1 with the RCCL calls of the sharded engine in the loop (a 1-rank communicator: the all-reduce kernels really sit on
+        # the bulk stream) -- what every rank of an N > 1 run does besides waiting for its peers
+        f.comm_init(1, 0, _capi.DeviceFilter.comm_unique_id())
 
     for a, Yc in series.chunks():
         f.upload_series(Yc, t0=a, T_total=T)
@@ -382,6 +396,8 @@ def main():
         f.counters(reset=True)
         f.filter_kernel_time(reset=True)
     barrier()
+    if args.pid_dir:
+        open(os.path.join(args.pid_dir, f"rank{rank}.timed"), "w").close()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         f.run(0, T, sync=False)
@@ -407,22 +423,27 @@ def main():
         t_apply = f.time_kernel(2, 50)
         t_block_insitu = insitu["filter_us_mean"] if insitu and insitu["filter_launches"] > 0 else t_filter
         if chained[0] > 0:
-            kernel, kernel_us, steps_per_launch = "psmf_blk_filter3", 1e3 * chained[1] / chained[0], float(T)
-            kernel_us = min(kernel_us, 1e6 * elapsed / args.steps)   # a kernel cannot take longer than the wall time of its pass (two clocks: HIP events vs host)
+            # HIP events around every chained launch of the timed region, on the stream it runs on: reported as measured (the host
+            # wall time of a pass is beside it as ms_per_step; the two clocks differ by ~0.2 %)
+            kernel, kernel_us, steps_per_launch = geo.get("filter_kernel", "psmf_blk_filter3"), 1e3 * chained[1] / chained[0], float(T)
         else:
             full_blocks_only = (T % B == 0)
-            kernel, kernel_us = "psmf_blk_filter3", t_block_insitu
+            kernel, kernel_us = geo.get("filter_kernel", "psmf_blk_filter3"), t_block_insitu
             steps_per_launch = B if full_blocks_only else T / (insitu["filter_launches"] / args.steps)
         zbytes = es * d_local * 64
         nb1 = min(B, 64)
         xg_bytes = es * d_local * (r + B + nb1)          # cross-Gram reads C, the current and the next series block
         ap_bytes = 2.0 * es * d_local * (r + B)          # apply reads C, Y_cur and writes C, Y_hat
-        pmc = load_pmc("r2_pmc_traffic_block_engine.json") or load_pmc("r1_pmc_traffic_block_engine.json")
+        pmc_name = next((n for n in ("r3_pmc_traffic_block_engine.json", "r2_pmc_traffic_block_engine.json", "r1_pmc_traffic_block_engine.json")
+                         if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
+        pmc = load_pmc(pmc_name) if pmc_name else None
         real_hbm = None
+        traffic_source = None
         if (d, r, args.storage, world) == (100_000, 32, "f32", 1) and pmc:
             # rocprofv3 --pmc passes of this workload (counter collection serialises the kernels; the library then runs
             # one filter launch per block): bytes per block of B timesteps, scaled to the blocks one launch advances
             traffic = pmc["traffic_bytes_per_launch"] * (steps_per_launch / B)
+            traffic_source = f"profiles/{pmc_name} (rocprofv3 --pmc passes of this workload, committed; NOT measured in this run)"
             if "all_kernels_bytes_per_block" in pmc:
                 real_hbm = pmc["all_kernels_bytes_per_block"] * (T / B) / (elapsed / args.steps) / 1e9
         steps_timed = max(1, (insitu["ns_steps"] + insitu["sweep_steps"])) if insitu else 1
@@ -434,6 +455,12 @@ def main():
                  "one_block_us_hip_events_standalone": t_filter,
                  "gap_between_blocks_us": insitu["filter_gap_us_mean"] if insitu else None,
                  "real_hbm_GBps": real_hbm,
+                 "traffic_source": traffic_source,
+                 # the blocked formulation's own minimum per block of B timesteps: cross-Gram reads C, Y_cur, Y_next; apply reads
+                 # C, Y_cur and writes C, Y_hat (f32) -- against what the counters say the kernels of a block move
+                 "blocked_min_bytes_per_block": xg_bytes + ap_bytes,
+                 "blocked_traffic_over_min": (pmc["all_kernels_bytes_per_block"] / (xg_bytes + ap_bytes))
+                                             if (traffic_source and pmc and "all_kernels_bytes_per_block" in pmc) else None,
                  "filter_chain_frac": (iters_per_step * NS_ITER_ISSUE_US / step_us) if iters_per_step else None,
                  "filter_chain": {"newton_schulz_iterations_per_timestep": iters_per_step, "mfma_issue_us_per_iteration": NS_ITER_ISSUE_US,
                                   "us_per_timestep_in_kernel": step_us,
@@ -443,10 +470,11 @@ def main():
                                                               "frac_of_hbm_peak": xg_bytes / (t_gram * 1e-6) / 1e9 / HBM_PEAK_GBS},
                                   "psmf_blk_apply2": {"bytes": ap_bytes, "us": t_apply, "GBps": ap_bytes / (t_apply * 1e-6) / 1e9,
                                                       "frac_of_hbm_peak": ap_bytes / (t_apply * 1e-6) / 1e9 / HBM_PEAK_GBS}},
-                 "note": "frac = SURVEY 8(d) bookkeeping: step-at-a-time algorithmic bytes of the timesteps one launch advances / its duration / 8 TB/s. "
-                         "The blocked engine does not move those bytes (traffic, real_hbm_GBps): the filter kernel is a latency-bound chain of r x r stages "
-                         "(one workgroup, f64-MFMA Newton-Schulz) -- its distance to its own limit is filter_chain_frac; the kernels that stream the data "
-                         "are under bulk_kernels"}
+                 "note": "filter_chain_frac is the distance of the timed kernel to ITS bound: matrix-core issue time of the Newton-Schulz products of a "
+                         "timestep / measured time per timestep inside the filter kernel (one workgroup, a chain of r x r stages bound by its "
+                         "instruction stream on one CU).  frac = SURVEY 8(d) bookkeeping: step-at-a-time algorithmic bytes of the timesteps one "
+                         "launch advances / its duration / 8 TB/s -- the blocked engine does not move those bytes (traffic, real_hbm_GBps, "
+                         "blocked_min_bytes_per_block); the kernels that do stream the data are under bulk_kernels"}
     else:
         kernel, kernel_us, steps_per_launch = "psmf_sweep_solve", f.time_kernel(0, 300), 1
         extra = {"steps_per_launch": 1, "kernels_us": {"psmf_sweep_solve": kernel_us, "psmf_serial": f.time_kernel(1, 300)}}
@@ -467,15 +495,16 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",      # the arithmetic type: float64 accumulation of every d -> r contraction and float64 r x r state
             "storage_dtype": args.storage,   # C, y, y_hat in HBM (f32: one rounding of C per block)
             "data": "synthetic",
             "config": {"workload": f"{'rPSMF' if args.robust else 'PSMF'} full filter, random-walk dynamics, d={d} r={r} "
-                                   f"T={T} synthetic Gaussian series, rows sharded over {world} GPU(s)",
-                       "d": d, "r": r, "T": T, "timesteps_per_pass": T, "store_y_pred": not args.no_y_pred,
-                       "exchange": None if world == 1 else ("RCCL all-reduce on the bulk stream" if args.comm == "rccl" else "host-mediated all-reduce over gloo (rehearsal transport)"),
+                                   f"T={T} synthetic Gaussian series, rows sharded over {world} GPU(s)"
+                                   + (f" ({args.d} rows per GPU: weak scaling, d = N x {args.d})" if args.scaling == "weak" else ""),
+                       "d": d, "d_per_gpu": d_local, "r": r, "T": T, "timesteps_per_pass": T, "store_y_pred": not args.no_y_pred,
+                       "exchange": ("RCCL all-reduce on the bulk stream, 1-rank communicator (PSMF_FORCE_COLLECTIVE)" if os.environ.get("PSMF_FORCE_COLLECTIVE") else None) if world == 1 else ("RCCL all-reduce on the bulk stream" if args.comm == "rccl" else "host-mediated all-reduce over gloo (rehearsal transport)"),
                        "us_per_timestep": 1e6 * elapsed / (args.steps * T), "engine": geo["engine"], "geometry": geo},
             "cold_pass_steps_per_s": T / cold_elapsed,
             "cold_pass_runs_steps_per_s": [T / c for c in cold_runs],

@@ -34,3 +34,82 @@ def test_bench_two_ranks_one_gpu(engine, d, r):
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0 and out["config"]["engine"] == engine
     par = out["parity_vs_cpu_oracle"]
     assert par["ranks"] == 2 and max(par["C"], par["V"], par["mu"], par["P"]) < 1e-5, par
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_bench_weak_scaling_two_ranks_one_gpu():
+    """`--scaling weak`: every rank holds --rows rows, the filter has N x as many; the line says so."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rows", "4000",
+           "--latent-rank", "32", "--timesteps", "400", "--cpu-steps", "150", "--no-extras", "--comm", "gloo", "--one-device", "--scaling", "weak"]
+    pr = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=dict(os.environ, OMP_NUM_THREADS="4"), cwd=ROOT)
+    assert pr.returncode == 0, pr.stdout[-2000:] + pr.stderr[-3000:]
+    out = json.loads([ln for ln in pr.stdout.splitlines() if ln.startswith("{")][0])
+    assert out["scaling"] == "weak" and out["n_gpus"] == 2
+    assert out["config"]["d"] == 8000 and out["config"]["d_per_gpu"] == 4000 and "weak scaling" in out["config"]["workload"]
+    par = out["parity_vs_cpu_oracle"]
+    assert par["ranks"] == 2 and max(par["C"], par["V"], par["mu"], par["P"]) < 1e-5, par
+
+
+def test_forced_collective_single_rank_bench_costs_nothing():
+    """PSMF_FORCE_COLLECTIVE=1: bench.py at N = 1 with the RCCL all-reduce kernels of the sharded blocked engine really enqueued
+    on the bulk stream (1-rank communicator) -- what each rank of an N > 1 run does besides waiting for its peers.  The exchange
+    is one block ahead of its use and off the critical path: throughput within 3 % of the plain run."""
+    vals = {}
+    for forced in (False, True, False, True):          # interleaved: box drift hits both alike; best of two each
+        env = dict(os.environ, OMP_NUM_THREADS="4")
+        env.pop("PSMF_FORCE_COLLECTIVE", None)
+        if forced:
+            env["PSMF_FORCE_COLLECTIVE"] = "1"
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "8", "--warmup", "2", "--timesteps", "3200", "--cpu-steps", "0", "--no-extras"]
+        pr = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=env, cwd=ROOT)
+        assert pr.returncode == 0, pr.stdout[-2000:] + pr.stderr[-3000:]
+        out = json.loads([ln for ln in pr.stdout.splitlines() if ln.startswith("{")][0])
+        assert (out["config"]["exchange"] is not None) == forced
+        vals[forced] = max(vals.get(forced, 0.0), out["value"])
+    assert vals[True] > 0.97 * vals[False], vals
+    print("timesteps/s plain vs forced collective:", vals)
+
+
+def test_survivor_exits_when_its_peer_is_killed(tmp_path):
+    """Fault injection on the N > 1 path: two ranks (fresh child processes, gloo host communicator, one GPU), rank 1 is killed
+    inside the timed region; rank 0 must notice at its next exchange and exit non-zero -- within the 20 s bound that every wait
+    of the sharded engines has -- instead of hanging in a collective or a device-side wait."""
+    import signal
+    import time
+
+    port = _free_port()
+    procs = []
+    for rank in (0, 1):
+        env = dict(os.environ, OMP_NUM_THREADS="2", RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "100000", "--warmup", "1", "--rows", "8000",
+               "--latent-rank", "32", "--timesteps", "640", "--cpu-steps", "0", "--no-extras", "--comm", "gloo", "--one-device",
+               "--pid-dir", str(tmp_path)]
+        procs.append(subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env, cwd=ROOT))
+    try:
+        t0 = time.time()
+        while not all(os.path.exists(tmp_path / f"rank{q}.timed") for q in (0, 1)):
+            assert time.time() - t0 < 200, "ranks did not reach the timed region"
+            assert all(p.poll() is None for p in procs), [p.stderr.read()[-2000:] for p in procs if p.poll() is not None]
+            time.sleep(0.2)
+        time.sleep(1.0)                                   # well inside the timed loop (it would run for hours)
+        procs[1].send_signal(signal.SIGKILL)              # the exact PID this test started
+        t_kill = time.time()
+        rc0 = procs[0].wait(timeout=25)
+        waited = time.time() - t_kill
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        for p in procs:
+            p.wait(timeout=30)
+    err0 = procs[0].stderr.read()
+    assert rc0 not in (0, None), err0[-1500:]
+    assert waited < 20.0, waited
+    assert "all-reduce" in err0 or "allreduce" in err0.lower() or "Connection" in err0, err0[-1500:]

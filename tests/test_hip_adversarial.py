@@ -1,0 +1,67 @@
+"""Adversarial series against the carried Newton-Schulz starts of the blocked engine (psmf_blk_filter3): an abrupt level
+shift, blocks of 1000-sigma outliers, a process noise of 1e-8, a nearly singular P0 (tests/adversarial_cases.py) -- device
+(f32 storage, the engine the library selects) against the CPU oracle at checkpoints around the event and at the end, 1e-5
+(north_star), plus what the inversion counters (psmf_counters) say happened: where the previous step's inverse is useless as
+a start the direct symmetric sweep must take over, and the result must not care.  GPU only: `pytest -m gpu`.
+Reference: pypsmf/psmf/psmf.py:85-102,140-165 (np.linalg.inv every step, no carried state to go stale)."""
+
+import numpy as np
+import pytest
+
+from adversarial_cases import CASES, make_case
+from conftest import relerr
+from oracle import psmf_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+D, T = 20_000, 1000
+
+
+@pytest.mark.parametrize("r,robust", [(32, False), (20, True)], ids=["PSMF_r32", "rPSMF_r20"])
+@pytest.mark.parametrize("name", CASES)
+def test_adversarial_series_vs_oracle(name, r, robust):
+    from rpsmf_amd import _capi
+
+    cs = make_case(name, D, r, T, robust)
+    st = O.State(C=cs["C0"].copy(), V=cs["V0"], mu=np.zeros(r), P=cs["P0"], Q=cs["Q"], rho=1.0, lam=1.8)
+    st, Yp, trace = O.run_epoch(st, cs["Y"].astype(np.float64), O.Mode(robust=robust), O.RandomWalkDyn(), keep=cs["checkpoints"],
+                                want_grad=False)
+    f = _capi.DeviceFilter(D, r, robust=robust, storage="f32")
+    assert f.geometry()["engine"] == "block"
+    f.upload_series(cs["Y"])
+    f.set_state(cs["C0"], cs["V0"], cs["P0"], cs["Q"], np.zeros(r), rho=1.0, lambda0=1.8)
+    k_prev, counters, worst = 0, {}, 0.0
+    for k in cs["checkpoints"]:
+        f.counters(reset=True)
+        f.run(k_prev, k)
+        s = f.get_state()
+        counters[k] = f.counters()
+        ref = trace[k][0]
+        for n in ("C", "V", "mu", "P"):
+            e = relerr(s[n], getattr(ref, n))
+            worst = max(worst, e)
+            assert e < TOL, (name, n, k, e)
+        if robust:
+            assert relerr(s["rho"], ref.rho) < TOL and relerr(s["Q"], ref.Q) < TOL
+        k_prev = k
+    e = relerr(f.y_pred(0, T), Yp)
+    f.close()
+    assert e < TOL, (name, "y_pred", e)
+    # every timestep was inverted one way or the other, and the counters add up
+    for a, k in zip((0,) + cs["checkpoints"][:-1], cs["checkpoints"]):
+        c = counters[k]
+        assert c["ns_steps"] + c["sweep_steps"] == k - a, (k, c)
+    ev = cs["event"]
+    after = counters[ev + 40] if (ev + 40) in counters else None
+    if name in ("outlier_block", "outliers_then_quiet"):
+        # 1000-sigma innovations move kappa and G by orders of magnitude from one step to the next: the carried start is useless,
+        # the iteration is given up (ns_failed) and the direct sweep inverts those steps
+        assert after["ns_failed"] >= 1 and after["sweep_steps"] >= 1, after
+    if name == "tiny_Q":
+        # W = (M / beta + I / q)^-1 with 1 / q = 1e8: the early steps cannot be started from anything
+        assert counters[cs["checkpoints"][0]]["sweep_steps"] >= 1
+    tail = counters[T]
+    assert tail["sweep_steps"] <= 0.2 * (T - cs["checkpoints"][-2]), tail        # ... and the filter goes back to iterating
+    print(name, "rPSMF" if robust else "PSMF", f"worst rel-err {worst:.1e}, y_pred {e:.1e}",
+          {k: (c["ns_steps"], c["sweep_steps"], c["ns_iterations"], c["ns_failed"]) for k, c in counters.items()})

@@ -10,7 +10,7 @@ series cannot show either.  Tolerance: BASELINE.json north_star, 1e-5 relative (
 import numpy as np
 import pytest
 
-from conftest import relerr
+from conftest import load_golden as load_golden_fixture, relerr
 from oracle import psmf_oracle as O
 from oracle.impute_oracle import impute_filter
 
@@ -80,6 +80,67 @@ def test_config_E_single_gpu_shard_size():
     worst, geo = _checkpointed_parity(100_000, 32, 1_000, False, (300, 1000))
     assert geo["engine"] == "block" and geo["block_steps"] == 32
     print("config E (1 GPU) worst rel-err:", worst)
+
+
+@pytest.mark.parametrize("which", ["psmf", "rpsmf"])
+def test_config_E_full_horizon_two_epochs_vs_oracle_fixture(which):
+    """BASELINE config E over its WHOLE horizon and into a second, carried-state epoch -- what bench.py's headline number is
+    quoted on: d = 100 000, r = 32, T = 10 000, bench.py's own series and initial state, PSMF and rPSMF.  The oracle's answers
+    were computed once in the build container (tests/golden/make_golden_fullsize.py, ~15 min of CPU per variant) and are stored
+    as r-sized state + fixed sketches of the d-sized quantities at k = 300 ... 20 000; y_hat of four series is compared at
+    EVERY timestep of both epochs.  Tolerance 1e-5 (north_star), f32 storage, the engine the library selects."""
+    import bench
+    from golden.make_golden_fullsize import sketch_matrix
+
+    g = load_golden_fixture(f"fullsize_E_{which}")
+    d, r, T, robust = int(g["d"]), int(g["r"]), int(g["T"]), bool(g["robust"])
+    c = _capi()
+    series = bench.Series(d, r, T, int(g["seed"]), 0, d, robust)
+    st0 = bench.init_state(d, r, int(g["seed"]))
+    f = c.DeviceFilter(d, r, robust=robust, storage="f32")
+    for a, Yc in series.chunks(chunk=1000):
+        f.upload_series(Yc, t0=a, T_total=T)
+    f.set_state(st0["C"], st0["V"], st0["P"], st0["Q"], st0["mu"], rho=st0["rho"], lambda0=st0["lam"])
+    S, rows, track = sketch_matrix(d), g["rows"], g["track"]
+    worst = {}
+
+    def check(name, got, ref, k, tol=TOL):
+        e = relerr(got, ref)
+        worst[name] = max(worst.get(name, 0.0), e)
+        assert e < tol, (which, name, k, e)
+
+    epochs = int(g["epochs"])
+    cps = [int(k) for k in g["checkpoints"]]
+    for ep in range(epochs):
+        if ep > 0 and robust:          # epoch start (rpsmf.py:106-114): Q, R, lambda back to their initial values; C, V, mu, P carried
+            f.set_state(Q=st0["Q"], rho=st0["rho"], lambda0=st0["lam"])
+        k_prev = 0
+        for kg in [c_ for c_ in cps if ep * T < c_ <= (ep + 1) * T]:
+            k = kg - ep * T
+            f.run(k_prev, k)
+            k_prev = k
+            s = f.get_state()
+            p = f"k{kg}_"
+            for name in ("V", "P", "mu"):
+                check(name, s[name], g[p + name], kg)
+            check("StC", S.T @ s["C"], g[p + "StC"], kg)
+            check("Crows", s["C"][rows], g[p + "Crows"], kg)
+            check("yhat_rows", f.y_pred(k - 1, 1)[0][rows], g[p + "yhat_rows"], kg)
+            check("eta", s["eta"], g[p + "eta"], kg)
+            check("N", s["N"], g[p + "N"], kg)
+            if robust:
+                check("rho", s["rho"], g[p + "rho"], kg)
+                check("q", s["Q"][0, 0], g[p + "q"], kg)
+                assert relerr(s["lam"], g[p + "lam"]) < 1e-12
+        if k_prev < T:
+            f.run(k_prev, T)
+        yt = np.concatenate([f.y_pred(a, 1000, dtype=np.float32)[:, track] for a in range(0, T, 1000)])
+        check("yhat_track", yt, g["yhat_track"][ep * T:(ep + 1) * T], (ep + 1) * T)
+    geo = f.geometry()
+    cnt = f.counters()
+    f.close()
+    assert geo["engine"] == "block" and geo["block_steps"] == 32
+    print(f"config E {which}, two epochs of {T}: worst rel-err", {k: f"{v:.2e}" for k, v in worst.items()}, "counters", cnt)
 
 
 def test_per_step_engine_tolerance_r40():
