@@ -1,9 +1,17 @@
 """Row sharding of the d x r dictionary over GPUs (one process per GPU).
 
-The filter shards naturally along the rows of C and y_k: each rank sweeps its own rows, the
-ranks exchange the r+1 partial sums (h = C^T e, ee = e^T e) once per timestep with one
-RCCL all-reduce, and every rank repeats the identical r x r float64 arithmetic, so the
-replicated state stays bit-identical across ranks.
+The filter shards along the rows of C, y_k and y_hat_k; every r-sized quantity is replicated and every rank repeats the
+identical float64 r x r / coefficient-space arithmetic on all-reduced inputs, so the replicated state stays bit-identical
+across ranks.  What is exchanged depends on the engine:
+
+* blocked engine (default, r <= 32): ONE sum-all-reduce per block of min(64 - r, 48) timesteps -- the 128 x 64 float64
+  cross-Gram [Z | Y_next]^T Y_next (64 KB), on the bulk stream, one block ahead of its use, i.e. off the critical path --
+  plus the 64 x 64 Gram of the first block of a run;
+* per-step engine (r > 32, host-stepped dynamics, non-uniform R): the r + 1 partial sums (h = C^T e, ee = e^T e) once per
+  timestep, between the local reduction kernel and the serial stage.
+
+Transport: RCCL on the library's streams (`DeviceFilter.comm_init`), or any host transport through the host-mediated
+communicator (`comm_init_host`: gloo in bench.py's one-GPU rehearsal, MPI, ...).
 """
 
 import numpy as np
