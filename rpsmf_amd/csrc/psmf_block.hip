@@ -555,10 +555,12 @@ __global__ __launch_bounds__(WG) void psmf_blk_filter(BlockParams b) {
   __syncthreads();
 
   double s_last = 0.0, eta_last = 0.0, N_last = 0.0, phi = 1.0, omega = 1.0, ee_last = 0.0;
+  BLK_T0();
   for (int jb = 0; jb < b.nb; ++jb) {
     const long long kstep = b.k0 + jb + 1;   // 1-based step index
     // ---- S1: mu_bar = f(theta, mu, k), F = df/dx (psmf.py:104-115; psmf_dyn.hip) ----
     dyn_forward<WG>(p, (double)kstep, s_mu, s_mub, s_f, sF, RS, s_val, s_tp, tid);     // ends with a barrier
+    BLK_T(0);
     // PSMFIter reads Q[k], R[k] of the step (psmf.py:115,123,141): scalar schedules (never with rPSMF's running Q, R)
     const double qs = p.q_sched ? p.q_sched[kstep - p.series_t0] : 1.0;
     if (p.rho_sched) rho = p.rho_sched[kstep - p.series_t0];
@@ -617,6 +619,7 @@ __global__ __launch_bounds__(WG) void psmf_blk_filter(BlockParams b) {
     const double N = s + eta;
     const double invN = fast_rcp(N);
     const double kappa = fast_rcp(rho + s);
+    BLK_T(1);
     // ---- S3: P+ = (Pbar^-1 + kappa G)^-1 ----
     double Pp[M];
     if (p.coef_update) {
@@ -633,6 +636,7 @@ __global__ __launch_bounds__(WG) void psmf_blk_filter(BlockParams b) {
 #pragma unroll
       for (int m = 0; m < M; ++m) Pp[m] = Pb[m];
     }
+    BLK_T(2);
     // ---- S4: coefficient space: b = A mu_bar, Ka = K[:, r+jb] - KA mu_bar, a = u - b ----
     {
       const int mrow = tid & (RB - 1), qtr = tid >> 6;        // 4 quarter-row partial dots per row
@@ -658,6 +662,7 @@ __global__ __launch_bounds__(WG) void psmf_blk_filter(BlockParams b) {
       b.Bcoef[(size_t)jb * RB + tid] = bm;
     }
     __syncthreads();
+    BLK_T(3);
     // ---- h = A^T Ka (8 row groups x RPAD columns), ee = a . Ka ----
     {
       double ph = 0.0;
@@ -668,6 +673,7 @@ __global__ __launch_bounds__(WG) void psmf_blk_filter(BlockParams b) {
     }
     double ee = (tid < RB) ? s_a[tid] * s_Ka[tid] : 0.0;
     ee = block_sum(ee, s4);
+    BLK_T(4);
     // ---- S5: mu = mu_bar + kappa P+ h, quad ----
     double quad = kappa * ee;
     double mu_new = 0.0;
@@ -684,6 +690,7 @@ __global__ __launch_bounds__(WG) void psmf_blk_filter(BlockParams b) {
     } else {
       if (tid < r) mu_new = s_mub[tid];
     }
+    BLK_T(5);
     // theta gradient at the pre-update state: g_f = d(incremental likelihood)/df (psmf.py:57-64, rpsmf.py:62-71),
     // then gradsum += J_theta^T g_f
     if (p.n_theta > 0) {
@@ -701,6 +708,7 @@ __global__ __launch_bounds__(WG) void psmf_blk_filter(BlockParams b) {
       __syncthreads();
       dyn_backward<WG>(p, (double)kstep, s_mu, s_gf, s_val, s_tp, s_u, tid);        // ends with a barrier
     }
+    BLK_T(6);
     double vscale = 1.0, pscale = 1.0, qscale = 1.0;
     phi = 1.0; omega = 1.0;
     if (p.robust) {
@@ -740,9 +748,12 @@ __global__ __launch_bounds__(WG) void psmf_blk_filter(BlockParams b) {
     }
     s_last = s; eta_last = eta; N_last = N; ee_last = ee;
     __syncthreads();
+    BLK_T(7);
     // PSMFRecursive: optimiser step on theta every update_every observations (psmf.py:299-304)
     if (p.recursive && p.n_theta > 0 && (kstep % p.update_every) == 0) dyn_adam_step<WG>(p, kstep, tid);
+    BLK_T(8);
   }
+  BLK_TOUT();
 
   // ---- block end: coefficients and state back to memory ----
   for (int idx = tid; idx < RB * r; idx += WG) { const int m = idx / r; b.Acoef[idx] = sA[m * RS + (idx - m * r)]; }
