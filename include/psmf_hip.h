@@ -192,6 +192,11 @@ int psmf_time_kernel(psmf_handle h, int which, int iters, float* avg_us);
  * out[2] = padded row length (elements), out[3] = lanes per row, out[4] = graph chunk steps,
  * out[5] = engine in use (1 per-step, 2 blocked), out[6] = steps per block (blocked engine) */
 int psmf_geometry(psmf_handle h, int32_t* out7);
+/* Which kernel advances the r x r / coefficient-space state with the handle's present configuration (mode flags, dynamics, the Q
+ * last uploaded, schedules, switches): 0 = per-step engine (psmf_sweep_solve + psmf_serial), 1 = psmf_blk_filter (general blocked
+ * kernel), 2 = psmf_blk_filter2, 3 = psmf_blk_filter3, 4 = psmf_blk_filter3s, 5 = psmf_blk_filter4, 6 = psmf_blk_filter4s.
+ * (New: diagnostics for tests and bench.py -- the reference has one code path, pypsmf/psmf/psmf.py:90-102.) */
+int psmf_filter_kernel(psmf_handle h);
 /* diagnostics of the blocked engine's r x r inversions since the last reset: out[0] = timesteps inverted by
  * Newton-Schulz refinement, out[1] = by the direct symmetric sweep, out[2] = Newton-Schulz iterations in
  * total, out[3] = failed Newton-Schulz attempts, out[4] / out[5] = summed in-kernel durations / gaps between

@@ -72,6 +72,7 @@ SIGNATURES = {
     "psmf_time_kernel": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "psmf_geometry": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "psmf_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
+    "psmf_filter_kernel": (C.c_int, [C.c_void_p]),
     "psmf_filter_kernel_time": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_int]),
     "psmf_measure_copy_bandwidth": (C.c_int, [C.c_int, C.c_size_t, C.c_int, _dp]),
     "psmf_impute_run": (C.c_int, [C.POINTER(PsmfImputeConfig), _dp, _u8p, _u8p, _dp, _dp, _dp, _dp, _dp,
@@ -301,8 +302,10 @@ class DeviceFilter:
     def geometry(self):
         g = (C.c_int32 * 7)()
         self._check(self._lib.psmf_geometry(self._h, g))
+        kern = {0: "psmf_sweep_solve", 1: "psmf_blk_filter", 2: "psmf_blk_filter2", 3: "psmf_blk_filter3", 4: "psmf_blk_filter3s",
+                5: "psmf_blk_filter4", 6: "psmf_blk_filter4s"}.get(self._lib.psmf_filter_kernel(self._h), "?")
         return dict(n_sweep_wg=g[0], rows_per_wg=g[1], row_stride=g[2], lanes_per_row=g[3], graph_chunk=g[4],
-                    engine={1: "step", 2: "block"}.get(g[5], g[5]), block_steps=g[6])
+                    engine={1: "step", 2: "block"}.get(g[5], g[5]), block_steps=g[6], filter_kernel=kern)
 
     def counters(self, reset=False):
         c = (C.c_int64 * 8)()

@@ -965,9 +965,12 @@ __device__ __forceinline__ void f3_v_program(const BlockParams& b, const F3Blk& 
 #undef F3_V0_FINISH_PREV
 }
 
+#include "psmf_blk4.hip"      // filter4: the same skeleton for diagonal-Jacobian dynamics (sequential inversions); uses everything above
+
 // SMALL = true: the r <= 16 instantiation, a kernel of its own -- compiled into the same kernel as the two r > 16 programs it
 // cost the r = 32 path 2 % (register allocation over the larger kernel: 111 spilled registers against 96; measured A / B on one box)
-template <bool SMALL>
+// KIND 0: filter3 (random walk, two parallel inversions); KIND 1: filter4 (psmf_blk4.hip)
+template <bool SMALL, int KIND = 0>
 __device__ __forceinline__ void blk_filter3_body(const BlockParams& b0) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* sm = reinterpret_cast<double*>(smem_raw);
@@ -1008,6 +1011,9 @@ __device__ __forceinline__ void blk_filter3_body(const BlockParams& b0) {
   L.s32 = hotS;
   __shared__ long long s_tick[2];
   L.tick = s_tick;
+  __shared__ __attribute__((aligned(16))) double hot4[KIND == 1 ? 5 * RM + 2 * 48 + F4_NKC : 2];
+  F4Lds D;
+  D.fd = hot4; D.mu = D.fd + RM; D.tp = D.mu + RM; D.th = D.tp + RM; D.rs = D.th + 2 * RM; D.qs = D.rs + 48; D.kc = D.qs + 48;
 
   // ---- one launch = `chain` consecutive blocks (1 when the blocks are launched one by one) ----
   // Chained, the blocks of a run pay the kernel launch, the cold instruction cache and the hand-off round trips once
@@ -1067,12 +1073,33 @@ __device__ __forceinline__ void blk_filter3_body(const BlockParams& b0) {
     f3_assemble_K(b, k, L, r, tid);
   }
   if (tid == 0) *L.errflag = 0;
-  if (tid < RM) { L.mub[tid] = (tid < r) ? st->mu[tid] : 0.0; L.w[tid] = 0.0; L.h[tid] = 0.0; }
-  if (tid < F3_NSC) L.sc[tid] = 0.0;
-  const bool carried = st->ns_valid == 3;       // the previous block (or run) left the f3_* register dump behind
+  // filter4, a block that follows another one in the same launch: h, w, ee, N, kappa and (a, b) of that block's last step stay
+  // where they are in LDS -- the first step's start predictor uses them
+  const bool warm = KIND == 1 && j > 0;
+  if (tid < RM) { L.mub[tid] = (tid < r && KIND == 0) ? st->mu[tid] : 0.0; if (!warm) { L.w[tid] = 0.0; L.h[tid] = 0.0; } }
+  if (tid < F3_NSC && !warm) L.sc[tid] = 0.0;
+  if (KIND == 1) {
+    // filter4: mu_{k0}, theta and the block's share of the R_k / Q_k schedules into LDS (mu_bar, F of the first step: X pair's prologue)
+    if (tid < RM) { D.mu[tid] = (tid < r) ? st->mu[tid] : 0.0; D.fd[tid] = 0.0; D.tp[tid] = 0.0; }
+    if (tid >= 64 && tid < 64 + 2 * RM) {
+      const int i = tid - 64, j = i & (RM - 1), hi = i >> 6;       // [0, RM): frequencies b (theta of cos-phase) | [RM, 2 RM): gains c
+      const bool phased = p.dyn_kind == DYN_SINUSOID && (p.dyn_flags & 2);
+      const bool have = p.n_theta > 0 && j < r && (hi == 0 || phased);
+      const double tv = p.theta[have ? hi * r + j : 0];
+      D.th[i] = have ? tv : 0.0;
+    }
+    if (tid >= 320 && tid < 320 + F4_NKC) f4_fill_trig_constants(D.kc, tid - 320);
+    if (tid >= 256 && tid < 256 + 48) {
+      const int jb_ = tid - 256;
+      const long long ks = min((long long)(k.k0 + jb_ + 1), (long long)(k.k0 + k.nb)) - p.series_t0;
+      if (p.rho_sched) D.rs[jb_] = p.rho_sched[ks];
+      if (p.q_sched) D.qs[jb_] = p.q_sched[ks];
+    }
+  }
+  const bool carried = st->ns_valid == (KIND == 1 ? 4 : 3);       // the previous block (or run) left the f3_* register dump behind
   __syncthreads();
   const long long t_a = (long long)__builtin_amdgcn_s_memrealtime();
-  if (!carried) {
+  if (!carried && KIND == 0) {
     // Lbar_1 = (P + q I)^-1 by the direct sweep: both halves run it in lockstep on their own image
     const int lt = tid & (WG - 1), c32 = lt & 31, rg = lt >> 5;
     double* im = tid < WG ? L.img : L.img + 32 * F3_S;
@@ -1087,7 +1114,21 @@ __device__ __forceinline__ void blk_filter3_body(const BlockParams& b0) {
     __syncthreads();
     f3_sweep_images(L, r2, tid);          // image X now holds Lbar_1 (ends with a barrier)
   }
-  if (role < 4) {
+  if (KIND == 1) {
+    // filter4 (psmf_blk4.hip): waves 0-1 the X pair (P+), 2-3 the Y pair (Lbar), 4-7 the vector waves
+    const int md = SMALL ? 2 : (r == 32 ? 0 : 1);
+    if (role < 2) {
+      if (md == 2) { if (role & 1) f4_x_program<1, 2>(b, k, L, D, role, lane, carried, warm && carried); else f4_x_program<0, 2>(b, k, L, D, role, lane, carried, warm && carried); }
+      else if (md == 0) { if (role & 1) f4_x_program<1, 0>(b, k, L, D, role, lane, carried, warm && carried); else f4_x_program<0, 0>(b, k, L, D, role, lane, carried, warm && carried); }
+      else { if (role & 1) f4_x_program<1, 1>(b, k, L, D, role, lane, carried, warm && carried); else f4_x_program<0, 1>(b, k, L, D, role, lane, carried, warm && carried); }
+    } else if (role < 4) {
+      if (md == 2) { if (role & 1) f4_y_program<1, 2>(b, k, L, D, role, lane, carried, warm && carried); else f4_y_program<0, 2>(b, k, L, D, role, lane, carried, warm && carried); }
+      else if (md == 0) { if (role & 1) f4_y_program<1, 0>(b, k, L, D, role, lane, carried, warm && carried); else f4_y_program<0, 0>(b, k, L, D, role, lane, carried, warm && carried); }
+      else { if (role & 1) f4_y_program<1, 1>(b, k, L, D, role, lane, carried, warm && carried); else f4_y_program<0, 1>(b, k, L, D, role, lane, carried, warm && carried); }
+    } else {
+      f4_v_program(b, k, L, D, role, lane, carried, warm && carried);
+    }
+  } else if (role < 4) {
     const int inv = role >> 1;
     if (SMALL) {
       if (role & 1) f3_ns_program<1, 2>(b, k, L, inv, role, lane, carried);
@@ -1123,5 +1164,8 @@ __device__ __forceinline__ void blk_filter3_body(const BlockParams& b0) {
 
 __global__ __launch_bounds__(F3_NT) void psmf_blk_filter3(BlockParams b0) { blk_filter3_body<false>(b0); }     // 16 < r <= 32
 __global__ __launch_bounds__(F3_NT) void psmf_blk_filter3s(BlockParams b0) { blk_filter3_body<true>(b0); }     // r <= 16
+// diagonal-Jacobian dynamics / per-step schedules (psmf_blk4.hip)
+__global__ __launch_bounds__(F3_NT) void psmf_blk_filter4(BlockParams b0) { blk_filter3_body<false, 1>(b0); }   // 16 < r <= 32
+__global__ __launch_bounds__(F3_NT) void psmf_blk_filter4s(BlockParams b0) { blk_filter3_body<true, 1>(b0); }   // r <= 16
 
 }  // namespace psmf

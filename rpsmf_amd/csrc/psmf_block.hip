@@ -773,6 +773,7 @@ __global__ __launch_bounds__(WG) void psmf_blk_filter(BlockParams b) {
     st->rho = rho; st->lam = lam; st->phi = phi; st->omega = omega; st->ee = ee_last;
     st->s_done = s_last; st->eta_done = eta_last; st->N_done = N_last;
     if (*errflag && st->err == 0) st->err = (int)(b.k0 + 1);
+    st->ns_valid = 0;          // nothing the two-inversion kernels carry from block to block describes this state
   }
 }
 
@@ -871,7 +872,7 @@ __global__ __launch_bounds__(2 * WG) void psmf_blk_filter2(BlockParams b) {
   int c_ns = 0, c_sw = 0, c_it = 0, c_fail = 0;   // diagnostics (uniform over the workgroup)
   float c_l0 = 0.f, c_l1 = 0.f, c_l2 = 0.f, c_m0 = -99.f;
   double Xp[M];                       // inverse found at the previous step (Newton-Schulz start)
-  const bool carried = st->ns_valid != 0;     // uniform: the previous block left Lbar and both inverses behind
+  const bool carried = st->ns_valid == 1 || st->ns_valid == 3;     // uniform: the previous block left Lbar and both inverses behind
   if (carried) {
 #pragma unroll
     for (int m = 0; m < M; ++m) {

@@ -39,11 +39,11 @@ constexpr int kGramWG = 128;
 // Environment switches ("Switches"): read ONCE per handle, at psmf_create -- tests flip them between
 // handles of one process; nothing on the per-block host path calls getenv.
 struct Switches {
-  bool block_mfma = true, bulk2 = true, filter3 = true, block_dual = true, block_flags = true, block_chain = true, block_pipe = true;
+  bool block_mfma = true, bulk2 = true, filter3 = true, filter4 = true, block_dual = true, block_flags = true, block_chain = true, block_pipe = true;
   bool force_collective = false;
   static bool off(const char* name) { const char* e = getenv(name); return e && atoi(e) == 0; }
   void read() {
-    block_mfma = !off("PSMF_BLOCK_MFMA"); bulk2 = !off("PSMF_BULK2"); filter3 = !off("PSMF_FILTER3"); block_dual = !off("PSMF_BLOCK_DUAL");
+    block_mfma = !off("PSMF_BLOCK_MFMA"); bulk2 = !off("PSMF_BULK2"); filter3 = !off("PSMF_FILTER3"); filter4 = !off("PSMF_FILTER4"); block_dual = !off("PSMF_BLOCK_DUAL");
     block_flags = !off("PSMF_BLOCK_FLAGS"); block_chain = !off("PSMF_BLOCK_CHAIN"); block_pipe = !off("PSMF_BLOCK_PIPE");
     force_collective = getenv("PSMF_FORCE_COLLECTIVE") != nullptr;
   }
@@ -299,8 +299,22 @@ bool blk_dual_ok(const psmf_filter* h) {
          h->cfg.dyn_kind == PSMF_DYN_RANDOM_WALK && !h->sp.rho_sched && !h->sp.q_sched;
 }
 
+// filter4 (psmf_blk4.hip): the role-specialised kernel for diagonal-Jacobian dynamics -- cos-phase, unscaled sinusoid, and the
+// random walk when R_k / Q_k schedules keep it off filter3 -- full filter, Q = q I, r <= 32; the recursive classes included
+bool blk_seq_ok(const psmf_filter* h) {
+  const int kd = h->cfg.dyn_kind;
+  const bool diag_dyn = kd == PSMF_DYN_RANDOM_WALK || kd == PSMF_DYN_COS_PHASE || (kd == PSMF_DYN_SINUSOID && !(h->cfg.dyn_flags & 1));
+  return h->sw.filter4 && h->sw.filter3 && h->sw.block_dual && h->q_iso && h->cfg.coef_update && h->cfg.pbar_predict && h->cfg.eta_full && diag_dyn &&
+         h->cfg.r <= 32;
+}
+
 void launch_blk_filter(psmf_filter* h, const psmf::BlockParams& b, hipStream_t stream = nullptr) {
   if (!stream) stream = h->stream;
+  if (!(blk_dual_ok(h) && blk_use_filter3(h)) && blk_seq_ok(h)) {
+    if (h->cfg.r > 16) hipLaunchKernelGGL(psmf::psmf_blk_filter4, dim3(1), dim3(psmf::F3_NT), psmf::blk_filter3_lds_bytes(), stream, b);
+    else hipLaunchKernelGGL(psmf::psmf_blk_filter4s, dim3(1), dim3(psmf::F3_NT), psmf::blk_filter3_lds_bytes(), stream, b);
+    return;
+  }
   if (blk_dual_ok(h) && blk_use_filter3(h)) {
     if (h->cfg.r > 16) hipLaunchKernelGGL(psmf::psmf_blk_filter3, dim3(1), dim3(psmf::F3_NT), psmf::blk_filter3_lds_bytes(), stream, b);
     else hipLaunchKernelGGL(psmf::psmf_blk_filter3s, dim3(1), dim3(psmf::F3_NT), psmf::blk_filter3_lds_bytes(), stream, b);
@@ -397,7 +411,7 @@ int enqueue_blocks_pipelined(psmf_filter* h, int64_t k_begin, int64_t k_end) {
   h->seq_next += nblk;
   // chain: the filter kernels of the whole run as ONE launch (psmf_blk_filter3; the bulk stream is driven as before)
   const bool chain_off = !h->sw.block_chain;
-  const bool chain = use_flags && !chain_off && nblk > 1 && blk_dual_ok(h) && blk_use_filter3(h);
+  const bool chain = use_flags && !chain_off && nblk > 1 && ((blk_dual_ok(h) && blk_use_filter3(h)) || blk_seq_ok(h));
   // first block: plain Gram of the stored C
   fill_block_params(h, b, k0_of(0), nb_of(0), 0);
   launch_blk_gram(h, b, h->bulk);
@@ -762,6 +776,8 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_apply_mfma<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)alds));
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_filter3, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psmf::blk_filter3_lds_bytes()));
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_filter3s, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psmf::blk_filter3_lds_bytes()));
+    CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_filter4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psmf::blk_filter3_lds_bytes()));
+    CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_filter4s, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psmf::blk_filter3_lds_bytes()));
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_xgram2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psmf::blk_xgram2_lds_bytes()));
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_xgram2<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psmf::blk_xgram2_lds_bytes()));
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_apply2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psmf::blk_apply2_lds_bytes()));
@@ -1201,6 +1217,26 @@ int psmf_geometry(psmf_handle h, int32_t* out7) {
   return PSMF_OK;
 }
 
+#ifdef F4_DEBUG
+// debug builds only (tools/probe_f4d.py): the scratch area the filter4 kernel writes its per-step residuals to
+int psmf_debug_read(psmf_handle h, double* out, int n) {
+  if (!h || !out) return PSMF_ERR_ARG;
+  int rc = psmf_sync(h);
+  if (rc) return rc;
+  HIP_TRY(h, hipMemcpy(out, h->st->GR, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+  return PSMF_OK;
+}
+#endif
+
+int psmf_filter_kernel(psmf_handle h) {
+  if (!h) return PSMF_ERR_ARG;
+  if (h->engine != 2) return 0;
+  if (blk_dual_ok(h) && blk_use_filter3(h)) return h->cfg.r > 16 ? 3 : 4;
+  if (blk_seq_ok(h)) return h->cfg.r > 16 ? 5 : 6;
+  if (blk_dual_ok(h)) return 2;
+  return 1;
+}
+
 int psmf_counters(psmf_handle h, int64_t* out8, int reset) {
   if (!h || !out8) return PSMF_ERR_ARG;
   if (set_device(h) != PSMF_OK) return PSMF_ERR_HIP;
@@ -1446,6 +1482,7 @@ int psmf_set_schedules(psmf_handle h, const double* rho_k, const double* q_k, in
     if (q_k) h->sp.q_sched = h->sched + n + 1;
   }
   destroy_graph(h);      // the graph's kernel nodes carry StepParams by value
+  { const int zero = 0; HIP_TRY(h, hipMemcpy(&h->st->ns_valid, &zero, sizeof(int), hipMemcpyHostToDevice)); }   // another filter kernel may run next: no carried register dump
   h->need_prep = true;
   return PSMF_OK;
 }

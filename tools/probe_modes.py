@@ -32,9 +32,14 @@ for name, kw in cases:
     f.set_state(st0["C"], st0["V"], st0["P"], st0["Q"], st0["mu"], rho=st0["rho"], lambda0=st0["lam"], theta=theta)
     best = 1e9
     try:
+        cn = {}
         for i in range(3):
+            f.counters(reset=True)
             t0 = time.perf_counter(); f.run(0, T); best = min(best, time.perf_counter() - t0)
-        print(f"{name:52s} {T / best:10.0f} timesteps/s  ({1e6 * best / T:.2f} us)  engine={f.geometry()['engine']}", flush=True)
+            cn = f.counters() if f.geometry()["engine"] == "block" else {}
+        g = f.geometry()
+        extra = f" ns/sweep/iter/failed={cn['ns_steps']}/{cn['sweep_steps']}/{cn['ns_iterations']}/{cn['ns_failed']}" if cn else ""
+        print(f"{name:52s} {T / best:10.0f} timesteps/s  ({1e6 * best / T:.2f} us)  {g['filter_kernel']}{extra}", flush=True)
     except Exception as e:
         print(f"{name:52s} failed: {type(e).__name__}: {e}", flush=True)
     f.close()
