@@ -37,6 +37,7 @@ constexpr int RB = 64;           // r + B, padded coefficient dimension (r <= 32
 constexpr int RS = RM / 2 + 1;   // LDS row stride of the RB x r coefficient matrices (odd: lane = row reads are conflict-free)
 constexpr int BLK_GRAM_WG = 256; // workgroups (= partials) of the block Gram
 constexpr int XGB = 64;          // column capacity of the cross-Gram (>= block length)
+constexpr int BLK_TH_CAP = 2048; // psmf_blk_filter: theta / gradient sums of at most this many parameters live in LDS during a block
 
 struct BlockParams {
   StepParams sp;
@@ -518,9 +519,16 @@ __global__ __launch_bounds__(WG) void psmf_blk_filter(BlockParams b) {
   double* s_tp = s_val + DYN_MAX_TERMS * RM;
   double* s_gf = s_tp + DYN_MAX_TERMS * RM;   // RM
   double* s_u = s_gf + RM;            // RM
+  double* s_theta = s_u + RM;         // BLK_TH_CAP   (theta and gradsum of the block, when they fit)
+  double* s_grad = s_theta + BLK_TH_CAP;
   const bool dense = dyn_dense(p.dyn_kind, p.dyn_flags);
+  const bool th_lds = p.n_theta > 0 && p.n_theta <= BLK_TH_CAP;
+  StepParams pd = p;                  // what the dynamics see: theta / gradsum in LDS when they fit
+  if (th_lds) { pd.theta = s_theta; pd.gradsum = s_grad; }
 
   if (!blk_handoff_begin(b)) return;
+  if (th_lds)
+    for (int idx = tid; idx < p.n_theta; idx += WG) { s_theta[idx] = p.theta[idx]; s_grad[idx] = p.gradsum[idx]; }
   if (!b.assemble) {
     for (int idx = tid; idx < RB * RB; idx += WG) sK[idx] = b.K[idx];
   } else {
@@ -559,7 +567,7 @@ __global__ __launch_bounds__(WG) void psmf_blk_filter(BlockParams b) {
   for (int jb = 0; jb < b.nb; ++jb) {
     const long long kstep = b.k0 + jb + 1;   // 1-based step index
     // ---- S1: mu_bar = f(theta, mu, k), F = df/dx (psmf.py:104-115; psmf_dyn.hip) ----
-    dyn_forward<WG>(p, (double)kstep, s_mu, s_mub, s_f, sF, RS, s_val, s_tp, tid);     // ends with a barrier
+    dyn_forward<WG>(pd, (double)kstep, s_mu, s_mub, s_f, sF, RS, s_val, s_tp, sT, tid);     // ends with a barrier (sT: scratch here, P F^T below)
     BLK_T(0);
     // PSMFIter reads Q[k], R[k] of the step (psmf.py:115,123,141): scalar schedules (never with rPSMF's running Q, R)
     const double qs = p.q_sched ? p.q_sched[kstep - p.series_t0] : 1.0;
@@ -706,7 +714,7 @@ __global__ __launch_bounds__(WG) void psmf_blk_filter(BlockParams b) {
         s_gf[tid] = gf;
       }
       __syncthreads();
-      dyn_backward<WG>(p, (double)kstep, s_mu, s_gf, s_val, s_tp, s_u, tid);        // ends with a barrier
+      dyn_backward<WG>(pd, (double)kstep, s_mu, s_gf, s_val, s_tp, tid);        // ends with a barrier
     }
     BLK_T(6);
     double vscale = 1.0, pscale = 1.0, qscale = 1.0;
@@ -750,13 +758,15 @@ __global__ __launch_bounds__(WG) void psmf_blk_filter(BlockParams b) {
     __syncthreads();
     BLK_T(7);
     // PSMFRecursive: optimiser step on theta every update_every observations (psmf.py:299-304)
-    if (p.recursive && p.n_theta > 0 && (kstep % p.update_every) == 0) dyn_adam_step<WG>(p, kstep, tid);
+    if (p.recursive && p.n_theta > 0 && (kstep % p.update_every) == 0) dyn_adam_step<WG>(pd, kstep, tid);
     BLK_T(8);
   }
   BLK_TOUT();
 
   // ---- block end: coefficients and state back to memory ----
   for (int idx = tid; idx < RB * r; idx += WG) { const int m = idx / r; b.Acoef[idx] = sA[m * RS + (idx - m * r)]; }
+  if (th_lds)
+    for (int idx = tid; idx < p.n_theta; idx += WG) { p.gradsum[idx] = s_grad[idx]; if (p.recursive) p.theta[idx] = s_theta[idx]; }
 #pragma unroll
   for (int m = 0; m < M; ++m) {
     if (val[m]) {
@@ -1169,9 +1179,12 @@ inline size_t blk_filter2_lds_bytes() {
   return (doubles * 8 + 15) & ~(size_t)15;
 }
 
+// theta and its summed gradient are kept in LDS for the duration of a block when they fit (n_theta <= BLK_TH_CAP): the dynamics
+// read / accumulate them every timestep (FourierBasis N = 2, r = 10: 480 parameters; from global memory that was 24 000 of the
+// 42 000 cycles of a timestep, tools/blkgen_prof.hip)
 inline size_t blk_filter_lds_bytes() {
   const size_t doubles = (size_t)RB * RB + 2 * (size_t)RB * RS + WG + 6 * RM + 2 * RB + 8 * RB + 4 * RM + 4 + 2 +
-                         3 * (size_t)(RM / 2) * RS + 2 * (size_t)DYN_MAX_TERMS * RM + 2 * RM;
+                         3 * (size_t)(RM / 2) * RS + 2 * (size_t)DYN_MAX_TERMS * RM + 2 * RM + 2 * (size_t)BLK_TH_CAP;
   return (doubles * 8 + 15) & ~(size_t)15;
 }
 

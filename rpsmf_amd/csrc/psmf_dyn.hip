@@ -68,14 +68,37 @@ __host__ __device__ inline DynTerm dyn_term(int kind, int flags, int N, int r, i
   return d;
 }
 
+// sin(pi a), cos(pi a): exact reduction to |f| <= 1/4 half-turns (a - n / 2 is exact in float64), the fdlibm kernel polynomials on
+// |pi f| <= pi / 4, quadrant rotation -- branch-free, ~40 instructions.  The arguments here are 2 pi b k + c x with k up to the
+// series length: sincos() of the radian argument goes through its large-argument path (scratch memory, branches) for every
+// element; in half-turns the reduction is one rint.  Agrees with sincos(2 pi b k + c x) to the rounding of that argument (~1e-12).
+__device__ __forceinline__ void dyn_sincospi(const double a, double& sn, double& cs) {
+  const double n = rint(2.0 * a);
+  const double f = fma(-0.5, n, a);
+  const double x = f * M_PI, z = x * x;
+  const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08), 2.75573137070700676789e-06),
+                                           -1.98412698298579493134e-04), 8.33333333332248946124e-03), -1.66666666666666324348e-01);
+  const double s0 = fma(x * z, ps, x);
+  const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07),
+                                           2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+  const double c0 = fma(z * z, pc, fma(-0.5, z, 1.0));
+  const int qd = (int)((long long)n) & 3;
+  const double s1 = (qd & 1) ? c0 : s0, c1 = (qd & 1) ? s0 : c0;
+  sn = (qd == 2 || qd == 3) ? -s1 : s1;
+  cs = (qd == 1 || qd == 2) ? -c1 : c1;
+}
+
 // Forward pass, all NTH threads of the workgroup; ends with a barrier.
 //   s_x    mu_{k-1} (LDS, r)             s_mub  out: mu_bar (r)
 //   s_fd   out: diagonal of F when !dense (r)
 //   sF     out: dense F, row stride ldf, when dense
 //   s_val, s_tp   out: [term][RM] trig(arg), trig'(arg) for the gradient
+//   s_part scratch, DYN_MAX_TERMS * RM doubles (partial mat-vecs of the terms)
+// Every O(nt r^2) loop is spread over the workgroup (one (row, term) or (row, column) pair per thread): with r threads
+// walking the terms one after the other a FourierBasis step spent 8 000 cycles here (tools/blkgen_prof.hip).
 template <int NTH>
 __device__ __forceinline__ void dyn_forward(const StepParams& p, const double tk, const double* s_x, double* s_mub, double* s_fd,
-                                            double* sF, const int ldf, double* s_val, double* s_tp, const int tid) {
+                                            double* sF, const int ldf, double* s_val, double* s_tp, double* s_part, const int tid) {
   const int r = p.r, kind = p.dyn_kind, flags = p.dyn_flags, N = p.dyn_terms;
   const double* th = p.theta;
   if (kind == DYN_RANDOM_WALK) {
@@ -98,48 +121,57 @@ __device__ __forceinline__ void dyn_forward(const StepParams& p, const double tk
     const int t = idx / r, j = idx - t * r;
     const DynTerm d = dyn_term(kind, flags, N, r, t);
     const double c = d.c_off >= 0 ? th[d.c_off + j] : 1.0;
-    const double arg = 2.0 * M_PI * th[d.b_off + j] * tk + c * s_x[j];
     double sn, cs;
-    sincos(arg, &sn, &cs);
+    dyn_sincospi(2.0 * th[d.b_off + j] * tk + (c * s_x[j]) * 0.31830988618379067154, sn, cs);
     s_val[t * RM + j] = d.is_cos ? cs : sn;
     s_tp[t * RM + j] = d.is_cos ? -sn : cs;
   }
   __syncthreads();
   const bool dense = dyn_dense(kind, flags);
-  if (tid < r) {
-    double a = 0.0, fd = 0.0;
-    for (int t = 0; t < nt; ++t) {
-      const DynTerm d = dyn_term(kind, flags, N, r, t);
-      if (d.m_off >= 0) {
-        for (int j = 0; j < r; ++j) a += th[d.m_off + tid * r + j] * s_val[t * RM + j];
-      } else {
-        a += s_val[t * RM + tid];
-        fd += s_tp[t * RM + tid] * (d.c_off >= 0 ? th[d.c_off + tid] : 1.0);
-      }
+  // per (term, row): the term's share of mu_bar_i (and of the diagonal of F for identity-matrix terms)
+  for (int idx = tid; idx < nt * r; idx += NTH) {
+    const int t = idx / r, i = idx - t * r;
+    const DynTerm d = dyn_term(kind, flags, N, r, t);
+    double a = 0.0;
+    if (d.m_off >= 0) {
+      const double* row = th + d.m_off + i * r;
+      for (int j = 0; j < r; ++j) a += row[j] * s_val[t * RM + j];
+    } else {
+      a = s_val[t * RM + i];
     }
-    s_mub[tid] = a;
-    if (!dense) s_fd[tid] = fd;
+    s_part[t * RM + i] = a;
   }
   if (dense) {
     for (int idx = tid; idx < r * r; idx += NTH) {
-      const int j = idx % r;
+      const int i = idx / r, j = idx - i * r;
       double a = 0.0;
       for (int t = 0; t < nt; ++t) {
         const DynTerm d = dyn_term(kind, flags, N, r, t);
         const double dv = s_tp[t * RM + j] * (d.c_off >= 0 ? th[d.c_off + j] : 1.0);
-        a += (d.m_off >= 0 ? th[d.m_off + idx] : ((idx / r == j) ? 1.0 : 0.0)) * dv;
+        a += (d.m_off >= 0 ? th[d.m_off + idx] : ((i == j) ? 1.0 : 0.0)) * dv;
       }
-      sF[(idx / r) * ldf + j] = a;
+      sF[i * ldf + j] = a;
     }
+  }
+  __syncthreads();
+  if (tid < r) {
+    double a = 0.0, fd = 0.0;
+    for (int t = 0; t < nt; ++t) {
+      const DynTerm d = dyn_term(kind, flags, N, r, t);
+      a += s_part[t * RM + tid];
+      if (d.m_off < 0) fd += s_tp[t * RM + tid] * (d.c_off >= 0 ? th[d.c_off + tid] : 1.0);
+    }
+    s_mub[tid] = a;
+    if (!dense) s_fd[tid] = fd;
   }
   __syncthreads();
 }
 
-// Gradient pass: gradsum += J_theta^T g_f.  s_gf: g_f (LDS, r), s_x: mu_{k-1}, s_u: scratch (RM).  All NTH threads; the
-// caller has a barrier between writing s_gf and this call; ends with a barrier.
+// Gradient pass: gradsum += J_theta^T g_f.  s_gf: g_f (LDS, r), s_x: mu_{k-1}.  All NTH threads; the caller has a barrier
+// between writing s_gf and this call; ends with a barrier.  One (term, column) pair or one matrix element per thread.
 template <int NTH>
 __device__ __forceinline__ void dyn_backward(const StepParams& p, const double tk, const double* s_x, const double* s_gf,
-                                             const double* s_val, const double* s_tp, double* s_u, const int tid) {
+                                             const double* s_val, const double* s_tp, const int tid) {
   const int r = p.r, kind = p.dyn_kind, flags = p.dyn_flags, N = p.dyn_terms;
   const double* th = p.theta;
   double* g = p.gradsum;
@@ -151,23 +183,26 @@ __device__ __forceinline__ void dyn_backward(const StepParams& p, const double t
     return;
   }
   const int nt = dyn_n_terms(kind, N);
-  for (int t = 0; t < nt; ++t) {
+  // d/dM_t[i][j] = g_f[i] trig_t(arg_tj)
+  for (int idx = tid; idx < nt * r * r; idx += NTH) {
+    const int t = idx / (r * r), e = idx - t * r * r;
     const DynTerm d = dyn_term(kind, flags, N, r, t);
+    if (d.m_off >= 0) g[d.m_off + e] += s_gf[e / r] * s_val[t * RM + e % r];
+  }
+  // d/db_t[j], d/dc_t[j] = (M_t^T g_f)_j trig_t'(arg_tj) {2 pi k, x_j}
+  for (int idx = tid; idx < nt * r; idx += NTH) {
+    const int t = idx / r, j = idx - t * r;
+    const DynTerm d = dyn_term(kind, flags, N, r, t);
+    double u;
     if (d.m_off >= 0) {
-      for (int idx = tid; idx < r * r; idx += NTH) g[d.m_off + idx] += s_gf[idx / r] * s_val[t * RM + idx % r];
-      if (tid < r) {
-        double u = 0.0;
-        for (int i = 0; i < r; ++i) u += th[d.m_off + i * r + tid] * s_gf[i];
-        s_u[tid] = u;
-      }
-    } else if (tid < r) {
-      s_u[tid] = s_gf[tid];
+      u = 0.0;
+      for (int i = 0; i < r; ++i) u += th[d.m_off + i * r + j] * s_gf[i];
+    } else {
+      u = s_gf[j];
     }
-    if (tid < r) {          // (the same thread wrote s_u[tid])
-      const double ut = s_u[tid] * s_tp[t * RM + tid];
-      g[d.b_off + tid] += ut * (2.0 * M_PI * tk);
-      if (d.c_off >= 0) g[d.c_off + tid] += ut * s_x[tid];
-    }
+    const double ut = u * s_tp[t * RM + j];
+    g[d.b_off + j] += ut * (2.0 * M_PI * tk);
+    if (d.c_off >= 0) g[d.c_off + j] += ut * s_x[j];
   }
   __syncthreads();
 }
