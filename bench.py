@@ -214,7 +214,7 @@ def run_filter_config(_capi, name, d, r, T, robust, passes=3):
             "hbm_frac_step_at_a_time": (T / steady) * 8.0 * d * (r + 1) / (HBM_PEAK_GBS * 1e9)}
 
 
-def run_impute_config(seeds=50, n=295_719, d=19, r=10, n_par=3000):
+def run_impute_config(seeds=50, n=295_719, d=19, r=10, n_par=3000, variants=(False, True)):
     """Config D: masked filter, gas-sensor shape (the CSV is not in the reference checkout: synthetic stand-in of the same
     shape), 40 % missing, `seeds` replicas in one launch; parity of replica 0 on an n_par-column prefix against the oracle."""
     from oracle.impute_oracle import impute_filter
@@ -232,7 +232,7 @@ def run_impute_config(seeds=50, n=295_719, d=19, r=10, n_par=3000):
     M, Mm, C0, X0 = np.stack(M), np.stack(Mm), np.stack(C0), np.stack(X0)
     V, Q, P = 2 * np.eye(r), 0.1 * np.eye(r), np.eye(r)
     out = {}
-    for robust in (False, True):
+    for robust in variants:
         res = impute.impute_batch(Yint, M, Mm, C0, X0, V, Q, 10.0, P, 2, 2, robust=robust, lambda0=1.8)
         steps = seeds * 2 * n
         # parity: replica 0 on a prefix, device vs oracle
@@ -535,6 +535,10 @@ def main():
                     other["D"] = run_impute_config()
                 except Exception as e:
                     other["D"] = {"error": repr(e)}
+                try:     # the reference's own batch: IMPUTE_REPEATS = 100 (Makefile:160,176-177) -- one workgroup per replica, 100 CUs busy
+                    other["D_100_repeats"] = run_impute_config(seeds=100, variants=(False,))
+                except Exception as e:
+                    other["D_100_repeats"] = {"error": repr(e)}
                 line["other_configs"] = other
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -44,16 +44,15 @@ struct F4Lds {
     else last_ = w_ * w_ < 0.25 * p.ns_tol2;      /* one more iteration is the last: no check needed */     \
   } while (0)
 
-// x_skip / y_skip: steps for which the iteration is not even tried after a failure; x_back / y_back: the length of the next
-// such pause -- doubled with every failure in a row (3, 6, ... 48), back to 3 with the first success -- so that in a regime in
-// which a start is useless (P ~ q: Pbar has no small parameter) the kernel degrades to the direct sweeps, not to both
-// The direct symmetric sweep of ONE 32 x 32 image (in place, A <- A^-1) by waves 0-3 -- one per SIMD, so that a pivot round costs
-// what it costs in the one-group kernels (filter3's fallback sweeps two images on all eight waves: two waves per SIMD share the
-// arithmetic of every round, 1 400 cycles per round against 970, and here only one matrix is inverted at a time); waves 4-7 keep
-// the barrier count.  Called by all 512 threads at the same point; the image was published before the barrier that precedes it.
+// The direct symmetric sweep of ONE 32 x 32 image (in place, A <- A^-1) by the four VECTOR waves -- one per SIMD, so that a pivot
+// round costs what it costs in the one-group kernels (filter3's fallback sweeps two images on all eight waves: two waves per
+// SIMD share the arithmetic of every round, and here only one matrix is inverted at a time), and waves with few live registers:
+// inlined into the inversion programs (~200 live registers each) the sweep's temporaries would be spilled inside its pivot loop.
+// Waves 0-3 keep the barrier count.  Called by all 512 threads at the same point; the image was published before the barrier
+// that precedes it.
 __device__ __forceinline__ void f4_sweep_image(const F3Lds& L, double* im, const int r2, const int tid) {
-  if (tid < WG) {
-    const int c32 = tid & 31, rg = tid >> 5;
+  if (tid >= WG) {
+    const int lt = tid - WG, c32 = lt & 31, rg = lt >> 5;
     double A1[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) A1[m] = im[(rg + 8 * m) * F3_S + c32];
@@ -70,6 +69,9 @@ __device__ __forceinline__ void f4_sweep_image(const F3Lds& L, double* im, const
   __syncthreads();
 }
 
+// x_skip / y_skip: steps for which the iteration is not even tried after a failure; x_back / y_back: the length of the next
+// such pause -- doubled with every failure in a row (3, 6, ... 48), back to 3 with the first success -- so that in a regime in
+// which a start is useless (P ~ q: Pbar has no small parameter) the kernel degrades to the direct sweeps, not to both
 struct F4Ctl {
   bool have_prev;
   int x_skip, y_skip;

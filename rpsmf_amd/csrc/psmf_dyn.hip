@@ -128,6 +128,22 @@ __device__ __forceinline__ void dyn_forward(const StepParams& p, const double tk
   }
   __syncthreads();
   const bool dense = dyn_dense(kind, flags);
+  if (!dense && kind != DYN_FOURIER) {
+    // no matrix in any term (cos-phase, unscaled sinusoid -- the ExperimentSynthetic modes): mu_bar and the diagonal of F
+    // straight from the trig values, one barrier less
+    if (tid < r) {
+      double a = 0.0, fd = 0.0;
+      for (int t = 0; t < nt; ++t) {
+        const DynTerm d = dyn_term(kind, flags, N, r, t);
+        a += s_val[t * RM + tid];
+        fd += s_tp[t * RM + tid] * (d.c_off >= 0 ? th[d.c_off + tid] : 1.0);
+      }
+      s_mub[tid] = a;
+      s_fd[tid] = fd;
+    }
+    __syncthreads();
+    return;
+  }
   // per (term, row): the term's share of mu_bar_i (and of the diagonal of F for identity-matrix terms)
   for (int idx = tid; idx < nt * r; idx += NTH) {
     const int t = idx / r, i = idx - t * r;
