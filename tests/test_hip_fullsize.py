@@ -221,3 +221,59 @@ def test_config_D_fifty_seed_batch_equals_single_runs():
             one = impute.impute_batch(Yint, M[i], Mm[i], C0[i], X0[i], V, Q, 10.0, P, 2, 2, robust=False)
             for k in ("Epred", "Efull", "inside", "C", "X"):
                 assert np.array_equal(one[k][0], res[k][i]), (n, i, k)
+
+
+# ----------------------------------------------------------------------------- filter4 at size
+@pytest.mark.parametrize("robust,q,recursive", [(False, 0.1, False), (True, 1.0, False), (False, 1.0, True)],
+                         ids=["PSMF_q0.1", "rPSMF_q1", "PSMFRecursive_q1"])
+def test_filter4_cos_phase_at_size(robust, q, recursive):
+    """psmf_blk_filter4 (diagonal-Jacobian dynamics: sequential Newton-Schulz inversions with sweep fallback, theta gradient,
+    in-loop Adam) at d = 20 000, r = 20 against the oracle (pypsmf/psmf/psmf.py:90-115,167-177,287-304; rpsmf.py:116-184).
+
+    The horizon is short on purpose.  The FULL filter with f = cos(2 pi theta t + x) is a chaotic recursion on this data: any
+    two float64 implementations separate by a factor ~1e5 every 50 timesteps (the general kernel, this kernel and the oracle agree
+    to 1e-11 at k = 50, 1e-6 at k = 100 and not at all at k = 200: tools/probe_f4g.py, float64 storage) -- the reference itself
+    would not reproduce its own run under a different BLAS.  So: float64 storage over 48 timesteps (two blocks) at 1e-6, float32
+    storage over the first 30 at 1e-5 (north_star)."""
+    c = _capi()
+    d, r, T = 20_000, 20, 48
+    Y, C0 = _bench_problem(d, r, T, robust)
+    rng = np.random.default_rng(77)
+    theta0 = 0.05 + 0.1 * rng.random(r)
+    V0, P0, Q = 0.1 * np.eye(r), np.eye(r), q * np.eye(r)
+    dyn = O.CosPhaseDyn(r)
+    Y64 = Y.astype(np.float64)
+    mode = O.Mode(robust=robust)
+    for storage, Tn, tol in (("f64", 48, 1e-6), ("f32", 30, TOL)):
+        st = O.State(C=C0, V=V0, mu=np.zeros(r), P=P0, Q=Q, rho=1.0, lam=1.8, theta=theta0.copy(), gradsum=np.zeros(r))
+        if recursive:
+            m = v = np.zeros(r)
+            Yp = np.empty((Tn, d))
+            for k in range(1, Tn + 1):
+                st, info = O.lowrank_step(st, Y64[k - 1], k, mode, dyn)
+                Yp[k - 1] = info.y_pred
+                st.theta, m, v = O.adam_update(st.theta, st.gradsum, m, v, k)      # update_every = 1 (psmf.py:299-304)
+                st.gradsum = np.zeros(r)
+        else:
+            st, Yp, _ = O.run_epoch(st, Y64[:Tn], mode, dyn)
+        kw = dict(recursive=True, update_every=1, adam_lr=1e-3) if recursive else {}
+        f = c.DeviceFilter(d, r, robust=robust, storage=storage, dyn_kind=c.DYN_COS_PHASE, **kw)
+        f.upload_series(Y)
+        f.set_state(C0, V0, P0, Q, np.zeros(r), rho=1.0, lambda0=1.8, theta=theta0)
+        assert f.geometry()["filter_kernel"] == "psmf_blk_filter4"      # (the choice depends on the Q just uploaded: Q = q I)
+        f.zero_gradsum()
+        if recursive:
+            f.set_adam(np.zeros(r), np.zeros(r))
+        f.counters(reset=True)
+        f.run(0, Tn)
+        s = f.get_state()
+        cnt = f.counters()
+        for name in ("C", "V", "mu", "P"):
+            assert relerr(s[name], getattr(st, name)) < tol, (storage, name, relerr(s[name], getattr(st, name)))
+        assert relerr(f.y_pred(0, Tn), Yp) < tol
+        if recursive:
+            assert relerr(s["theta"], st.theta) < tol
+        else:
+            assert relerr(s["gradsum"], st.gradsum) < 10 * tol
+        assert cnt["ns_steps"] + cnt["sweep_steps"] == Tn
+        f.close()
