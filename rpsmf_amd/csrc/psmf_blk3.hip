@@ -969,7 +969,7 @@ __device__ __forceinline__ void f3_v_program(const BlockParams& b, const F3Blk& 
 
 // SMALL = true: the r <= 16 instantiation, a kernel of its own -- compiled into the same kernel as the two r > 16 programs it
 // cost the r = 32 path 2 % (register allocation over the larger kernel: 111 spilled registers against 96; measured A / B on one box)
-// KIND 0: filter3 (random walk, two parallel inversions); KIND 1: filter4 (psmf_blk4.hip)
+// KIND 0: filter3 (random walk, two parallel inversions); KIND 1: filter4, KIND 2: filter5 (simplified hooks) (psmf_blk4.hip)
 template <bool SMALL, int KIND = 0>
 __device__ __forceinline__ void blk_filter3_body(const BlockParams& b0) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -1011,7 +1011,7 @@ __device__ __forceinline__ void blk_filter3_body(const BlockParams& b0) {
   L.s32 = hotS;
   __shared__ long long s_tick[2];
   L.tick = s_tick;
-  __shared__ __attribute__((aligned(16))) double hot4[KIND == 1 ? 5 * RM + 2 * 48 + F4_NKC : 2];
+  __shared__ __attribute__((aligned(16))) double hot4[KIND >= 1 ? 5 * RM + 2 * 48 + F4_NKC : 2];
   F4Lds D;
   D.fd = hot4; D.mu = D.fd + RM; D.tp = D.mu + RM; D.th = D.tp + RM; D.rs = D.th + 2 * RM; D.qs = D.rs + 48; D.kc = D.qs + 48;
 
@@ -1075,11 +1075,11 @@ __device__ __forceinline__ void blk_filter3_body(const BlockParams& b0) {
   if (tid == 0) *L.errflag = 0;
   // filter4, a block that follows another one in the same launch: h, w, ee, N, kappa and (a, b) of that block's last step stay
   // where they are in LDS -- the first step's start predictor uses them
-  const bool warm = KIND == 1 && j > 0;
+  const bool warm = KIND == 1 && j > 0;      // (filter5 has no start to predict)
   if (tid < RM) { L.mub[tid] = (tid < r && KIND == 0) ? st->mu[tid] : 0.0; if (!warm) { L.w[tid] = 0.0; L.h[tid] = 0.0; } }
   if (tid < F3_NSC && !warm) L.sc[tid] = 0.0;
-  if (KIND == 1) {
-    // filter4: mu_{k0}, theta and the block's share of the R_k / Q_k schedules into LDS (mu_bar, F of the first step: X pair's prologue)
+  if (KIND >= 1) {
+    // filter4 / filter5: mu_{k0}, theta and the block's share of the R_k / Q_k schedules into LDS (mu_bar, F of the first step: X pair's prologue)
     if (tid < RM) { D.mu[tid] = (tid < r) ? st->mu[tid] : 0.0; D.fd[tid] = 0.0; D.tp[tid] = 0.0; }
     if (tid >= 64 && tid < 64 + 2 * RM) {
       const int i = tid - 64, j = i & (RM - 1), hi = i >> 6;       // [0, RM): frequencies b (theta of cos-phase) | [RM, 2 RM): gains c
@@ -1096,7 +1096,7 @@ __device__ __forceinline__ void blk_filter3_body(const BlockParams& b0) {
       if (p.q_sched) D.qs[jb_] = p.q_sched[ks];
     }
   }
-  const bool carried = st->ns_valid == (KIND == 1 ? 4 : 3);       // the previous block (or run) left the f3_* register dump behind
+  const bool carried = st->ns_valid == (KIND == 2 ? 5 : (KIND == 1 ? 4 : 3));       // the previous block (or run) left the f3_* register dump behind
   __syncthreads();
   const long long t_a = (long long)__builtin_amdgcn_s_memrealtime();
   if (!carried && KIND == 0) {
@@ -1114,7 +1114,11 @@ __device__ __forceinline__ void blk_filter3_body(const BlockParams& b0) {
     __syncthreads();
     f3_sweep_images(L, r2, tid);          // image X now holds Lbar_1 (ends with a barrier)
   }
-  if (KIND == 1) {
+  if (KIND == 2) {
+    // filter5 (psmf_blk4.hip): the simplified hooks -- the vector program alone; waves 0-3 keep the barrier count
+    if (role < 4) f5_idle_program(k);
+    else f5_v_program(b, k, L, D, role, lane, carried);
+  } else if (KIND == 1) {
     // filter4 (psmf_blk4.hip): waves 0-1 the X pair (P+), 2-3 the Y pair (Lbar), 4-7 the vector waves
     const int md = SMALL ? 2 : (r == 32 ? 0 : 1);
     if (role < 2) {
@@ -1167,5 +1171,7 @@ __global__ __launch_bounds__(F3_NT) void psmf_blk_filter3s(BlockParams b0) { blk
 // diagonal-Jacobian dynamics / per-step schedules (psmf_blk4.hip)
 __global__ __launch_bounds__(F3_NT) void psmf_blk_filter4(BlockParams b0) { blk_filter3_body<false, 1>(b0); }   // 16 < r <= 32
 __global__ __launch_bounds__(F3_NT) void psmf_blk_filter4s(BlockParams b0) { blk_filter3_body<true, 1>(b0); }   // r <= 16
+// simplified hooks (ExperimentSynthetic), diagonal-Jacobian dynamics, any r <= 32 (psmf_blk4.hip)
+__global__ __launch_bounds__(F3_NT) void psmf_blk_filter5(BlockParams b0) { blk_filter3_body<false, 2>(b0); }
 
 }  // namespace psmf

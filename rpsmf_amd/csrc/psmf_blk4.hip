@@ -1024,3 +1024,309 @@ __device__ __forceinline__ void f4_v_program(const BlockParams& b, const F3Blk& 
 #undef Y_WORK
 #undef Y_TO_IMAGE
 }
+
+// ------------------------------------------------------------------------------------------------------------
+// "filter5": the SIMPLIFIED hook configuration of the synthetic experiments (ExperimentSynthetic/synthetic_psmf.py:78-100,
+// synthetic_rpsmf.py:82-118; SURVEY App. A mode table: P_bar = P_{k-1}, eta = tr(R_{k-1}) / d, no coefficient update: mu_k = mu_bar_k,
+// P_k = P_bar_k; rPSMF: omega from (R + s I)^-1 alone, R scaled by it, Q and P carried) with diagonal-Jacobian dynamics.  No r x r
+// inversion is left in a timestep, so the whole step is the vector program of filter3 / filter4 -- V and the scalars (wave 4), A by
+// rows (5), K A by rows (6), A^T by columns (7) -- plus mu_bar_{k+1} = f(theta, mu_bar_k, k + 1), which wave 4 iterates by itself
+// (it depends on nothing the step computes), the theta gradient and, for the recursive classes, Adam.  Three barriers per timestep.
+// The general kernel ran these modes at 5.4 us per timestep (seven barrier-separated stages of a 256-thread group).
+// Launched with the 512 threads of the common skeleton (K assembly, chained blocks); waves 0-3 only keep the barrier count.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void f5_idle_program(const F3Blk& k) {
+  f3_barrier();                                                       // init barrier
+  for (int jb = 0; jb < k.nb; ++jb) {
+    f3_barrier();                                                     // B1
+    f3_barrier();                                                     // B2
+    f3_barrier();                                                     // BF
+  }
+  f3_barrier();                                                       // block end
+}
+
+__device__ __forceinline__ void f5_v_program(const BlockParams& b, const F3Blk& k, const F3Lds& L, const F4Lds& D, const int role, const int lane,
+                                             const bool carried) {
+  const StepParams& p = b.sp;
+  DevState* st = p.st;
+  const int r = p.r, tid = 64 * role + lane;
+  const double dd = (double)p.d;
+  const bool isV0 = role == 4, isV1 = role == 5, isV2 = role == 6, isV3 = role == 7;
+  double pr[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) pr[i] = 0.0;
+  double kappa = 0.0, Nk = 0.0, invN = 0.0, s_k = 0.0, eta_k = 0.0, ee_k = 0.0, phi = 1.0, omega = 1.0, wj = 0.0;
+  double rho = st->rho, lam = st->lam;
+  const bool has_th = p.n_theta > 0;
+  const bool phased = p.dyn_kind == DYN_SINUSOID && (p.dyn_flags & 2);
+  const int jth = lane & 31;
+  const bool own_th = isV0 && has_th && lane < 32 && jth < r;
+  double gs_b = 0.0, gs_c = 0.0, am_b = 0.0, av_b = 0.0, am_c = 0.0, av_c = 0.0;
+  double b1k = 1.0, b2k = 1.0, lr_k = p.lr, lr_g = 1.0;
+  double mu_j = 0.0, mub_j = 0.0, tp_j = 0.0;         // wave 4, lane j: mu_{k-1,j}, mu_bar_{k,j}, trig'(arg_kj)
+  // wave 7 also tracks G = C^T C (rank-2 update per timestep): the next block's K is assembled from it
+  // (K A_0 = the first r columns of K).  Layout: lane = (column c = lane & 31, half hf = lane >> 5), g[t] = G[16 hf + t][c].
+  double g[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t) g[t] = 0.0;
+  if (own_th) {
+    gs_b = p.gradsum[jth];
+    if (phased) gs_c = p.gradsum[r + jth];
+    if (p.recursive) {
+      am_b = p.adam_m[jth]; av_b = p.adam_v[jth];
+      if (phased) { am_c = p.adam_m[r + jth]; av_c = p.adam_v[r + jth]; }
+    }
+  }
+  if (isV0 && has_th && p.recursive) {
+    b1k = pow(p.b1, (double)k.k0); b2k = pow(p.b2, (double)k.k0);
+    if (p.lr_steps > 0.0) { lr_k = p.lr * pow(p.lr_end / p.lr, (double)k.k0 / p.lr_steps); lr_g = pow(p.lr_end / p.lr, 1.0 / p.lr_steps); }
+  }
+  if (isV0) {
+    const int j = lane & 31, hf = lane >> 5;
+    if (carried) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) pr[t] = st->f3_V[t * 64 + lane];
+    } else {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int i = 16 * hf + t;
+        const bool in = i < r && j < r;
+        const double v = st->V[in ? i * r + j : 0];
+        pr[t] = in ? v : 0.0;
+      }
+    }
+    // mu_bar and trig' of the block's first step (D.mu = mu_{k0}, D.th = theta: filled by the skeleton)
+    mu_j = D.mu[j];
+    double fd;
+    if (j < r) f4_dyn_eval(p, D, j, (double)(k.k0 + 1), mu_j, mub_j, fd, tp_j);
+    if (lane < 32) L.mub[j] = j < r ? mub_j : 0.0;
+  } else if (isV1) {
+#pragma unroll
+    for (int c = 0; c < 32; ++c) pr[c] = (lane == c && c < r) ? 1.0 : 0.0;
+  } else if (isV2) {
+#pragma unroll
+    for (int c = 0; c < 32; ++c) pr[c] = (c < r) ? L.sK[lane * RB + c] : 0.0;
+  } else {
+    const int c = lane & 31, hf = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < 32; ++t) pr[t] = (32 * hf + t == c && c < r) ? 1.0 : 0.0;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) g[t] = (16 * hf + t < r && c < r) ? L.sK[(16 * hf + t) * RB + c] : 0.0;    // G_0: exact Gram / tracked G
+  }
+  f3_barrier();                                                       // ---- init barrier
+  if (role == 4 && lane == 0) L.tick[0] = (long long)__builtin_amdgcn_s_memrealtime();
+  BLK_T0();
+  for (int jb = 0; jb < k.nb; ++jb) {
+    const long long kstep = k.k0 + jb + 1;
+    // =============================== phase 0: w = V mu_bar, s | a = u - A mu_bar, K a ===============================
+    double cm = 0.0;
+    bool mub_next_ready = false;
+    double tp_prev = tp_j;
+    const double mu_prev = mu_j;
+    if (isV0) {
+      const int j = lane & 31, hf = lane >> 5;
+      if (p.rho_sched) rho = D.rs[jb];
+      double part0 = 0.0, part1 = 0.0;
+#pragma unroll
+      for (int t = 0; t < 16; t += 2) {
+        part0 += pr[t] * L.mub[16 * hf + t];
+        part1 += pr[t + 1] * L.mub[16 * hf + t + 1];
+      }
+      const double part = part0 + part1;
+      s_k = wave_sum_f64_dpp(part * L.mub[j]);
+      kappa = fast_rcp(rho + s_k);
+      eta_k = rho;                                  // tr(R) / d (synthetic_psmf.py:86-87)
+      Nk = s_k + eta_k;
+      invN = fast_rcp(Nk);
+      if (lane == 0) { L.sc[F3_N] = Nk; L.sc[F3_INVN] = invN; }
+      wj = xor32_sum_f64(part);                     // w = V mu_bar
+      if (lane < 32) L.w[lane] = wj;
+    } else if (isV1 || isV2) {
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+      for (int c = 0; c < 32; c += 4) {
+        a0 += pr[c] * L.mub[c];
+        a1 += pr[c + 1] * L.mub[c + 1];
+        a2 += pr[c + 2] * L.mub[c + 2];
+        a3 += pr[c + 3] * L.mub[c + 3];
+      }
+      const double dot = (a0 + a1) + (a2 + a3);
+      if (isV1) {
+        cm = (lane == r + jb ? 1.0 : 0.0) - dot;
+        L.a[lane] = cm;
+        coef_store(k.Bcoef + (size_t)jb * RB + lane, dot);
+      } else {
+        cm = L.sK[lane * RB + r + jb] - dot;
+        L.Ka[lane] = cm;
+      }
+    }
+    BLK_T(0);
+    f3_barrier();                                                     // ---- B1
+    BLK_T(1);
+    // =============================== phase 1: h = A^T K a, ee; rank-1 updates that need only w, N ===============================
+    if (isV3) {
+      const int c = lane & 31, hf = lane >> 5;
+      double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+      for (int t = 0; t < 32; t += 4) {
+        a0 += pr[t] * L.Ka[32 * hf + t];
+        a1 += pr[t + 1] * L.Ka[32 * hf + t + 1];
+        a2 += pr[t + 2] * L.Ka[32 * hf + t + 2];
+        a3 += pr[t + 3] * L.Ka[32 * hf + t + 3];
+      }
+      const double hc = xor32_sum_f64((a0 + a1) + (a2 + a3));
+      if (hf == 0) L.h[c] = hc;
+      const double wn = L.w[c] * L.sc[F3_INVN];
+#pragma unroll
+      for (int t = 0; t < 32; ++t) pr[t] += L.a[32 * hf + t] * wn;      // A^T by columns (psmf.py:130-133 in coefficient space)
+    } else if (isV1 || isV2) {
+      if (isV1) {
+        const double e1 = wave_sum_f64_dpp(cm * L.Ka[lane]);
+        if (lane == 0) L.sc[F3_EE] = e1;
+      }
+      const double cn = cm * L.sc[F3_INVN];
+#pragma unroll
+      for (int c = 0; c < 32; ++c) pr[c] += cn * L.w[c];                // A, K A by rows
+    } else {
+      // wave 4 has nothing to wait for here: the rank-1 part of the V update (w, N are its own) and -- unless theta is stepped
+      // inside the loop -- the next step's mu_bar, which depends on nothing this step computes
+      const int j = lane & 31, hf = lane >> 5;
+      const double wjn = wj * invN;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) pr[t] -= L.w[16 * hf + t] * wjn;    // psmf.py:135-138
+      if (!(p.recursive && has_th)) {
+        mu_j = mub_j;                                                   // mu_k = mu_bar_k (no coefficient update)
+        tp_prev = tp_j;
+        if (lane < 32 && j < r && p.mu_hist) p.mu_hist[(size_t)(kstep - p.series_t0) * r + j] = mu_j;
+        double fd;
+        if (j < r) f4_dyn_eval(p, D, j, (double)(kstep + 1), mu_j, mub_j, fd, tp_j);
+        mub_next_ready = true;
+      }
+    }
+    BLK_T(2);
+    f3_barrier();                                                     // ---- B2
+    BLK_T(1);
+    // =============================== phase 2 (wave 4): V, the scalars, gradient, Adam, the next mu_bar; (wave 7): G ===============================
+    if (isV3) {
+      // G_k = G_{k-1} + (h w^T + w h^T) / N + ee w w^T / N^2 = G + u w^T + w hn^T,  u = h / N + (ee / N^2) w,  hn = h / N
+      const int c = lane & 31, hf = lane >> 5;
+      const double iN = L.sc[F3_INVN], e2 = L.sc[F3_EE] * iN * iN;
+      const double wc = L.w[c], hnc = L.h[c] * iN;
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const double hi = L.h[16 * hf + t], wi = L.w[16 * hf + t];
+        g[t] += (hi * iN + e2 * wi) * wc + wi * hnc;
+      }
+    } else if (isV0) {
+      const int j = lane & 31, hf = lane >> 5;
+      ee_k = L.sc[F3_EE];
+      phi = 1.0; omega = 1.0;
+      double vscale = 1.0;
+      const double lam0 = lam, N0 = Nk;
+      if (p.robust) {
+        const double ild = fast_rcp(lam + dd);
+        phi = (lam + ee_k * invN) * ild;                                // rpsmf.py:133-138
+        omega = (lam + kappa * ee_k) * ild;                             // synthetic_rpsmf.py:91-107: S^-1 = (R + s I)^-1
+        vscale = p.alpha * phi;
+      }
+      if (p.robust) {
+#pragma unroll
+        for (int t = 0; t < 16; ++t) pr[t] *= vscale;
+      }
+      (void)hf;
+      if (has_th) {
+        const double hj = L.h[j];
+        double gf;
+        if (p.robust) {
+          const double Dn = lam0 * N0;
+          gf = dd * wj / N0 + 0.5 * (dd + lam0) * (-2.0 * hj / Dn - 2.0 * lam0 * ee_k * wj / (Dn * Dn)) / (1.0 + ee_k / Dn);
+        } else {
+          gf = dd * wj * invN - hj * invN - ee_k * wj * invN * invN;
+        }
+        // (trig' and mu_{k-1} of THIS step: when the next mu_bar was formed in phase 1 they are the saved ones)
+        const double tpk = mub_next_ready ? tp_prev : tp_j, xk = mub_next_ready ? mu_prev : mu_j;
+        const double ut = gf * tpk;
+        gs_b += ut * (2.0 * M_PI * (double)kstep);
+        if (phased) gs_c += ut * xk;
+        if (p.recursive) {
+          b1k *= p.b1; b2k *= p.b2;
+          if (p.lr_steps > 0.0) lr_k *= lr_g;
+          if ((kstep % p.update_every) == 0) {
+            const double c1 = 1.0 / (1.0 - b1k), c2 = 1.0 / (1.0 - b2k);
+            am_b = p.b1 * am_b + (1.0 - p.b1) * gs_b;
+            av_b = p.b2 * av_b + (1.0 - p.b2) * gs_b * gs_b;
+            const double thb = fmax(D.th[j] - lr_k * (am_b * c1) / (sqrt(av_b * c2) + 1e-8), 0.0);
+            gs_b = 0.0;
+            double thc = 0.0;
+            if (phased) {
+              am_c = p.b1 * am_c + (1.0 - p.b1) * gs_c;
+              av_c = p.b2 * av_c + (1.0 - p.b2) * gs_c * gs_c;
+              thc = fmax(D.th[RM + j] - lr_k * (am_c * c1) / (sqrt(av_c * c2) + 1e-8), 0.0);
+              gs_c = 0.0;
+            }
+            if (own_th) { D.th[j] = thb; if (phased) D.th[RM + j] = thc; }      // (each lane reads back only what it wrote)
+          }
+        }
+      }
+      if (p.robust) { rho *= omega; if (!p.fixed_lambda) lam += dd; }
+      // mu_k = mu_bar_k (no coefficient update); mu_bar_{k+1} = f(theta, mu_k, k + 1)
+      if (!mub_next_ready) {
+        mu_j = mub_j;
+        if (lane < 32 && j < r && p.mu_hist) p.mu_hist[(size_t)(kstep - p.series_t0) * r + j] = mu_j;
+        double fd;
+        if (j < r) f4_dyn_eval(p, D, j, (double)(kstep + 1), mu_j, mub_j, fd, tp_j);
+      }
+      if (lane < 32 && j < r) L.mub[j] = mub_j;       // (read by the other waves in the next phase 0 only)
+    }
+    BLK_T(3);
+    f3_barrier();                                                     // ---- BF
+    BLK_T(1);
+  }
+  BLK_TOUT();
+  if (role == 4 && lane == 0) L.tick[1] = (long long)__builtin_amdgcn_s_memrealtime();
+  // ---- block end ----
+  if (isV1) {
+#pragma unroll
+    for (int c = 0; c < 32; ++c) L.sA[lane * F3_AS + c] = pr[c];
+  }
+  f3_barrier();
+  if (isV0) {
+    const int j = lane & 31, hf = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) st->f3_V[t * 64 + lane] = pr[t];
+    if (k.last) {
+#pragma unroll
+      for (int t = 0; t < 16; ++t) {
+        const int i = 16 * hf + t;
+        if (i < r && j < r) st->V[i * r + j] = pr[t];
+      }
+    }
+    if (lane < r) st->mu[lane] = mu_j;
+    if (own_th) {
+      p.gradsum[jth] = gs_b;
+      if (phased) p.gradsum[r + jth] = gs_c;
+      if (p.recursive) {
+        p.theta[jth] = D.th[jth]; p.adam_m[jth] = am_b; p.adam_v[jth] = av_b;
+        if (phased) { p.theta[r + jth] = D.th[RM + jth]; p.adam_m[r + jth] = am_c; p.adam_v[r + jth] = av_c; }
+      }
+    }
+    if (lane == 0) {
+      st->k = k.k0 + k.nb;
+      st->rho = rho; st->lam = lam; st->phi = phi; st->omega = omega; st->ee = ee_k;
+      st->s_done = s_k; st->eta_done = eta_k; st->N_done = Nk;
+      st->ns_valid = 5;
+      st->cnt[0] += k.nb;            // (no inversion in this mode: every timestep counts as "iterated", none swept)
+    }
+  }
+  if (isV3) {
+    // the tracked G where the K assembly of the next block (f3_assemble_K) and other kernels expect it: T-layout dump, row-major
+    const int c = lane & 31, hf = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) {
+      const int e = hf * 8 + (c >> 4) * 4 + (t >> 2), ln = 16 * (t & 3) + (c & 15);
+      st->f3_G[e * 64 + ln] = g[t];
+      if (k.last && 16 * hf + t < r && c < r) st->G[(16 * hf + t) * r + c] = g[t];
+    }
+  }
+  for (int idx = tid - 256; idx < RB * r; idx += 256) { const int m = idx / r, c = idx - m * r; coef_store(k.Acoef + idx, L.sA[m * F3_AS + c]); }
+}

@@ -308,8 +308,20 @@ bool blk_seq_ok(const psmf_filter* h) {
          h->cfg.r <= 32;
 }
 
+// filter5: the simplified hook configuration (no coefficient update, eta = tr(R) / d, P_bar = P) with diagonal-Jacobian dynamics
+bool blk_simpl_ok(const psmf_filter* h) {
+  const int kd = h->cfg.dyn_kind;
+  const bool diag_dyn = kd == PSMF_DYN_RANDOM_WALK || kd == PSMF_DYN_COS_PHASE || (kd == PSMF_DYN_SINUSOID && !(h->cfg.dyn_flags & 1));
+  return h->sw.filter4 && h->sw.filter3 && !h->cfg.coef_update && !h->cfg.eta_full && !h->cfg.pbar_predict && diag_dyn && h->cfg.r <= 32 &&
+         !h->sp.q_sched;
+}
+
 void launch_blk_filter(psmf_filter* h, const psmf::BlockParams& b, hipStream_t stream = nullptr) {
   if (!stream) stream = h->stream;
+  if (blk_simpl_ok(h)) {
+    hipLaunchKernelGGL(psmf::psmf_blk_filter5, dim3(1), dim3(psmf::F3_NT), psmf::blk_filter3_lds_bytes(), stream, b);
+    return;
+  }
   if (!(blk_dual_ok(h) && blk_use_filter3(h)) && blk_seq_ok(h)) {
     if (h->cfg.r > 16) hipLaunchKernelGGL(psmf::psmf_blk_filter4, dim3(1), dim3(psmf::F3_NT), psmf::blk_filter3_lds_bytes(), stream, b);
     else hipLaunchKernelGGL(psmf::psmf_blk_filter4s, dim3(1), dim3(psmf::F3_NT), psmf::blk_filter3_lds_bytes(), stream, b);
@@ -411,7 +423,7 @@ int enqueue_blocks_pipelined(psmf_filter* h, int64_t k_begin, int64_t k_end) {
   h->seq_next += nblk;
   // chain: the filter kernels of the whole run as ONE launch (psmf_blk_filter3; the bulk stream is driven as before)
   const bool chain_off = !h->sw.block_chain;
-  const bool chain = use_flags && !chain_off && nblk > 1 && ((blk_dual_ok(h) && blk_use_filter3(h)) || blk_seq_ok(h));
+  const bool chain = use_flags && !chain_off && nblk > 1 && ((blk_dual_ok(h) && blk_use_filter3(h)) || blk_seq_ok(h) || blk_simpl_ok(h));
   // first block: plain Gram of the stored C
   fill_block_params(h, b, k0_of(0), nb_of(0), 0);
   launch_blk_gram(h, b, h->bulk);
@@ -778,6 +790,7 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_filter3s, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psmf::blk_filter3_lds_bytes()));
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_filter4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psmf::blk_filter3_lds_bytes()));
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_filter4s, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psmf::blk_filter3_lds_bytes()));
+    CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_filter5, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psmf::blk_filter3_lds_bytes()));
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_xgram2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psmf::blk_xgram2_lds_bytes()));
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_xgram2<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psmf::blk_xgram2_lds_bytes()));
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_apply2<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)psmf::blk_apply2_lds_bytes()));
@@ -1231,6 +1244,7 @@ int psmf_debug_read(psmf_handle h, double* out, int n) {
 int psmf_filter_kernel(psmf_handle h) {
   if (!h) return PSMF_ERR_ARG;
   if (h->engine != 2) return 0;
+  if (blk_simpl_ok(h)) return 7;
   if (blk_dual_ok(h) && blk_use_filter3(h)) return h->cfg.r > 16 ? 3 : 4;
   if (blk_seq_ok(h)) return h->cfg.r > 16 ? 5 : 6;
   if (blk_dual_ok(h)) return 2;

@@ -133,6 +133,8 @@ def test_simplified_cos_mode(robust, storage, engine):
     f = c.DeviceFilter(d, r, storage=storage, dyn_kind=c.DYN_COS_PHASE, engine=engine, **_mode_kwargs(mode))
     f.upload_series(Y)
     f.set_state(g["C0"], g["V0"], g["P0"], np.zeros((r, r)), g["mu0"], rho=1.0, lambda0=1.8, theta=g["theta0"])
+    if engine == "block":       # the simplified hooks with a diagonal-Jacobian f: the vector-program kernel (psmf_blk4.hip, filter5)
+        assert f.geometry()["filter_kernel"] == "psmf_blk_filter5"
     f.zero_gradsum()
     f.run(0, T)
     s = f.get_state()

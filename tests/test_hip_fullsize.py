@@ -277,3 +277,33 @@ def test_filter4_cos_phase_at_size(robust, q, recursive):
             assert relerr(s["gradsum"], st.gradsum) < 10 * tol
         assert cnt["ns_steps"] + cnt["sweep_steps"] == Tn
         f.close()
+
+
+@pytest.mark.parametrize("robust", [False, True], ids=["PSMF", "rPSMF"])
+def test_filter5_simplified_cos_phase_at_size(robust):
+    """The ExperimentSynthetic configuration (simplified hooks, f = cos(2 pi theta t + x): synthetic_psmf.py:78-106,
+    synthetic_rpsmf.py:82-124) at d = 20 000, r = 20, T = 1 000, f32 storage, on psmf_blk_filter5 -- state, predictions and the
+    theta gradient against the oracle.  (Unlike the full filter this recursion is stable: mu_k = mu_bar_k does not see the data.)"""
+    c = _capi()
+    d, r, T = 20_000, 20, 1_000
+    Y, C0 = _bench_problem(d, r, T, robust)
+    theta0 = 1e-3 * np.arange(1, r + 1) + 0.01 * np.random.default_rng(5).random(r)
+    V0, P0, Q = 0.1 * np.eye(r), np.zeros((r, r)), np.zeros((r, r))
+    mode = O.Mode(robust=robust, coef_update=False, eta_full=False, pbar_predict=False)
+    mu0 = np.random.default_rng(6).standard_normal(r)
+    st = O.State(C=C0, V=V0, mu=mu0, P=P0, Q=Q, rho=1.0, lam=1.8, theta=theta0.copy(), gradsum=np.zeros(r))
+    st, Yp, _ = O.run_epoch(st, Y.astype(np.float64), mode, O.CosPhaseDyn(r))
+    f = c.DeviceFilter(d, r, robust=robust, storage="f32", dyn_kind=c.DYN_COS_PHASE, coef_update=False, eta_full=False, pbar_predict=False)
+    f.upload_series(Y)
+    f.set_state(C0, V0, P0, Q, mu0, rho=1.0, lambda0=1.8, theta=theta0)
+    assert f.geometry()["filter_kernel"] == "psmf_blk_filter5"
+    f.zero_gradsum()
+    f.run(0, T)
+    s = f.get_state()
+    for name in ("C", "V", "mu"):
+        assert relerr(s[name], getattr(st, name)) < TOL, (name, relerr(s[name], getattr(st, name)))
+    assert relerr(f.y_pred(0, T), Yp) < TOL
+    assert relerr(s["gradsum"], st.gradsum) < 10 * TOL
+    if robust:
+        assert relerr(s["rho"], st.rho) < TOL and relerr(s["lam"], st.lam) < 1e-12
+    f.close()
