@@ -214,6 +214,41 @@ def run_filter_config(_capi, name, d, r, T, robust, passes=3):
             "hbm_frac_step_at_a_time": (T / steady) * 8.0 * d * (r + 1) / (HBM_PEAK_GBS * 1e9)}
 
 
+def run_synthetic_simplified(_capi, d=10_000, r=20, T=5_000, robust=False, passes=3):
+    """ExperimentSynthetic's own hook configuration (synthetic_psmf.py:78-106: P_bar = P_{k-1}, eta = tr R / d, no coefficient
+    update, f = cos(2 pi theta t + x)) at config B's size: throughput and parity against the oracle on the first 300 timesteps."""
+    from oracle import psmf_oracle as O
+
+    seed = 35833 if robust else 35853
+    series = Series(d, r, T, seed, 0, d, robust)
+    st0 = init_state(d, r, seed)
+    theta0 = 0.1 * np.random.default_rng(seed + 1).random(r)        # synthetic_psmf.py:128: theta0 = 0.1 * rand(r, 1)
+    P0, Q0 = np.zeros((r, r)), np.zeros((r, r))                     # synthetic_psmf.py:131-132
+    f = _capi.DeviceFilter(d, r, robust=robust, storage="f32", dyn_kind=_capi.DYN_COS_PHASE, coef_update=False, eta_full=False, pbar_predict=False)
+    for a, Yc in series.chunks(chunk=1000):
+        f.upload_series(Yc, t0=a, T_total=T)
+    reset = lambda: f.set_state(st0["C"], st0["V"], P0, Q0, st0["mu"], rho=st0["rho"], lambda0=st0["lam"], theta=theta0)
+    n_par = 300
+    Y = np.vstack([Yc for _, Yc in series.chunks(chunk=n_par)][:1])[:n_par].astype(np.float64)
+    st = O.State(C=st0["C"].copy(), V=st0["V"].copy(), mu=st0["mu"].copy(), P=P0, Q=Q0, rho=st0["rho"], lam=st0["lam"], theta=theta0.copy(), gradsum=np.zeros(r))
+    st, _, _ = O.run_epoch(st, Y, O.Mode(robust=robust, coef_update=False, eta_full=False, pbar_predict=False), O.CosPhaseDyn(r))
+    reset(); f.zero_gradsum()
+    f.run(0, n_par)
+    s = f.get_state()
+    rel = lambda a, b_: float(np.max(np.abs(a - b_)) / np.max(np.abs(b_)))
+    par = dict(steps=n_par, C=rel(s["C"], st.C), V=rel(s["V"], st.V), mu=rel(s["mu"], st.mu), gradsum=rel(s["gradsum"], st.gradsum))
+    reset(); f.run(0, T); reset(); f.sync()
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        f.run(0, T, sync=False)
+    f.sync()
+    dt = (time.perf_counter() - t0) / passes
+    geo = f.geometry()
+    f.close()
+    return {"workload": f"{'rPSMF' if robust else 'PSMF'} with ExperimentSynthetic's simplified hooks, f = cos(2 pi theta t + x), d={d} r={r} T={T}, f32 storage, 1 GPU",
+            "value": T / dt, "unit": "timesteps/s", "us_per_timestep": 1e6 * dt / T, "kernel": geo["filter_kernel"], "parity_vs_cpu_oracle": par}
+
+
 def run_impute_config(seeds=50, n=295_719, d=19, r=10, n_par=3000, variants=(False, True)):
     """Config D: masked filter, gas-sensor shape (the CSV is not in the reference checkout: synthetic stand-in of the same
     shape), 40 % missing, `seeds` replicas in one launch; parity of replica 0 on an n_par-column prefix against the oracle."""
@@ -531,6 +566,10 @@ def main():
                         other[name] = run_filter_config(_capi, name, 10_000, 20, 5_000, rob)
                     except Exception as e:
                         other[name] = {"error": repr(e)}
+                try:
+                    other["ExperimentSynthetic_hooks"] = run_synthetic_simplified(_capi)
+                except Exception as e:
+                    other["ExperimentSynthetic_hooks"] = {"error": repr(e)}
                 try:
                     other["D"] = run_impute_config()
                 except Exception as e:

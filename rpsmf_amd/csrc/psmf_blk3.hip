@@ -1117,7 +1117,10 @@ __device__ __forceinline__ void blk_filter3_body(const BlockParams& b0) {
   if (KIND == 2) {
     // filter5 (psmf_blk4.hip): the simplified hooks -- the vector program alone; waves 0-3 keep the barrier count
     if (role < 4) f5_idle_program(k);
-    else f5_v_program(b, k, L, D, role, lane, carried);
+    else if (role == 4) f5_v_program<4>(b, k, L, D, lane, carried);
+    else if (role == 5) f5_v_program<5>(b, k, L, D, lane, carried);
+    else if (role == 6) f5_v_program<6>(b, k, L, D, lane, carried);
+    else f5_v_program<7>(b, k, L, D, lane, carried);
   } else if (KIND == 1) {
     // filter4 (psmf_blk4.hip): waves 0-1 the X pair (P+), 2-3 the Y pair (Lbar), 4-7 the vector waves
     const int md = SMALL ? 2 : (r == 32 ? 0 : 1);

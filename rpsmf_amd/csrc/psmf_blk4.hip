@@ -1045,13 +1045,17 @@ __device__ __forceinline__ void f5_idle_program(const F3Blk& k) {
   f3_barrier();                                                       // block end
 }
 
-__device__ __forceinline__ void f5_v_program(const BlockParams& b, const F3Blk& k, const F3Lds& L, const F4Lds& D, const int role, const int lane,
+// ROLE is a compile-time constant: each of the four waves gets a loop that holds only its own registers (with the role as a
+// run-time value the allocator kept the union of all four live: 227 spilled registers in a program that needs ~100)
+template <int ROLE>
+__device__ __forceinline__ void f5_v_program(const BlockParams& b, const F3Blk& k, const F3Lds& L, const F4Lds& D, const int lane,
                                              const bool carried) {
   const StepParams& p = b.sp;
   DevState* st = p.st;
+  constexpr int role = ROLE;
   const int r = p.r, tid = 64 * role + lane;
   const double dd = (double)p.d;
-  const bool isV0 = role == 4, isV1 = role == 5, isV2 = role == 6, isV3 = role == 7;
+  constexpr bool isV0 = ROLE == 4, isV1 = ROLE == 5, isV2 = ROLE == 6, isV3 = ROLE == 7;
   double pr[32];
 #pragma unroll
   for (int i = 0; i < 32; ++i) pr[i] = 0.0;
@@ -1064,7 +1068,7 @@ __device__ __forceinline__ void f5_v_program(const BlockParams& b, const F3Blk& 
   double gs_b = 0.0, gs_c = 0.0, am_b = 0.0, av_b = 0.0, am_c = 0.0, av_c = 0.0;
   double b1k = 1.0, b2k = 1.0, lr_k = p.lr, lr_g = 1.0;
   double mu_j = 0.0, mub_j = 0.0, tp_j = 0.0;         // wave 4, lane j: mu_{k-1,j}, mu_bar_{k,j}, trig'(arg_kj)
-  // wave 7 also tracks G = C^T C (rank-2 update per timestep): the next block's K is assembled from it
+  // wave 6 also tracks G = C^T C (rank-2 update per timestep): the next block's K is assembled from it
   // (K A_0 = the first r columns of K).  Layout: lane = (column c = lane & 31, half hf = lane >> 5), g[t] = G[16 hf + t][c].
   double g[16];
 #pragma unroll
@@ -1104,14 +1108,15 @@ __device__ __forceinline__ void f5_v_program(const BlockParams& b, const F3Blk& 
 #pragma unroll
     for (int c = 0; c < 32; ++c) pr[c] = (lane == c && c < r) ? 1.0 : 0.0;
   } else if (isV2) {
+    const int c = lane & 31, hf = lane >> 5;
 #pragma unroll
-    for (int c = 0; c < 32; ++c) pr[c] = (c < r) ? L.sK[lane * RB + c] : 0.0;
+    for (int cc = 0; cc < 32; ++cc) pr[cc] = (cc < r) ? L.sK[lane * RB + cc] : 0.0;
+#pragma unroll
+    for (int t = 0; t < 16; ++t) g[t] = (16 * hf + t < r && c < r) ? L.sK[(16 * hf + t) * RB + c] : 0.0;    // G_0: exact Gram / tracked G
   } else {
     const int c = lane & 31, hf = lane >> 5;
 #pragma unroll
     for (int t = 0; t < 32; ++t) pr[t] = (32 * hf + t == c && c < r) ? 1.0 : 0.0;
-#pragma unroll
-    for (int t = 0; t < 16; ++t) g[t] = (16 * hf + t < r && c < r) ? L.sK[(16 * hf + t) * RB + c] : 0.0;    // G_0: exact Gram / tracked G
   }
   f3_barrier();                                                       // ---- init barrier
   if (role == 4 && lane == 0) L.tick[0] = (long long)__builtin_amdgcn_s_memrealtime();
@@ -1176,9 +1181,6 @@ __device__ __forceinline__ void f5_v_program(const BlockParams& b, const F3Blk& 
       }
       const double hc = xor32_sum_f64((a0 + a1) + (a2 + a3));
       if (hf == 0) L.h[c] = hc;
-      const double wn = L.w[c] * L.sc[F3_INVN];
-#pragma unroll
-      for (int t = 0; t < 32; ++t) pr[t] += L.a[32 * hf + t] * wn;      // A^T by columns (psmf.py:130-133 in coefficient space)
     } else if (isV1 || isV2) {
       if (isV1) {
         const double e1 = wave_sum_f64_dpp(cm * L.Ka[lane]);
@@ -1208,6 +1210,12 @@ __device__ __forceinline__ void f5_v_program(const BlockParams& b, const F3Blk& 
     BLK_T(1);
     // =============================== phase 2 (wave 4): V, the scalars, gradient, Adam, the next mu_bar; (wave 7): G ===============================
     if (isV3) {
+      // A^T by columns (psmf.py:130-133 in coefficient space): a, w, N of this step are stable until the next step's phases 0 / 0 / 0
+      const int c = lane & 31, hf = lane >> 5;
+      const double wn = L.w[c] * L.sc[F3_INVN];
+#pragma unroll
+      for (int t = 0; t < 32; ++t) pr[t] += L.a[32 * hf + t] * wn;
+    } else if (isV2) {
       // G_k = G_{k-1} + (h w^T + w h^T) / N + ee w w^T / N^2 = G + u w^T + w hn^T,  u = h / N + (ee / N^2) w,  hn = h / N
       const int c = lane & 31, hf = lane >> 5;
       const double iN = L.sc[F3_INVN], e2 = L.sc[F3_EE] * iN * iN;
@@ -1318,7 +1326,7 @@ __device__ __forceinline__ void f5_v_program(const BlockParams& b, const F3Blk& 
       st->cnt[0] += k.nb;            // (no inversion in this mode: every timestep counts as "iterated", none swept)
     }
   }
-  if (isV3) {
+  if (isV2) {
     // the tracked G where the K assembly of the next block (f3_assemble_K) and other kernels expect it: T-layout dump, row-major
     const int c = lane & 31, hf = lane >> 5;
 #pragma unroll

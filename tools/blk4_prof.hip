@@ -31,13 +31,16 @@ int main(int argc, char** argv) {
   hipMemcpy(th, thh.data(), 64 * 8, hipMemcpyHostToDevice);
   hipMemcpy(dK, K.data(), RB * RB * 8, hipMemcpyHostToDevice);
   BlockParams b{}; b.sp.st = st; b.sp.r = r; b.sp.d = dd; b.sp.d_local = dd; b.sp.use_ns = getenv("NS") ? atoi(getenv("NS")) : 1; b.sp.coef_update = 1; b.sp.eta_full = 1; b.sp.pbar_predict = 1;
+  const int mode5 = getenv("MODE") && atoi(getenv("MODE")) == 5;
+  if (mode5) { b.sp.coef_update = 0; b.sp.eta_full = 0; b.sp.pbar_predict = 0; }
   b.sp.alpha = b.sp.beta = 1.0; b.sp.ns_predict = 7; b.sp.ns_far2 = 0.09; b.sp.ns_tol2 = getenv("TOL") ? atof(getenv("TOL")) * atof(getenv("TOL")) : 9e-8;
   b.sp.dyn_kind = DYN_COS_PHASE; b.sp.n_theta = r; b.sp.theta = th; b.sp.gradsum = th + 64; b.sp.adam_m = th + 128; b.sp.adam_v = th + 192; b.sp.update_every = 1;
   b.K = dK; b.Acoef = dA; b.Bcoef = dB; b.Kpart = dKp; b.k0 = 0; b.nb = nb; b.last = 1;
   const size_t lds = blk_filter3_lds_bytes();
   hipFuncSetAttribute((const void*)psmf_blk_filter4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipFuncSetAttribute((const void*)psmf_blk_filter4s, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  auto go = [&]() { if (r > 16) psmf_blk_filter4<<<1, F3_NT, lds>>>(b); else psmf_blk_filter4s<<<1, F3_NT, lds>>>(b); };
+  hipFuncSetAttribute((const void*)psmf_blk_filter5, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  auto go = [&]() { if (mode5) psmf_blk_filter5<<<1, F3_NT, lds>>>(b); else if (r > 16) psmf_blk_filter4<<<1, F3_NT, lds>>>(b); else psmf_blk_filter4s<<<1, F3_NT, lds>>>(b); };
   for (int it = 0; it < 40; ++it) go();
   hipDeviceSynchronize();
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
@@ -50,7 +53,8 @@ int main(int argc, char** argv) {
   printf("r=%d q=%g use_ns=%d: block of %d steps: %.1f us = %.2f us/step (%s); last block: ns %lld sweep %lld decides %lld failed %lld\n", r, q, b.sp.use_ns, nb, ms * 1e3, ms * 1e3 / nb,
          hipGetErrorString(hipGetLastError()), c1[0] - c0[0], c1[1] - c0[1], c1[2] - c0[2], c1[3] - c0[3]);
   const char* nx[8] = {"-", "barrier waits", "phase 1 (M, it 0)", "phase 2 (it 1, G)", "more iterations + sweep", "phase F", "Y control", "phase 0"};
-  for (int w : {0, 2, 4, 7}) {
+  for (int w : {0, 2, 4, 5, 6, 7}) {
+    if (mode5 && w < 4) continue;
     printf("wave %d (%s):", w, w < 2 ? "X" : (w < 4 ? "Y" : "V"));
     if (w < 4) { for (int qq = 1; qq < 8; ++qq) printf("  %s %.0f", nx[qq], (double)h[w * 12 + qq] / nb); }
     else { for (int qq = 0; qq < 5; ++qq) printf("  [%d] %.0f", qq, (double)h[w * 12 + qq] / nb); }
