@@ -691,12 +691,14 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Blk&
 // ------------------------------------------------------------------------------------------------------------
 // Program of the four vector waves: 4 = V and every scalar, 5 = A by rows, 6 = KA by rows, 7 = A^T by columns.
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void f3_v_program(const BlockParams& b, const F3Blk& k, const F3Lds& L, const int role, const int lane, const bool carried) {
+template <int ROLE>
+__device__ __forceinline__ void f3_v_program(const BlockParams& b, const F3Blk& k, const F3Lds& L, const int lane, const bool carried) {
   const StepParams& p = b.sp;
   DevState* st = p.st;
+  constexpr int role = ROLE;
   const int r = p.r, r2 = r + (r & 1), tid = 64 * role + lane;
   const double dd = (double)p.d, idd = 1.0 / dd;
-  const bool isV0 = role == 4, isV1 = role == 5, isV2 = role == 6, isV3 = role == 7;
+  constexpr bool isV0 = ROLE == 4, isV1 = ROLE == 5, isV2 = ROLE == 6, isV3 = ROLE == 7;
   // Each vector wave shares its SIMD with an inversion wave.  At equal priority its ~60 VALU instructions per phase were
   // issued about one per MFMA (64 cycles) and the barrier waited for THEM (3.7k cycles against 3.1k, stamps); with
   // priority they issue back to back and cost the MFMA stream a few hundred cycles instead.
@@ -1148,7 +1150,10 @@ __device__ __forceinline__ void blk_filter3_body(const BlockParams& b0) {
       else f3_ns_program<0, 1>(b, k, L, inv, role, lane, carried);
     }
   } else {
-    f3_v_program(b, k, L, role, lane, carried);
+    if (role == 4) f3_v_program<4>(b, k, L, lane, carried);
+    else if (role == 5) f3_v_program<5>(b, k, L, lane, carried);
+    else if (role == 6) f3_v_program<6>(b, k, L, lane, carried);
+    else f3_v_program<7>(b, k, L, lane, carried);
   }
   if (tid == 0) {
     // cnt[4]: sum of in-kernel durations, cnt[5]: sum of the gaps to the previous filter kernel, cnt[7]: launches (10 ns ticks)
