@@ -1135,7 +1135,10 @@ __device__ __forceinline__ void blk_filter3_body(const BlockParams& b0) {
       else if (md == 0) { if (role & 1) f4_y_program<1, 0>(b, k, L, D, role, lane, carried, warm && carried); else f4_y_program<0, 0>(b, k, L, D, role, lane, carried, warm && carried); }
       else { if (role & 1) f4_y_program<1, 1>(b, k, L, D, role, lane, carried, warm && carried); else f4_y_program<0, 1>(b, k, L, D, role, lane, carried, warm && carried); }
     } else {
-      f4_v_program(b, k, L, D, role, lane, carried, warm && carried);
+      if (role == 4) f4_v_program<4>(b, k, L, D, lane, carried, warm && carried);
+      else if (role == 5) f4_v_program<5>(b, k, L, D, lane, carried, warm && carried);
+      else if (role == 6) f4_v_program<6>(b, k, L, D, lane, carried, warm && carried);
+      else f4_v_program<7>(b, k, L, D, lane, carried, warm && carried);
     }
   } else if (role < 4) {
     const int inv = role >> 1;

@@ -693,13 +693,15 @@ __device__ __forceinline__ void f4_y_program(const BlockParams& b, const F3Blk& 
 // Vector waves: filter3's program (4 = V and every scalar, 5 = A by rows, 6 = KA by rows, 7 = A^T by columns and the start
 // predictor's 2 x 2 core) with the step control of this kernel; wave 4 also runs the R_k / Q_k schedules and the theta path.
 // ------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void f4_v_program(const BlockParams& b, const F3Blk& k, const F3Lds& L, const F4Lds& D, const int role, const int lane,
+template <int ROLE>       // compile-time role: one loop per wave, holding only its own registers (see f5_v_program)
+__device__ __forceinline__ void f4_v_program(const BlockParams& b, const F3Blk& k, const F3Lds& L, const F4Lds& D, const int lane,
                                              const bool carried, const bool warm) {
   const StepParams& p = b.sp;
   DevState* st = p.st;
+  constexpr int role = ROLE;
   const int r = p.r, r2 = r + (r & 1), tid = 64 * role + lane;
   const double dd = (double)p.d, idd = 1.0 / dd;
-  const bool isV0 = role == 4, isV1 = role == 5, isV2 = role == 6, isV3 = role == 7;
+  constexpr bool isV0 = ROLE == 4, isV1 = ROLE == 5, isV2 = ROLE == 6, isV3 = ROLE == 7;
   __builtin_amdgcn_s_setprio(3);
   double pr[32];
 #pragma unroll
