@@ -14,6 +14,5 @@ find gpurun_out/r3p -name "*kernel_stats.csv" -exec cp {} gpurun_out/r3p/kernel_
 find gpurun_out/r3p -name "*kernel_trace.csv" -size +10M -delete || true
 du -sh gpurun_out/r3p
 # the general-dynamics kernels under the profiler: per-kernel durations of the cos-phase full filter (psmf_blk_filter4) and FourierBasis (psmf_blk_filter)
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r3p/kt_modes -- python3 tools/probe_modes.py > gpurun_out/r3p/modes_under_rocprof.txt 2> gpurun_out/r3p/kt_modes.err || true
-find gpurun_out/r3p/kt_modes -name "*kernel_stats.csv" -exec cp {} gpurun_out/r3p/kernel_stats_modes.csv \; || true
+# (rocprofv3 segfaults in its CSV writer on the many short launches of tools/probe_modes.py on this image: no kernel stats of the modes)
 find gpurun_out/r3p -name "*kernel_trace.csv" -size +10M -delete || true
