@@ -1156,11 +1156,14 @@ int psmf_time_kernel(psmf_handle h, int which, int iters, float* avg_us) {
     fill_block_params(h, b, h->sp.series_t0, nb);
     HIP_TRY(h, hipStreamSynchronize(h->stream));
     const size_t cbytes = (size_t)h->cfg.d_local * h->geo.rp * h->elem();
-    void* Csave = nullptr; DevState* ssave = nullptr;
+    void* Csave = nullptr; DevState* ssave = nullptr; double* thsave = nullptr;
+    const size_t thbytes = 4 * h->th_cap * sizeof(double);     // theta, gradient sums, Adam moments: the filter kernels step them too
     HIP_TRY(h, hipMalloc(&Csave, cbytes));
     HIP_TRY(h, hipMalloc((void**)&ssave, sizeof(DevState)));
+    HIP_TRY(h, hipMalloc((void**)&thsave, thbytes));
     HIP_TRY(h, hipMemcpy(Csave, h->C, cbytes, hipMemcpyDeviceToDevice));
     HIP_TRY(h, hipMemcpy(ssave, h->st, sizeof(DevState), hipMemcpyDeviceToDevice));
+    HIP_TRY(h, hipMemcpy(thsave, h->thbuf, thbytes, hipMemcpyDeviceToDevice));
     launch_blk_gram(h, b);           // a valid K for the filter / apply measurements
     launch_blk_filter(h, b);
     auto one = [&]() {
@@ -1189,8 +1192,10 @@ int psmf_time_kernel(psmf_handle h, int which, int iters, float* avg_us) {
     *avg_us = ms * 1000.f / iters;
     HIP_TRY(h, hipMemcpy(h->C, Csave, cbytes, hipMemcpyDeviceToDevice));
     HIP_TRY(h, hipMemcpy(h->st, ssave, sizeof(DevState), hipMemcpyDeviceToDevice));
+    HIP_TRY(h, hipMemcpy(h->thbuf, thsave, thbytes, hipMemcpyDeviceToDevice));
     HIP_TRY(h, hipFree(Csave));
     HIP_TRY(h, hipFree(ssave));
+    HIP_TRY(h, hipFree(thsave));
     return PSMF_OK;
   }
   if (h->need_prep) { rc = prepare(h, h->k_done); if (rc) return rc; }

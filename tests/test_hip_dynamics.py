@@ -386,3 +386,52 @@ def test_nonuniform_diagonal_R_on_device(robust):
         yp = np.array([f._y_pred[k].reshape(-1) for k in range(1, T + 1)])
         assert relerr(yp, Yp) < 1e-9
         f.optim_update(i)          # theta is empty; creates _theta[i] for the next epoch as the reference's run() does
+
+
+@pytest.mark.parametrize("robust", [False, True], ids=["PSMF", "rPSMF"])
+@pytest.mark.parametrize("kind", ["cos_phase", "sinusoid_unscaled"])
+@pytest.mark.parametrize("recursive", [False, True], ids=["epoch", "recursive"])
+def test_simplified_hooks_kernel_vs_oracle(kind, robust, recursive):
+    """psmf_blk_filter5: the simplified hook configuration (synthetic_psmf.py:78-100, synthetic_rpsmf.py:82-118) with a
+    diagonal-Jacobian f, PSMF and rPSMF, with the gradient summed over the epoch or Adam stepping theta inside the loop
+    (update_every = 2) -- against the oracle on the same callable (complex-step derivatives), float64 storage."""
+    c = _capi()
+    d, r, T, ue = 500, 12, 110, 2
+    nl = NL.CosPhase(r) if kind == "cos_phase" else NL.Sinusoid(r, scaled=False)
+    rng = np.random.default_rng(31 + r)
+    Y, C0 = _problem(d, r, T, 77)
+    theta = 0.1 * rng.random(nl.n_params)
+    V0, P0, Q = 0.1 * np.eye(r), 0.3 * np.eye(r), 0.05 * np.eye(r)
+    mu0 = 0.2 * rng.standard_normal(r)
+    mode = O.Mode(robust=robust, coef_update=False, eta_full=False, pbar_predict=False)
+    dyn = O.CallableDyn(nl, nl.n_params)
+    st = O.State(C=C0, V=V0, mu=mu0, P=P0, Q=Q, rho=1.0, lam=1.8, theta=theta.copy(), gradsum=np.zeros(nl.n_params))
+    Yp = np.empty((T, d))
+    m = v = np.zeros(nl.n_params)
+    for k in range(1, T + 1):
+        st, info = O.lowrank_step(st, Y[k - 1], k, mode, dyn)
+        Yp[k - 1] = info.y_pred
+        if recursive and k % ue == 0:
+            st.theta, m, v = O.adam_update(st.theta, st.gradsum, m, v, k)
+            st.gradsum = np.zeros(nl.n_params)
+    kw = dict(recursive=True, update_every=ue, adam_lr=1e-3) if recursive else {}
+    f = c.DeviceFilter(d, r, robust=robust, storage="f64", dyn_kind=nl.device_kind, dyn_flags=nl.device_flags, dyn_terms=nl.device_terms,
+                       coef_update=False, eta_full=False, pbar_predict=False, **kw)
+    f.upload_series(Y)
+    f.set_state(C0, V0, P0, Q, mu0, rho=1.0, lambda0=1.8, theta=theta)
+    assert f.geometry()["filter_kernel"] == "psmf_blk_filter5"
+    f.zero_gradsum()
+    if recursive:
+        f.set_adam(np.zeros(nl.n_params), np.zeros(nl.n_params))
+    f.run(0, 60)
+    f.run(60, T)                      # carried state, a second chain
+    s = f.get_state()
+    for name in ("C", "V", "mu", "P"):
+        assert relerr(s[name], getattr(st, name)) < 1e-8, name
+    assert relerr(f.y_pred(0, T), Yp) < 1e-8
+    assert relerr(s["theta"], st.theta) < 1e-8
+    if st.gradsum is not None and np.max(np.abs(st.gradsum)) > 0:
+        assert relerr(s["gradsum"], st.gradsum) < 1e-7
+    if robust:
+        assert relerr(s["rho"], st.rho) < 1e-9 and relerr(s["lam"], st.lam) < 1e-12
+    f.close()
