@@ -55,16 +55,20 @@ class HostGroup:
         return f
 
 
-def _run(c, nshards, d, r, Y, C0, st0, T, *, engine, storage, robust, env=None):
-    """nshards = 0: plain unsharded handle.  Returns (per-shard get_state dicts, per-shard y_pred, group)."""
+def _run(c, nshards, d, r, Y, C0, st0, T, *, engine, storage, robust, env=None, extra=None, theta=None, want_kernel=None):
+    """nshards = 0: plain unsharded handle.  Returns (per-shard get_state dicts, per-shard y_pred, group).
+    `extra`: further DeviceFilter keywords (dynamics kind, hook configuration), `theta` its parameters."""
     old = {k: os.environ.get(k) for k in (env or {})}
     os.environ.update(env or {})
     try:
-        kw = dict(storage=storage, engine=engine, robust=robust)
+        kw = dict(storage=storage, engine=engine, robust=robust, **(extra or {}))
+        skw = dict(rho=1.0, lambda0=1.8) if theta is None else dict(rho=1.0, lambda0=1.8, theta=theta)
         if nshards == 0:
             f = c.DeviceFilter(d, r, **kw)
             f.upload_series(Y)
-            f.set_state(C0, *st0, rho=1.0, lambda0=1.8)
+            f.set_state(C0, *st0, **skw)
+            if want_kernel:
+                assert f.geometry()["filter_kernel"] == want_kernel, f.geometry()
             f.run(0, T // 2)                    # the same two runs as the shards (same block boundaries)
             f.run(T // 2, T)
             out = [f.get_state()], [f.y_pred(0, T)], None
@@ -79,7 +83,9 @@ def _run(c, nshards, d, r, Y, C0, st0, T, *, engine, storage, robust, env=None):
                 f = c.DeviceFilter(d, r, row0=row0, d_local=dl, **kw)
                 f.comm_init_host(nshards, rank, grp.allreduce(rank))
                 f.upload_series(np.ascontiguousarray(Y[:, row0:row0 + dl]))
-                f.set_state(C0[row0:row0 + dl], *st0, rho=1.0, lambda0=1.8)
+                f.set_state(C0[row0:row0 + dl], *st0, **skw)
+                if want_kernel:
+                    assert f.geometry()["filter_kernel"] == want_kernel, f.geometry()
                 f.run(0, T // 2)                # two runs: the state carried between runs is sharded state too
                 f.run(T // 2, T)
                 states[rank] = f.get_state()
@@ -156,6 +162,42 @@ def test_shards_on_one_gpu_equal_unsharded(engine, storage, d, r, T, nshards, en
         B = 64 - r
         # pipelined: per run one first-block Gram (64 x 64) and one cross-Gram (128 x 64) per further block
         assert set(grp.sizes) <= {64 * 64, 128 * 64}
+
+
+DYN_CASES = [
+    # name, DeviceFilter keywords, kernel expected, r, T, tolerance against the unsharded run
+    # (the full cos-phase filter amplifies a last-bit difference by 1e5 per 50 steps, DESIGN 2c: short horizon, loose bound)
+    ("cos-phase full", dict(), "psmf_blk_filter4", 20, 88, 1e-6),
+    ("cos-phase simplified", dict(coef_update=False, eta_full=False, pbar_predict=False), "psmf_blk_filter5", 20, 176, 1e-9),
+    ("cos-phase simplified r=32", dict(coef_update=False, eta_full=False, pbar_predict=False), "psmf_blk_filter5", 32, 128, 1e-9),
+]
+
+
+@pytest.mark.parametrize("robust", [False, True], ids=["PSMF", "rPSMF"])
+@pytest.mark.parametrize("name,extra,kernel,r,T,tol", DYN_CASES, ids=[c[0] for c in DYN_CASES])
+def test_shards_of_the_diagonal_dynamics_kernels_equal_unsharded(name, extra, kernel, r, T, tol, robust):
+    """psmf_blk_filter4 / psmf_blk_filter5 under a host communicator: the cross-Gram K of every block is summed over the
+    shards, theta and the gradient sum are replicated (bit-identical), the gathered C and y_hat equal the unsharded run."""
+    c = _capi()
+    d = 3001
+    extra = dict(extra, dyn_kind=c.DYN_COS_PHASE)
+    Y = O.synthetic_series(d, r, T, 77 + r, noise="t" if robust else "normal", dtype=np.float64)
+    rng = np.random.default_rng(5 + r)
+    C0 = 0.1 * rng.standard_normal((d, r))
+    theta = 0.05 + 0.1 * rng.random(r)
+    st0 = (0.1 * np.eye(r), np.eye(r), 0.1 * np.eye(r), np.zeros(r))
+    kw = dict(engine="block", storage="f64", robust=robust, extra=extra, theta=theta, want_kernel=kernel)
+    ref_s, ref_y, _ = _run(c, 0, d, r, Y, C0, st0, T, **kw)
+    for nshards in (2, 3):
+        sh_s, sh_y, grp = _run(c, nshards, d, r, Y, C0, st0, T, **kw)
+        assert all(n == grp.calls[0] for n in grp.calls) and grp.calls[0] > 0
+        for k in ("V", "P", "mu", "rho", "lam", "gradsum"):
+            for s in sh_s[1:]:
+                assert np.array_equal(np.asarray(s[k]), np.asarray(sh_s[0][k])), k
+        C = np.vstack([s["C"] for s in sh_s])
+        assert relerr(C, ref_s[0]["C"]) < tol and relerr(np.hstack(sh_y), ref_y[0]) < tol
+        for k in ("V", "P", "mu", "gradsum"):
+            assert relerr(sh_s[0][k], ref_s[0][k]) < 10 * tol, k
 
 
 def test_missing_reduction_would_be_caught():
