@@ -810,6 +810,8 @@ inline size_t impute_lds_bytes(int d, int r) {
 
 }  // namespace psmf
 
+#include "psmf_impute3.hip"
+
 #ifndef PSMF_IMPUTE_KERNEL_ONLY
 extern "C" int psmf_impute_run(const psmf_impute_config* cfg, const double* YorgInt, const uint8_t* M,
                                const uint8_t* Mmiss, double* C, double* X, const double* V, const double* P,
@@ -827,7 +829,8 @@ extern "C" int psmf_impute_run(const psmf_impute_config* cfg, const double* Yorg
   if (cfg->method < 0 || cfg->method > 3) return fail(PSMF_ERR_ARG, "method must be 0 (PSMF), 1 (rPSMF), 2 (MLE-SMF) or 3 (TMF)");
   if (cfg->want_bands && (!Yrec || !YrecL || !YrecH)) return fail(PSMF_ERR_ARG, "want_bands needs Yrec, YrecL, YrecH");
   const bool v1 = getenv("PSMF_IMPUTE_V1") && atoi(getenv("PSMF_IMPUTE_V1")) != 0;     // the previous column loop (LDS sweeps, ~15 barriers per column)
-  const size_t lds = v1 ? impute_lds_bytes(d, r) : impute2_lds_bytes(d, r);
+  const bool v3 = !v1 && impute3_ok(d, r) && !(getenv("PSMF_IMPUTE_V3") && atoi(getenv("PSMF_IMPUTE_V3")) == 0);   // small shapes: every wave its own Gram
+  const size_t lds = v1 ? impute_lds_bytes(d, r) : (v3 ? impute3_lds_bytes(d, r) : impute2_lds_bytes(d, r));
   if (lds > 160 * 1024) return fail(PSMF_ERR_ARG, "d * r does not fit one workgroup's LDS");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(PSMF_ERR_NO_DEVICE, "no HIP device visible");
@@ -886,11 +889,13 @@ extern "C" int psmf_impute_run(const psmf_impute_config* cfg, const double* Yorg
     ip.q_iso = iso ? 1 : 0;
   }
   if (lds > 48 * 1024)
-    I_TRY(hipFuncSetAttribute(v1 ? (const void*)psmf_impute_kernel : (const void*)psmf_impute_kernel2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    I_TRY(hipFuncSetAttribute(v1 ? (const void*)psmf_impute_kernel : (v3 ? impute3_kernel(d) : (const void*)psmf_impute_kernel2),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   I_TRY(hipEventCreate(&e0));
   I_TRY(hipEventCreate(&e1));
   I_TRY(hipEventRecord(e0, 0));
   if (v1) hipLaunchKernelGGL(psmf_impute_kernel, dim3(B), dim3(WG), lds, 0, ip);
+  else if (v3) { void* args[] = {&ip}; I_TRY(hipLaunchKernel(impute3_kernel(d), dim3(B), dim3(WG), args, lds, 0)); }
   else hipLaunchKernelGGL(psmf_impute_kernel2, dim3(B), dim3(WG), lds, 0, ip);
   I_TRY(hipGetLastError());
   I_TRY(hipEventRecord(e1, 0));

@@ -26,10 +26,10 @@ int main(int argc, char** argv) {
   hipMemcpy(dV, V.data(), r * r * 8, hipMemcpyHostToDevice); hipMemcpy(dP, P.data(), r * r * 8, hipMemcpyHostToDevice); hipMemcpy(dQ, Q.data(), r * r * 8, hipMemcpyHostToDevice);
   hipMemcpy(dM, M.data(), M.size(), hipMemcpyHostToDevice); hipMemcpy(dMm, Mm.data(), Mm.size(), hipMemcpyHostToDevice);
   p.Yorg = dY; p.M = dM; p.Mmiss = dMm; p.C = dC; p.X = dX; p.V0 = dV; p.P0 = dP; p.Q0 = dQ; p.Epred = dE; p.Efull = dF; p.inside = dI; p.err = dErr; p.prof = prof; p.q_iso = argc > 5 ? atoi(argv[5]) : 1;
-  const size_t lds = ver == 1 ? impute_lds_bytes(d, r) : impute2_lds_bytes(d, r);
+  const size_t lds = ver == 1 ? impute_lds_bytes(d, r) : (ver == 3 ? impute3_lds_bytes(d, r) : impute2_lds_bytes(d, r));
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipEventRecord(e0);
-  if (ver == 1) psmf_impute_kernel<<<B, WG, lds>>>(p); else psmf_impute_kernel2<<<B, WG, lds>>>(p);
+  if (ver == 1) psmf_impute_kernel<<<B, WG, lds>>>(p); else if (ver == 3) { void* args[] = {&p}; hipLaunchKernel(impute3_kernel(d), dim3(B), dim3(WG), args, lds, 0); } else psmf_impute_kernel2<<<B, WG, lds>>>(p);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   std::vector<unsigned long long> h((size_t)B * 4 * 8); hipMemcpy(h.data(), prof, h.size() * 8, hipMemcpyDeviceToHost);
@@ -39,7 +39,9 @@ int main(int argc, char** argv) {
                         "E C update, bands, metrics (+barrier)", "F V, P, Q update (+barrier)", "-", "loop back-edge, prefetch issue"};
   const char* nm2[8] = {"P1 work (rows / w, s)", "   wait at barrier 1", "P2 work (MFMA Gram / wave 0: P + Q, kappa)", "   wait at barrier 2",
                         "P3a work (wave 0: G, eta, N, phi)", "   wait at barrier 3", "P3b sweeps, x, omega (wave 0) / P4 C, V, bands (waves 1-3)", "   wait at barrier 4"};
-  const char** nm = ver == 1 ? nm1 : nm2;
-  for (int w : {0, 1, 3}) { printf("replica 0, wave %d: shader-clock cycles per column (s_memtime)\n", w); for (int q = 0; q < 8; ++q) if (nm[q][0] != '-') printf("   %-56s %8.0f\n", nm[q], (double)h[(size_t)w * 8 + q] / cols); }
+  const char* nm3[8] = {"P1 work (wave 1: rows / 2: X store / 3: w, s)", "   wait at barrier 1", "operands -> registers", "own Gram, scalars",
+                        "sweep (waves 0, 1)", "rest: x, omega, P (0) / bands (1) / C, V (2, 3)", "   wait at barrier 2", "-"};
+  const char** nm = ver == 1 ? nm1 : (ver == 3 ? nm3 : nm2);
+  for (int w : {0, 1, 2, 3}) { printf("replica 0, wave %d: shader-clock cycles per column (s_memtime)\n", w); for (int q = 0; q < 8; ++q) if (nm[q][0] != '-') printf("   %-56s %8.0f\n", nm[q], (double)h[(size_t)w * 8 + q] / cols); }
   return 0;
 }
