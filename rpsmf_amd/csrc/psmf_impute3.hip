@@ -8,8 +8,9 @@
 //     group of four rows), and its output layout is the layout the sweep and the trace <G, P + Q> want.  Version 2 spread
 //     the MFMAs over three waves, exchanged partial tiles through LDS and had wave 0 reduce them and hand eta, N, phi to
 //     the others (two barriers, ~2 700 cycles of wave 0's chain per column).  The augmented columns e and 1 are STORED in
-//     the zero padding of C's LDS rows (columns r, r + 1), so the operands are b = row, a = m * row: the product holds G,
-//     b = C^T e (column r), e^T e at (r, r) and sum(m) at (r + 1, r + 1) -- no reductions for the last two.
+//     the zero padding of C's LDS rows (columns r2, r2 + 1; r2 = r rounded up to even), so the operands are b = row,
+//     a = m * row: the product holds G, b = C^T e (column r2), e^T e at (r2, r2) and sum(m) at (r2 + 1, r2 + 1) -- no
+//     reductions for the last two.
 //   * lane predicates as NUMBERS in VGPRs (0.0 / 1.0 multipliers, computed once): a select of a double is two v_cndmask
 //     plus, here, the reload of its lane mask from a spilled SGPR pair (two v_readlane) -- the kernel had 1 200 of those;
 //     a multiply-add is one instruction.  wave_sweep16m: 45 instructions per 2 x 2 pivot round instead of ~110.
@@ -17,12 +18,16 @@
 //     AGPRs -- 16 copies and a 16-cycle stall per pivot round).
 //   * C, the scalars, W and P + Q are double-buffered by column parity: what a column's tail writes is the NEXT column's
 //     slot, so the only barriers are "residual / w / s ready" and "end of column".
-//   P1   wave 1 (lane = row): masked residual rows, e into C's column r; wave 3: w = V x, s = x^T V x; wave 2: X of the
-//        previous column to global memory                                                                    | barrier 1
+//   * the sweep of M_t runs on the matrix AUGMENTED with kappa b = kappa C^T e (row / column r2 of the 16 x 16 tile, which the
+//     rank-2 updates of the pivot rounds cover anyway): when the r2 pivots are done that column holds kappa P+ b = x_t - x_p
+//     and its diagonal element 1 - kappa^2 b^T P+ b (for omega) -- no product P+ b afterwards.
+//   P1   wave 2 (two lanes per row): masked residual rows, e into C's column r2; wave 3 (four lanes per row): w = V x,
+//        s = x^T V x; wave 1: X of the previous column to global memory; waves 0, 1: Lbar_t from W_{t-1}        | barrier 1
 //   G    every wave: operands LDS -> registers, Gram, the scalars it needs from it
-//   wave 0: M_t = Lbar_t + kappa G -> sweep -> x_t, omega, P_t;  publishes x_t, 1/omega, 1/q, rho, lambda, P_t + Q_{t+1}
-//   wave 1: W_t = (M_t + I / q_t)^-1 beside it (Q = q I);  eta, N for itself;  bands and metrics of its rows
-//   waves 2, 3: <G, P + Q>, eta, N, phi for themselves;  rank-1 updates C_t -> next buffer, V in place          | barrier 2
+//   wave 0: [M_t = Lbar_t + kappa G | kappa b] -> sweep -> x_t, omega, P_t;  publishes x_t, 1/omega, 1/q, rho, lambda, P_t + Q_{t+1}
+//   wave 1: W_t = (M_t + I / q_t)^-1 beside it (Q = q I)
+//   waves 2, 3: <G, P + Q>, eta, N, phi for themselves;  rank-1 updates C_t -> next buffer, V in place;  wave 2: bands and
+//        metrics of its rows                                                                                     | barrier 2
 // Same recursion, same float64 arithmetic as version 2 up to summation order (G: one accumulating MFMA chain instead of three
 // partial tiles; e^T e on the matrix cores).  psmf_impute_run picks this kernel when the shape allows (PSMF_IMPUTE_V3=0:
 // version 2).
@@ -77,7 +82,11 @@ __device__ __forceinline__ void wave_sweep16m(double (&A)[4], const int r2, cons
       const double ka = readlane_f64(rk, b0 | k), kb = readlane_f64(rk, b0 | (k + 1)), ke = readlane_f64(rk, b1 | (k + 1));
       const double det = ka * ke - kb * kb;
       bad |= !(ka > 0.0) | !(det > 0.0);
-      const double dinv = fast_rcp(det);
+      // 1 / det: v_rcp_f64 (~1e-8) and ONE cubic step x (1 + e + e^2), e = 1 - det x -- three dependent operations
+      // instead of the four of two Newton steps (this chain is the round's critical path)
+      const double x0 = __builtin_amdgcn_rcp(det);
+      const double e1 = fma(-det, x0, 1.0);
+      const double dinv = fma(x0 * e1, 1.0 + e1, x0);
       // u_j (even row of the pair) and w_j (odd row) in both rows of each pair
       const unsigned lo = __double2loint(rk), hi = __double2hiint(rk);
       const auto l2 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
@@ -86,9 +95,9 @@ __device__ __forceinline__ void wave_sweep16m(double (&A)[4], const int r2, cons
       // det * (row of Ki that belongs to this lane's pivot row): even row [ke, -kb], odd row [-kb, ka]
       const double cu = c.fu * ke - c.fw * kb, cw = c.fw * ka - c.fu * kb;
       const double u1 = fma(uj, c.fnp[j], c.pc0[j]), w1 = fma(wj, c.fnp[j], c.pc1[j]);     // pivot columns: unit vectors -> the entries of Ki
-      const double sv = dinv * fma(cu, u1, cw * w1);
+      const double pre = fma(cu, u1, cw * w1) * c.sg[j];       // everything of the B operand but 1 / det
       const double aop = rk * c.fpiv[h];
-      const double bop = sv * c.sg[j];
+      const double bop = pre * dinv;
       f64x4 acc = {c.fnp[j] * A[0], c.fnp[j] * A[1], c.fnp[j] * A[2], c.fnp[j] * A[3]};
       acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
 #pragma unroll
@@ -126,7 +135,7 @@ __device__ __forceinline__ void impute3_wave(const ImputeParams& p) {
 
   for (int idx = tid; idx < 2 * D4 * IR; idx += WG) {
     const int i = (idx >> 4) % D4, l = idx & 15;
-    sC[idx] = (i < d && l < r) ? Cg[i * r + l] : ((i < d && l == r + 1) ? 1.0 : 0.0);
+    sC[idx] = (i < d && l < r) ? Cg[i * r + l] : ((i < d && l == r + (r & 1) + 1) ? 1.0 : 0.0);
   }
   for (int idx = tid; idx < IR * IR; idx += WG) { const int i = idx >> 4, l = idx & 15; sV[idx] = (i < r && l < r) ? p.V0[i * r + l] : 0.0; }
   if (tid < 2 * IR) sx[tid] = (tid < r) ? Xg[(size_t)(n - 1) * r + tid] : 0.0;   // t = 0 wraps to the last column (PSMF.py:65)
@@ -139,21 +148,23 @@ __device__ __forceinline__ void impute3_wave(const ImputeParams& p) {
   const bool sgd = p.method >= 2;     // MLE-SMF / TMF: gradient step on C along x_p, no V
   const bool tmf = p.method == 3;
   const bool par = p.q_iso && !tmf;   // Q = q I: the two inversions of a column are independent (see version 2)
-  const int r2 = r + (r & 1);
-  // where the scalar by-products of the Gram sit: element (r, r) = e^T e, (r + 1, r + 1) = sum(m)
-  const int rq_e = r >> 2, ln_e = ((r & 3) << 4) | r, rq_m = (r + 1) >> 2, ln_m = (((r + 1) & 3) << 4) | (r + 1);
-  // lane predicates as multipliers: inside the r x r matrix; its diagonal; the identity padding's diagonal; b's lanes
-  double finq[4], fdgin[4], fpad[4], fb[4];
+  const int r2 = r + (r & 1);         // sweep size: even, identity-padded; also the tile column of e / of kappa b
+  // where the scalar by-products of the Gram sit: element (r2, r2) = e^T e, (r2 + 1, r2 + 1) = sum(m)
+  const int rq_e = r2 >> 2, ln_e = ((r2 & 3) << 4) | r2, rq_m = (r2 + 1) >> 2, ln_m = (((r2 + 1) & 3) << 4) | (r2 + 1);
+  // lane predicates as multipliers: inside the r x r matrix; its diagonal; the identity padding's diagonal; the matrix plus
+  // the augmented row / column r2 (b)
+  double finq[4], fdgin[4], fpad[4], fga[4], fxr[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int i = lk + 4 * q;
+    fxr[q] = i < r ? 1.0 : 0.0;
     const bool in = i < r && lr < r, dg = i == lr;
     finq[q] = in ? 1.0 : 0.0;
     fdgin[q] = (in && dg) ? 1.0 : 0.0;
     fpad[q] = (!in && dg) ? 1.0 : 0.0;
-    fb[q] = (lr == r && i < r) ? 1.0 : 0.0;
+    fga[q] = (in || (lr == r2 && i < r) || (i == r2 && lr < r)) ? 1.0 : 0.0;
   }
-  const bool ce = lr == r;
+  const bool ce = lr == r2;
   Sw16K swk;
   if (WV < 2) sw16k_init(swk, lk, lr);
   // wave 0: P, Q in the MFMA output layout (element (lk + 4 q, lr)), rho, lambda, q
@@ -172,8 +183,8 @@ __device__ __forceinline__ void impute3_wave(const ImputeParams& p) {
   bool bad = false;
   unsigned long long nmiss_l = 0;
   int cur = 0;
-  const int row = min(lane, d - 1);            // wave 1: lane = row
-  const bool rown = WV == 1 && lane < d;
+  const int row = min(lane & 31, d - 1), half = lane >> 5;     // wave 2: two lanes per row (columns 8 half .. 8 half + 7)
+  const bool rown = WV == 2 && lane < d;
   __syncthreads();
   IMP_T0();
   for (int it = 0; it < p.n_iter; ++it) {
@@ -202,7 +213,7 @@ __device__ __forceinline__ void impute3_wave(const ImputeParams& p) {
 #pragma unroll
           for (int q = 0; q < 4; ++q) sW[cur * 256 + q * 64 + lane] = fdgin[q] * qv + finq[q] * qv * qv * A[q];
           iqv = 1.0 / qv;
-          if (lane == 0) { scc[4] = 1.0; scc[5] = iqv; scc[6] = iqv; }
+          if (lane == 0) { ssc[4] = 1.0; ssc[5] = iqv; ssc[6] = iqv; ssc[16 + 4] = 1.0; ssc[16 + 5] = iqv; ssc[16 + 6] = iqv; }   // (PSMF: constant)
         }
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
@@ -217,10 +228,10 @@ __device__ __forceinline__ void impute3_wave(const ImputeParams& p) {
     double sse_pred = 0.0;
     unsigned long long inside_l = 0;
     nmiss_l = 0;
-    // prefetch column 0 (wave 1; unconditional loads, row index clamped -- see version 2)
+    // prefetch column 0 (wave 2; unconditional loads, row index clamped -- see version 2)
     double ny = 0.0;
     uint8_t nm = 0, nmm = 0;
-    if (WV == 1) { ny = Yorg[row]; nm = Mk[row]; nmm = Mm[row]; }
+    if (WV == 2) { ny = Yorg[row]; nm = Mk[row]; nmm = Mm[row]; }
     for (int t = 0; t < n; ++t) {
       const double* sxc = sx + cur * IR;
       double* sxn = sx + (cur ^ 1) * IR;
@@ -230,41 +241,55 @@ __device__ __forceinline__ void impute3_wave(const ImputeParams& p) {
       double* scn = ssc + (cur ^ 1) * 16;
       double yv = 0.0, yh = 0.0;
       uint8_t mv = 0, mmv = 0;
-      // ---- P1: residual rows (wave 1), w = V x and s = x^T V x (wave 3), X of the previous column (wave 2) ----
-      if (WV == 1) {
-        yv = ny; mv = nm; mmv = nmm;
-        const size_t cbase = (size_t)min(t + 1, n - 1) * d;      // (the last column is simply loaded twice)
-        ny = Yorg[cbase + row];
-        nm = Mk[cbase + row];
-        nmm = Mm[cbase + row];
-        double cr[IR], xr[IR];
+      // ---- P1: residual rows (wave 2), w = V x and s = x^T V x (wave 3), X of the previous column (wave 1), Lbar (waves 0, 1) ----
+      double Lb[4] = {0.0, 0.0, 0.0, 0.0};       // Lbar_t (+ the identity padding's diagonal)
+      double iqt = 0.0, xc[4] = {0.0, 0.0, 0.0, 0.0};
+      if (WV < 2) {
+        if (WV == 1 && t > 0 && lane < r) Xg[(size_t)(t - 1) * r + lane] = sxc[lane];    // the reference overwrites X[:, t] in place
+        if (par) {
+          const double iom = scc[4], iq = scc[5];
+          iqt = scc[6];
+          const double k1 = iom * iq, k2 = k1 * iq;
 #pragma unroll
-        for (int l = 0; l < IR; ++l) { cr[l] = sCc[row * IR + l]; xr[l] = sxc[l]; }   // (x is zero in the columns of e and 1)
+          for (int q = 0; q < 4; ++q) Lb[q] = fma(-k2, sW[cur * 256 + q * 64 + lane], fma(fdgin[q], k1, fpad[q]));
+        }
+        if (WV == 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) xc[q] = sxc[lk + 4 * q];
+        }
+      }
+      if (WV == 2) {
+        yv = ny; mv = nm; mmv = nmm;
+        double cr[8], xr[8];
+#pragma unroll
+        for (int l = 0; l < 8; ++l) { cr[l] = sCc[row * IR + 8 * half + l]; xr[l] = sxc[8 * half + l]; }   // (x is zero in the columns of e and 1)
         double d0 = 0.0, d1 = 0.0;
 #pragma unroll
-        for (int l = 0; l < IR; l += 2) { d0 = fma(cr[l], xr[l], d0); d1 = fma(cr[l + 1], xr[l + 1], d1); }
-        yh = d0 + d1;
+        for (int l = 0; l < 8; l += 2) { d0 = fma(cr[l], xr[l], d0); d1 = fma(cr[l + 1], xr[l + 1], d1); }
+        yh = xor32_sum_f64(d0 + d1);
         const double mi = mv ? 1.0 : 0.0;
         const double yi = mv ? yv : 0.0;     // Y is 0 where unobserved (PSMF.py:147-148)
         const double ei = mi * (yi - yh);
-        if (rown) { se[lane] = ei; smk[lane] = mi; sCc[lane * IR + r] = ei; }
+        if (rown) { se[lane] = ei; smk[lane] = mi; sCc[lane * IR + r2] = ei; }
       }
       if (WV == 3) {
-        double vr[IR], xr[IR];
+        double vr[4], xr[4];
 #pragma unroll
-        for (int l = 0; l < IR; ++l) { vr[l] = sV[lr * IR + l]; xr[l] = sxc[l]; }     // (rows >= r of V are zero)
-        double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-        for (int l = 0; l < IR; l += 2) { a0 = fma(vr[l], xr[l], a0); a1 = fma(vr[l + 1], xr[l + 1], a1); }
-        const double wl = a0 + a1;           // every 16-lane row holds w
+        for (int l = 0; l < 4; ++l) { vr[l] = sV[lr * IR + 4 * lk + l]; xr[l] = sxc[4 * lk + l]; }     // (rows >= r of V are zero)
+        const double wl = xor32_sum_f64(xor16_sum_f64(fma(vr[0], xr[0], vr[1] * xr[1]) + fma(vr[2], xr[2], vr[3] * xr[3])));   // every 16-lane row holds w
         if (lane < IR) sw[lane] = wl;
         const double sv = row_sum_f64_dpp(sxc[lr] * wl);
         if (lane == 0) ssc[cur * 16] = sv;
       }
-      if (WV == 2 && t > 0 && lane < r) Xg[(size_t)(t - 1) * r + lane] = sxc[lane];    // the reference overwrites X[:, t] in place
       IMP_T(0);
       solve_barrier<true>();                                          // ---- barrier 1
       IMP_T(1);
+      if (WV == 2) {       // next column's inputs: issued here, off the path to barrier 1, a whole column before their use
+        const size_t cbase = (size_t)min(t + 1, n - 1) * d;      // (the last column is simply loaded twice)
+        ny = Yorg[cbase + row];
+        nm = Mk[cbase + row];
+        nmm = Mm[cbase + row];
+      }
       // ---- operands -> registers ----
       double cv[NG], mk[NG];
 #pragma unroll
@@ -273,18 +298,10 @@ __device__ __forceinline__ void impute3_wave(const ImputeParams& p) {
         mk[g] = smk[4 * g + lk];
       }
       const double s = scc[0], rho_t = scc[8], lam_t = scc[9];
-      double iom = 1.0, iq = 0.0, iqt = 0.0, Wv[4] = {0.0, 0.0, 0.0, 0.0}, PPv[4] = {0.0, 0.0, 0.0, 0.0}, xc[4] = {0.0, 0.0, 0.0, 0.0};
-      if (WV < 2 && par) {
-        iom = scc[4]; iq = scc[5]; iqt = scc[6];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) Wv[q] = sW[cur * 256 + q * 64 + lane];
-      }
-      if (WV > 0) {
+      double PPv[4] = {0.0, 0.0, 0.0, 0.0};
+      if (WV >= 2) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) PPv[q] = sPP[cur * 256 + q * 64 + lane];
-      } else {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) xc[q] = sxc[lk + 4 * q];
       }
       IMP_T(2);
       // ---- augmented masked Gram [C | e | 1]^T diag(m) [C | e | 1], two accumulators ----
@@ -298,25 +315,19 @@ __device__ __forceinline__ void impute3_wave(const ImputeParams& p) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) { Bq[q] = acc0[q] + acc1[q]; G[q] = finq[q] * Bq[q]; }   // b_i = (C^T e)_i: column r of rows i
       double ee = 0.0, msum = 0.0;
-      if (WV > 0 || p.robust) {
+      if (WV >= 2 || (WV == 0 && p.robust)) {
         const double ee_r = rq_e == 0 ? Bq[0] : (rq_e == 1 ? Bq[1] : (rq_e == 2 ? Bq[2] : Bq[3]));
         ee = readlane_f64(ee_r, ln_e);
       }
-      if (WV > 0) {
+      if (WV >= 2) {
         const double ms_r = rq_m == 0 ? Bq[0] : (rq_m == 1 ? Bq[1] : (rq_m == 2 ? Bq[2] : Bq[3]));
         msum = readlane_f64(ms_r, ln_m);
       }
       // weights of the observed rows: PSMF / rPSMF 1 / (rho + s) (PSMF.py:71-72), MLE-SMF 1 / rho (MLESMF.py:70), TMF 1
       const double kappa = tmf ? 1.0 : fast_rcp(sgd ? rho_t : rho_t + s);
-      double Lb[4] = {0.0, 0.0, 0.0, 0.0};       // Lbar_t (+ the identity padding's diagonal)
-      if (WV < 2 && par) {
-        const double k1 = iom * iq, k2 = k1 * iq;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) Lb[q] = fma(-k2, Wv[q], fma(fdgin[q], k1, fpad[q]));
-      }
-      // eta, N, phi: everybody but wave 0 forms them for itself
+      // eta, N, phi: the updating waves form them for themselves
       double eta = 0.0, N = 0.0, phi = 1.0;
-      if (WV > 0) {
+      if (WV >= 2) {
         double tr = 0.0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) tr = fma(G[q], PPv[q], tr);
@@ -327,57 +338,38 @@ __device__ __forceinline__ void impute3_wave(const ImputeParams& p) {
       }
       IMP_T(3);
       if (WV == 0) {
-        // ---- P+ = ((P + Q)^-1 + kappa G)^-1, x_t, omega, P, Q ----
+        // ---- P+ = ((P + Q)^-1 + kappa G)^-1 on the matrix augmented with kappa b; x_t, omega, P, Q ----
         double A[4];
         if (par) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) A[q] = fma(kappa, G[q], Lb[q]);
+          for (int q = 0; q < 4; ++q) A[q] = fma(kappa, fga[q] * Bq[q], Lb[q]);
         } else {
 #pragma unroll
           for (int q = 0; q < 4; ++q) A[q] = (tmf ? 0.5 * fdgin[q] : Pm[q] + Qm[q]) + fpad[q];
           wave_sweep16m(A, r2, swk, bad);                  // -(P + Q)^-1
 #pragma unroll
-          for (int q = 0; q < 4; ++q) A[q] = fma(kappa, G[q], fpad[q] - finq[q] * A[q]);
+          for (int q = 0; q < 4; ++q) A[q] = fma(kappa, fga[q] * Bq[q], fpad[q] - finq[q] * A[q]);
         }
-        wave_sweep16m(A, r2, swk, bad);                  // -P+
+        wave_sweep16m(A, r2, swk, bad);                  // [[-P+, kappa P+ b], [., 1 - kappa^2 b^T P+ b]]
         IMP_T(4);
-        // z = P+ b on the matrix cores: A[q] (symmetric) is the A operand of k-block q as it stands; b_i sits in Bq[q] of the
-        // lanes lr == r: as the B operand it makes column r of the product z.  (Outside the r x r block A is the swept
-        // identity padding and b is zero: no mask on the A operand.)
-        f64x4 zacc0 = {0.0, 0.0, 0.0, 0.0}, zacc1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          if (q & 1) zacc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(A[q], fb[q] * Bq[q], zacc1, 0, 0, 0);
-          else zacc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A[q], fb[q] * Bq[q], zacc0, 0, 0, 0);
-        }
-        double zs[4];                 // -(P+ C^T e)_i, i = lk + 4 q, on the lanes lr == r
-#pragma unroll
-        for (int q = 0; q < 4; ++q) zs[q] = zacc0[q] + zacc1[q];
         if (ce) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) sxn[lk + 4 * q] = fma(-kappa, zs[q], xc[q]);     // (entries >= r: 0 - kappa * 0)
+          for (int q = 0; q < 4; ++q) sxn[lk + 4 * q] = fma(fxr[q], A[q], xc[q]);      // x_p + kappa P+ b (entries >= r stay zero)
         }
-        double omega = 1.0;
         if (p.robust) {
-          double part = 0.0;
+          const double a_r = rq_e == 0 ? A[0] : (rq_e == 1 ? A[1] : (rq_e == 2 ? A[2] : A[3]));
+          const double nk2bPb = readlane_f64(a_r, ln_e) - 1.0;                      // -kappa^2 b^T P+ b
+          const double omega = (lam + kappa * ee + nk2bPb) * fast_rcp(lam + dd);   // rPSMF.py:105
 #pragma unroll
-          for (int q = 0; q < 4; ++q) part = fma(fb[q] * Bq[q], zs[q], part);          // -b_i z_i on the lanes that hold b_i
-          const double nbPb = (readlane_f64(part, r) + readlane_f64(part, 16 + r)) + (readlane_f64(part, 32 + r) + readlane_f64(part, 48 + r));
-          omega = (lam + kappa * ee + kappa * kappa * nbPb) * fast_rcp(lam + dd);   // rPSMF.py:105
-        }
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          Pm[q] = -omega * finq[q] * A[q];
-          if (p.robust) Qm[q] *= omega;
-        }
-        if (par) {          // for the next column: 1 / omega_t, 1 / q_t (the q W_t is formed with), 1 / q_{t+1}
-          const double io = p.robust ? fast_rcp(omega) : 1.0;
-          if (lane == 0) { scn[4] = io; scn[5] = iqv; scn[6] = iqv * io; }
+          for (int q = 0; q < 4; ++q) { Pm[q] = -omega * finq[q] * A[q]; Qm[q] *= omega; }
+          const double io = fast_rcp(omega);
+          if (par && lane == 0) { scn[4] = io; scn[5] = iqv; scn[6] = iqv * io; }
           iqv *= io;
-        }
-        if (p.robust) {
           rho *= omega; lam += dd; qv *= omega;
           if (lane == 0) { scn[8] = rho; scn[9] = lam; }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) Pm[q] = -finq[q] * A[q];
         }
         if (!tmf) {
 #pragma unroll
@@ -394,23 +386,6 @@ __device__ __forceinline__ void impute3_wave(const ImputeParams& p) {
           for (int q = 0; q < 4; ++q) sW[(cur ^ 1) * 256 + q * 64 + lane] = -finq[q] * A[q];
         }
         IMP_T(4);
-        // ---- bands, metrics of this lane's row ----
-        if (rown) {
-          const double band = p.sig * sqrt(p.robust ? (s * (mv ? 1.0 : 0.0) + eta) : (sgd ? eta : N));   // rPSMF.py:121-123 / PSMF.py:83-84 / MLESMF.py:81-82
-          const double lo = yh - band, hi = yh + band;
-          if (mmv) {
-            const double dl = yh - yv;
-            sse_pred += dl * dl;
-            nmiss_l += 1;
-            if (it == p.n_iter - 1 && !tmf && yv < hi && lo < yv) inside_l += 1;
-          }
-          if (p.want_bands) {
-            const size_t off = ((size_t)rep * n + t) * d + lane;
-            p.Yrec[off] = yh;
-            p.YrecL[off] = lo;
-            p.YrecH[off] = hi;
-          }
-        }
       } else {
         // ---- waves 2, 3: rank-1 updates with N, phi of this column: C into the next column's buffer, V in place ----
         IMP_T(4);
@@ -433,13 +408,30 @@ __device__ __forceinline__ void impute3_wave(const ImputeParams& p) {
             }
           }
         }
+        // ---- wave 2: bands, metrics of its rows ----
+        if (rown) {
+          const double band = p.sig * sqrt(p.robust ? (s * (mv ? 1.0 : 0.0) + eta) : (sgd ? eta : N));   // rPSMF.py:121-123 / PSMF.py:83-84 / MLESMF.py:81-82
+          const double lo = yh - band, hi = yh + band;
+          if (mmv) {
+            const double dl = yh - yv;
+            sse_pred += dl * dl;
+            nmiss_l += 1;
+            if (it == p.n_iter - 1 && !tmf && yv < hi && lo < yv) inside_l += 1;
+          }
+          if (p.want_bands) {
+            const size_t off = ((size_t)rep * n + t) * d + lane;
+            p.Yrec[off] = yh;
+            p.YrecL[off] = lo;
+            p.YrecH[off] = hi;
+          }
+        }
       }
       cur ^= 1;
       IMP_T(5);
       solve_barrier<true>();                                          // ---- barrier 2
       IMP_T(6);
     }
-    if (WV == 2 && lane < r) Xg[(size_t)(n - 1) * r + lane] = sx[cur * IR + lane];
+    if (WV == 1 && lane < r) Xg[(size_t)(n - 1) * r + lane] = sx[cur * IR + lane];
     // ---- end of pass: RMSE of the one-step predictions, RMSE of C @ X, coverage ----
     __syncthreads();                 // (drains the X stores)
     double nm_d = (double)nmiss_l;
