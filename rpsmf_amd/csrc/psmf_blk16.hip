@@ -1,0 +1,348 @@
+// psmf_blk_filter6: the general block filter (psmf_blk_filter, psmf_block.hip -- any dynamics kind, any hook configuration,
+// R_k / Q_k schedules, rPSMF, in-loop Adam) for ranks r <= 14, role-specialised.
+//
+// psmf_blk_filter runs every stage of a timestep on all 256 threads with a workgroup barrier after each: at r = 10
+// (ExperimentBeijing: FourierBasis, beijing_psmf.py:97-140) a step was 26 800 cycles, 8 500 of them the two LDS sweep
+// inversions (one exchange + barrier per 2 x 2 pivot), 4 200 the r x r products of Pbar = F P F^T + Q through LDS images, 3 000
+// the coefficient-space vectors -- all of it latency of barriers and LDS round trips, none of it arithmetic
+// (tools/blkgen_prof.hip).  Here the r x r state lives in ONE wave's registers as 16 x 16 tiles in the MFMA output layout and
+// the stages that do not depend on each other run side by side on different waves:
+//   dynamics forward (all waves, psmf_dyn.hip)                                                               | barriers inside
+//   A  wave 0 (matrix wave): w = V mu_bar, s, Pbar = F P F^T + Q (eight float64 MFMAs, operands straight from the
+//        registers: P and V are symmetric, so a tile in the output layout IS the A operand of its k-blocks), <G, Pbar>,
+//        eta, N, kappa -- published -- and the first sweep, -Pbar^-1 (wave_sweep16m: no LDS, no barrier)
+//      wave 1 (coefficient wave, lane = coefficient row): b = A mu_bar, Ka, a, h = A^T Ka, e'e; then, when wave 0 has
+//        published w and N (LDS flag), the likelihood gradient g_f                                                 | barrier
+//   B  wave 0: kappa G - (-Pbar^-1), augmented with kappa h in row / column r2 -> second sweep: P+ AND kappa P+ h (= mu - mu_bar)
+//        AND 1 - kappa^2 h'P+h in one go; omega, phi; V, P, G, Q updates in registers; rank-1 updates of A and K A
+//      waves 1-3: gradsum += J_theta^T g_f (dyn_backward on 192 threads)                                            | barrier
+//   mu, in-loop Adam (all waves)
+// Same recursion and float64 arithmetic as psmf_blk_filter (summation orders differ).  r <= 14: the augmented column needs
+// r2 < 16.  PSMF_FILTER6=0 sends these ranks back to psmf_blk_filter.
+#pragma once
+#include "psmf_blk3.hip"
+#include "psmf_wave16.hip"
+
+namespace psmf {
+
+constexpr int F6_RMAX = 14;
+
+__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2))) void psmf_blk_filter6(BlockParams b) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* sm = reinterpret_cast<double*>(smem_raw);
+  const StepParams& p = b.sp;
+  DevState* st = p.st;
+  const int r = p.r, tid = threadIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lk = lane >> 4, lr = lane & 15;
+  const int r2 = r + (r & 1);
+  const double dd = (double)p.d;
+  // ---- LDS carve: psmf_blk_filter's (blk_filter_lds_bytes), so that assemble_K and the dynamics see the arrays they know ----
+  double* sK = sm;                    // RB x RB
+  double* sA = sK + RB * RB;          // RB x r, row stride RS
+  double* sKA = sA + RB * RS;         // RB x r
+  double* s_img = sKA + RB * RS;      // WG: a 16 x 16 tile image of wave 0 (transposition)
+  double* s_mub = s_img + WG;         // RM each below
+  double* s_f = s_mub + RM;
+  double* s_w = s_f + RM;
+  double* s_h = s_w + RM;
+  double* s_munew = s_h + RM;
+  double* s_mu = s_munew + RM;
+  double* s_a = s_mu + RM;            // RB
+  double* s_Ka = s_a + RB;            // RB
+  double* s_sc = s_Ka + RB;           // (8 RB:) 0 s, 1 eta, 2 N, 3 1 / N, 4 kappa, 5 lambda of the step, 6 e'e
+  int* s_flag = reinterpret_cast<int*>(s_sc + 16);     // number of steps whose s_w / s_sc[0..5] wave 0 has published
+  double* rowbuf = s_sc + 8 * RB;     // 4 * RM (unused here)
+  double* s4 = rowbuf + 4 * RM;       // 4 (+ errflag)
+  int* errflag = reinterpret_cast<int*>(s4 + 4);
+  double* sF = s4 + 6;                // RM/2 x RS: dense Jacobian
+  double* sPm = sF + (RM / 2) * RS;
+  double* sT = sPm + (RM / 2) * RS;   // scratch of the dynamics
+  double* s_val = sT + (RM / 2) * RS; // DYN_MAX_TERMS x RM
+  double* s_tp = s_val + DYN_MAX_TERMS * RM;
+  double* s_gf = s_tp + DYN_MAX_TERMS * RM;   // RM
+  double* s_u = s_gf + RM;            // RM
+  double* s_theta = s_u + RM;         // BLK_TH_CAP   (theta and gradsum of the block, when they fit)
+  double* s_grad = s_theta + BLK_TH_CAP;
+  const bool dense = dyn_dense(p.dyn_kind, p.dyn_flags);
+  const bool th_lds = p.n_theta > 0 && p.n_theta <= BLK_TH_CAP;
+  const bool has_bw = p.n_theta > 0 && p.dyn_kind != DYN_RANDOM_WALK;
+  StepParams pd = p;                  // what the dynamics see: theta / gradsum in LDS when they fit
+  if (th_lds) { pd.theta = s_theta; pd.gradsum = s_grad; }
+
+  if (!blk_handoff_begin(b)) return;
+  if (th_lds)
+    for (int idx = tid; idx < p.n_theta; idx += WG) { s_theta[idx] = p.theta[idx]; s_grad[idx] = p.gradsum[idx]; }
+  if (!b.assemble) {
+    for (int idx = tid; idx < RB * RB; idx += WG) sK[idx] = b.K[idx];
+  } else {
+    assemble_K<WG>(b, sK, sA, sKA, r, tid);
+  }
+  if (tid == 0) { *errflag = 0; *s_flag = 0; }
+  if (tid < RM) { s_mub[tid] = 0.0; s_h[tid] = 0.0; s_w[tid] = 0.0; s_f[tid] = 1.0; s_munew[tid] = 0.0; s_gf[tid] = 0.0; }
+  for (int idx = tid; idx < (RM / 2) * RS; idx += WG) sF[idx] = 0.0;        // wave 0 reads whole 16 x 16 tiles: zero outside r x r
+  if (tid < r) s_mu[tid] = st->mu[tid];
+  // ---- wave 0: V, P, Q, G as 16 x 16 tiles (element (lk + 4 q, lr)); the lane predicates as multipliers ----
+  double Vm[4] = {0.0, 0.0, 0.0, 0.0}, Pm[4] = {0.0, 0.0, 0.0, 0.0}, Qm[4] = {0.0, 0.0, 0.0, 0.0}, Gm[4] = {0.0, 0.0, 0.0, 0.0};
+  double finq[4], fpad[4], faugc[4], faugr[4], fxr[4];
+  int trx[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int i = lk + 4 * q;
+    const bool in = i < r && lr < r;
+    finq[q] = in ? 1.0 : 0.0;
+    fpad[q] = (!in && i == lr) ? 1.0 : 0.0;
+    faugc[q] = (lr == r2 && i < r) ? 1.0 : 0.0;       // column r2: kappa h_i
+    faugr[q] = (i == r2 && lr < r) ? 1.0 : 0.0;       // row r2: kappa h_j
+    fxr[q] = i < r ? 1.0 : 0.0;
+    trx[q] = (lr >> 2) * 64 + (lr & 3) * 16 + i;      // the transposed element in a tile image
+    if (wv == 0) {
+      const int idx = in ? i * r + lr : 0;
+      const double lv = st->V[idx], lq = st->Q[idx], lp = st->P[idx];
+      Vm[q] = in ? lv : 0.0;
+      Qm[q] = in ? lq : 0.0;
+      Pm[q] = in ? lp : 0.0;
+    }
+  }
+  const int rq_c = r2 >> 2, ln_c = ((r2 & 3) << 4) | r2;       // where element (r2, r2) sits
+  Sw16K swk;
+  if (wv == 0) sw16k_init(swk, lk, lr);
+  double rho = st->rho, lam = st->lam;
+  bool bad = false;
+  __syncthreads();
+  // A_0 = [I; 0], K A_0 = first r columns of K, G_0 = K[0:r, 0:r] (exact Gram of the stored C)
+  for (int idx = tid; idx < RB * r; idx += WG) {
+    const int m = idx / r, c = idx - m * r;
+    sA[m * RS + c] = (m == c) ? 1.0 : 0.0;
+    sKA[m * RS + c] = sK[m * RB + c];
+  }
+  if (wv == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) Gm[q] = finq[q] != 0.0 ? sK[(lk + 4 * q) * RB + lr] : 0.0;
+  }
+  __syncthreads();
+
+  double s_last = 0.0, eta_last = 0.0, N_last = 0.0, phi = 1.0, omega = 1.0, ee_last = 0.0;
+  for (int jb = 0; jb < b.nb; ++jb) {
+    const long long kstep = b.k0 + jb + 1;   // 1-based step index
+    // ---- mu_bar = f(theta, mu, k), F = df/dx (psmf.py:104-115; psmf_dyn.hip) ----
+    dyn_forward<WG>(pd, (double)kstep, s_mu, s_mub, s_f, sF, RS, s_val, s_tp, sT, tid);     // ends with a barrier
+    // PSMFIter reads Q[k], R[k] of the step (psmf.py:115,123,141): scalar schedules (never with rPSMF's running Q, R)
+    const double qs = p.q_sched ? p.q_sched[kstep - p.series_t0] : 1.0;
+    if (p.rho_sched) rho = p.rho_sched[kstep - p.series_t0];
+    double A[4] = {0.0, 0.0, 0.0, 0.0}, Pb[4] = {0.0, 0.0, 0.0, 0.0}, wrow[4] = {0.0, 0.0, 0.0, 0.0}, mb[4] = {0.0, 0.0, 0.0, 0.0};
+    double s = 0.0, eta = rho, N = 1.0, invN = 1.0, kappa = 0.0;
+    if (wv == 0) {
+      // ================= phase A, matrix wave =================
+#pragma unroll
+      for (int q = 0; q < 4; ++q) mb[q] = s_mub[lk + 4 * q];         // mu_bar of this lane's rows = the B operand of V mu_bar
+      {
+        f64x4 a0 = {0.0, 0.0, 0.0, 0.0}, a1 = {0.0, 0.0, 0.0, 0.0};
+        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vm[0], mb[0], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vm[1], mb[1], a1, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vm[2], mb[2], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vm[3], mb[3], a1, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wrow[q] = a0[q] + a1[q];          // w_i = (V mu_bar)_i, i = lk + 4 q, in every column
+      }
+      s = xor32_sum_f64(xor16_sum_f64(fma(mb[0], wrow[0], mb[1] * wrow[1]) + fma(mb[2], wrow[2], mb[3] * wrow[3])));
+      if (p.pbar_predict) {
+        if (dense) {
+          // Pbar = F P F^T + Q: T = P F^T, then F T
+          double Fr[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) Fr[q] = sF[lr * RS + lk + 4 * q];            // F[lr][lk + 4 q]
+          f64x4 t0 = {0.0, 0.0, 0.0, 0.0}, t1 = {0.0, 0.0, 0.0, 0.0};
+          t0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Pm[0], Fr[0], t0, 0, 0, 0);
+          t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Pm[1], Fr[1], t1, 0, 0, 0);
+          t0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Pm[2], Fr[2], t0, 0, 0, 0);
+          t1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Pm[3], Fr[3], t1, 0, 0, 0);
+          f64x4 u0 = {0.0, 0.0, 0.0, 0.0}, u1 = {0.0, 0.0, 0.0, 0.0};
+          u0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Fr[0], t0[0] + t1[0], u0, 0, 0, 0);
+          u1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Fr[1], t0[1] + t1[1], u1, 0, 0, 0);
+          u0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Fr[2], t0[2] + t1[2], u0, 0, 0, 0);
+          u1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Fr[3], t0[3] + t1[3], u1, 0, 0, 0);
+          // symmetrise (F P F^T is symmetric up to round-off) through a tile image: (X + X^T) / 2, bitwise symmetric
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { Pb[q] = fma(qs, Qm[q], u0[q] + u1[q]); s_img[q * 64 + lane] = Pb[q]; }
+#pragma unroll
+          for (int q = 0; q < 4; ++q) Pb[q] = 0.5 * (Pb[q] + s_img[trx[q]]);
+        } else {
+          const double fc = s_f[lr];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) Pb[q] = fma(s_f[lk + 4 * q] * Pm[q], fc, qs * Qm[q]);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Pb[q] = Pm[q];
+      }
+      if (p.eta_full) {
+        const double tr = fma(Gm[0], Pb[0], Gm[1] * Pb[1]) + fma(Gm[2], Pb[2], Gm[3] * Pb[3]);
+        eta += wave_sum_f64_dpp(tr) / dd;
+      }
+      N = s + eta;
+      invN = fast_rcp(N);
+      kappa = fast_rcp(rho + s);
+      if (lr == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s_w[lk + 4 * q] = wrow[q];
+      }
+      if (lane == 0) { s_sc[0] = s; s_sc[1] = eta; s_sc[2] = N; s_sc[3] = invN; s_sc[4] = kappa; s_sc[5] = lam; }
+      // (LDS operations of one wave complete in program order: the flag needs no release fence -- which would also wait for
+      //  this wave's outstanding global stores)
+      asm volatile("" ::: "memory");
+      if (lane == 0) __hip_atomic_store(s_flag, jb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (p.coef_update) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) A[q] = Pb[q] + fpad[q];
+        wave_sweep16m(A, r2, swk, bad);                 // -Pbar^-1
+      }
+    } else if (wv == 1) {
+      // ================= phase A, coefficient wave: lane = coefficient row =================
+      const int m = lane;
+      double pb = 0.0, pk = 0.0;
+      for (int c = 0; c < r; ++c) {
+        const double mu_c = s_mub[c];
+        pb = fma(sA[m * RS + c], mu_c, pb);
+        pk = fma(sKA[m * RS + c], mu_c, pk);
+      }
+      const double am = (m == r + jb ? 1.0 : 0.0) - pb;
+      const double kam = sK[m * RB + r + jb] - pk;
+      s_a[m] = am;
+      s_Ka[m] = kam;
+      b.Bcoef[(size_t)jb * RB + m] = pb;
+      // h = A^T Ka: column j = lr, the sixteen rows 16 lk .. 16 lk + 15 per lane, then across the four lane rows
+      double ph = 0.0;
+      if (lr < r) {
+#pragma unroll 4
+        for (int mm = 0; mm < 16; ++mm) ph = fma(sA[(16 * lk + mm) * RS + lr], s_Ka[16 * lk + mm], ph);
+      }
+      const double hj = xor32_sum_f64(xor16_sum_f64(ph));
+      if (lane < 16) s_h[lane] = hj;
+      const double ee1 = wave_sum_f64_dpp(am * kam);
+      if (lane == 0) s_sc[6] = ee1;
+      // theta gradient at the pre-update state: g_f = d(incremental likelihood)/df (psmf.py:57-64, rpsmf.py:62-71)
+      if (has_bw) {
+        while (__hip_atomic_load(s_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < jb + 1) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        if (lane < r) {
+          const double Nn = s_sc[2], iN = s_sc[3], lm = s_sc[5], wi = s_w[lane];
+          double gf;
+          if (p.robust) {
+            const double D = lm * Nn;
+            gf = dd * wi / Nn + 0.5 * (dd + lm) * (-2.0 * hj / D - 2.0 * lm * ee1 * wi / (D * D)) / (1.0 + ee1 / D);
+          } else {
+            gf = dd * wi * iN - hj * iN - ee1 * wi * iN * iN;
+          }
+          s_gf[lane] = gf;
+        }
+      }
+    }
+    __syncthreads();                                     // ---- A | B
+    if (wv == 0) {
+      // ================= phase B, matrix wave =================
+      const double ee = s_sc[6];
+      double hrow[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) hrow[q] = s_h[lk + 4 * q];
+      const double hcol = s_h[lr], wcol = s_w[lr];
+      double Pp[4], quad = kappa * ee;
+      if (p.coef_update) {
+        // M = Pbar^-1 + kappa G, augmented with kappa h in row / column r2
+        const double khc = kappa * hcol;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          A[q] = fma(kappa, Gm[q], fpad[q] - finq[q] * A[q]) + (faugc[q] * (kappa * hrow[q]) + faugr[q] * khc);
+        wave_sweep16m(A, r2, swk, bad);                 // [[-P+, kappa P+ h], [., 1 - kappa^2 h'P+h]]
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Pp[q] = -finq[q] * A[q];
+        const double a_c = rq_c == 0 ? A[0] : (rq_c == 1 ? A[1] : (rq_c == 2 ? A[2] : A[3]));
+        quad += readlane_f64(a_c, ln_c) - 1.0;          // kappa e'e - kappa^2 h'P+h  (psmf.py:155-165)
+        if (lr == r2) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) s_munew[lk + 4 * q] = fma(fxr[q], A[q], mb[q]);      // mu = mu_bar + kappa P+ h
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Pp[q] = Pb[q];
+        if (lr == 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) s_munew[lk + 4 * q] = mb[q];
+        }
+      }
+      double vscale = 1.0, pscale = 1.0, qscale = 1.0;
+      phi = 1.0; omega = 1.0;
+      if (p.robust) {
+        const double ild = fast_rcp(lam + dd);
+        phi = (lam + ee * invN) * ild;
+        omega = (lam + quad) * ild;
+        vscale = p.alpha * phi;
+        if (p.coef_update) { pscale = p.beta * omega; qscale = omega; }
+        rho *= omega;
+        if (!p.fixed_lambda) lam += dd;
+      }
+      // V, P, G, Q of the step (psmf.py:150-170; G: the tracked Gram of C)
+      const double wj = wcol * invN, ew = ee * invN;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        Vm[q] = vscale * fma(-(wrow[q] * wcol), invN, Vm[q]);       // (w_i w_j first: bitwise symmetric)
+        Pm[q] = pscale * Pp[q];
+        Gm[q] += finq[q] * (fma(hrow[q], wj, wrow[q] * (hcol * invN)) + ew * (wrow[q] * wj));
+        Qm[q] *= qscale;
+      }
+      // rank-1 updates of the coefficient matrices, lane = row
+      {
+        const int m = lane;
+        const double am = s_a[m] * invN, km = s_Ka[m] * invN;
+        for (int c = 0; c < r; ++c) {
+          const double wc = s_w[c];
+          sA[m * RS + c] = fma(am, wc, sA[m * RS + c]);
+          sKA[m * RS + c] = fma(km, wc, sKA[m * RS + c]);
+        }
+      }
+      s_last = s; eta_last = eta; N_last = N; ee_last = ee;
+      if (has_bw) __syncthreads();                       // (the barrier that ends dyn_backward on the other waves)
+    } else {
+      // ================= phase B, waves 1-3: gradsum += J_theta^T g_f =================
+      if (has_bw) dyn_backward<WG - 64>(pd, (double)kstep, s_mu, s_gf, s_val, s_tp, tid - 64);        // ends with a barrier
+    }
+    __syncthreads();           // the step's mu, A, K A are complete; every read of s_mu, s_w, s_h, s_a, s_Ka is done
+    if (tid < r) {
+      const double mu_new = s_munew[tid];
+      s_mu[tid] = mu_new;
+      if (p.mu_hist) p.mu_hist[(size_t)(kstep - p.series_t0) * r + tid] = mu_new;
+    }
+    __syncthreads();
+    // PSMFRecursive: optimiser step on theta every update_every observations (psmf.py:299-304)
+    if (p.recursive && p.n_theta > 0 && (kstep % p.update_every) == 0) dyn_adam_step<WG>(pd, kstep, tid);
+  }
+
+  // ---- block end: coefficients and state back to memory ----
+  for (int idx = tid; idx < RB * r; idx += WG) { const int m = idx / r; b.Acoef[idx] = sA[m * RS + (idx - m * r)]; }
+  if (th_lds)
+    for (int idx = tid; idx < p.n_theta; idx += WG) { p.gradsum[idx] = s_grad[idx]; if (p.recursive) p.theta[idx] = s_theta[idx]; }
+  if (wv == 0) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = lk + 4 * q;
+      if (i < r && lr < r) {
+        const int idx = i * r + lr;
+        st->V[idx] = Vm[q];
+        st->P[idx] = Pm[q];
+        st->Q[idx] = Qm[q];
+        st->G[idx] = Gm[q];
+      }
+    }
+    if (bad) *errflag = 1;
+  }
+  if (tid < r) st->mu[tid] = s_mu[tid];
+  __syncthreads();
+  if (tid == 0) {
+    st->k = b.k0 + b.nb;
+    st->rho = rho; st->lam = lam; st->phi = phi; st->omega = omega; st->ee = ee_last;
+    st->s_done = s_last; st->eta_done = eta_last; st->N_done = N_last;
+    if (*errflag && st->err == 0) st->err = (int)(b.k0 + 1);
+    st->ns_valid = 0;          // nothing the two-inversion kernels carry from block to block describes this state
+  }
+}
+
+}  // namespace psmf

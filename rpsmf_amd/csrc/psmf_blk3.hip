@@ -115,7 +115,7 @@ struct F3Lds {
   double* a;        // RB
   double* Ka;       // RB
   double* sc;       // F3_NSC
-  double* nrm;      // [2][4]
+  double* nrm;      // [2][4] residual norms by dump parity and NS wave | 8: ns_tol2, 9: ns_far2, 10: ns_tol2 / 4
   double* hv;       // 2
   double* gp;       // 2
   double* tr;       // 2
@@ -285,10 +285,12 @@ struct F3Ctl {
     const double ny_ = L.nrm[par * 4 + 2] + L.nrm[par * 4 + 3];                                            \
     const double worst_ = fmax(nx_, ny_);                                                                  \
     ++ctl.c_it;                                                                                            \
-    if (worst_ < p.ns_tol2) done = true;          /* ||R|| below the tolerance BEFORE the update just made */ \
-    else if (!(worst_ < p.ns_far2) || it == F3_MAXIT - 1) failed = true;  /* start too far or not converging */   \
+    /* the thresholds are read from LDS beside the norms (L.nrm[8..10]): as kernel arguments they were kept in VGPRs,   */ \
+    /* spilled, and reloaded from scratch in front of every one of these comparisons (scratch_load; s_waitcnt vmcnt(0)) */ \
+    if (worst_ < L.nrm[8]) done = true;           /* ||R|| below the tolerance BEFORE the update just made */ \
+    else if (!(worst_ < L.nrm[9]) || it == F3_MAXIT - 1) failed = true;   /* start too far or not converging */   \
     /* ||R_next||_F <= (||R||_F + ||M (Xc - Xa)||) ||R||_F: one more iteration is the last, no check needed */   \
-    else last = worst_ * worst_ < 0.25 * p.ns_tol2;                                                        \
+    else last = worst_ * worst_ < L.nrm[10];                                                               \
     if (F3_KNOCK & 1) { done = false; failed = false; last = true; }      /* always exactly two iterations */ \
   } while (0)
 
@@ -621,6 +623,12 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Blk&
         vq0 += Xc[qq] * wrow[qq]; vq1 += Xc[4 + qq] * wrow[4 + qq];
       }
       const double vp = xor32_sum_f64(xor16_sum_f64(vp0 + vp1));
+      // (the lane index made opaque here: the LDS / global addresses and the lane predicate of the stores below are then formed
+      //  on the spot -- three integer instructions -- instead of being hoisted out of the step loop, spilled, and reloaded from
+      //  scratch right in front of the barrier that ends the step: scratch_load; s_waitcnt vmcnt(0); ds_write, three times per step)
+      int lane_f = lane;
+      asm volatile("" : "+v"(lane_f));
+      const int lcol = lane_f & 15, lrow = lane_f >> 4;
       const int j = 16 * C + lcol;
       if (isX) {
         const double mu_new = mub_j + kap_k * vp;
@@ -984,7 +992,7 @@ __device__ __forceinline__ void blk_filter3_body(const BlockParams& b0) {
   // Everything a step touches sits in STATIC LDS: its addresses are compile-time constants that fold into the ds
   // instructions' immediate offsets.  (Off the dynamic-LDS base the compiler formed (lane part + constant) + base for
   // every row / column it reads and kept each sum in a VGPR of its own across the loop: 136 spilled registers.)
-  __shared__ __attribute__((aligned(16))) double hot[2 * 4 * 8 * 64 + 3 * RM + 2 * RB + F3_NSC + 8 + 6 + 8 * 32];
+  __shared__ __attribute__((aligned(16))) double hot[2 * 4 * 8 * 64 + 3 * RM + 2 * RB + F3_NSC + 12 + 6 + 8 * 32];
   __shared__ __attribute__((aligned(16))) float hotP[2 * 4 * 2 * 64 * 4];
   __shared__ __attribute__((aligned(16))) float hotS[2 * 128];
   F3Lds L;
@@ -1004,7 +1012,7 @@ __device__ __forceinline__ void blk_filter3_body(const BlockParams& b0) {
   L.Ka = L.a + RB;
   L.sc = L.Ka + RB;
   L.nrm = L.sc + F3_NSC;
-  L.hv = L.nrm + 8;
+  L.hv = L.nrm + 12;
   L.gp = L.hv + 2;
   L.tr = L.gp + 2;
   L.sab = L.tr + 2;
@@ -1016,6 +1024,7 @@ __device__ __forceinline__ void blk_filter3_body(const BlockParams& b0) {
   __shared__ __attribute__((aligned(16))) double hot4[KIND >= 1 ? 5 * RM + 2 * 48 + F4_NKC : 2];
   F4Lds D;
   D.fd = hot4; D.mu = D.fd + RM; D.tp = D.mu + RM; D.th = D.tp + RM; D.rs = D.th + 2 * RM; D.qs = D.rs + 48; D.kc = D.qs + 48;
+  if (tid0 == 0) { L.nrm[8] = p.ns_tol2; L.nrm[9] = p.ns_far2; L.nrm[10] = 0.25 * p.ns_tol2; }   // (read behind the barriers of the block set-up)
 
   // ---- one launch = `chain` consecutive blocks (1 when the blocks are launched one by one) ----
   // Chained, the blocks of a run pay the kernel launch, the cold instruction cache and the hand-off round trips once

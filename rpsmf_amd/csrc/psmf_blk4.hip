@@ -39,9 +39,9 @@ struct F4Lds {
   do {                                                                                                     \
     const double w_ = L.nrm[(par_) * 4 + (base_)] + L.nrm[(par_) * 4 + (base_) + 1];                       \
     ++ctl.c_it;                                                                                            \
-    if (w_ < p.ns_tol2) done_ = true;             /* ||R|| below the tolerance BEFORE the update just made */ \
-    else if (!(w_ < p.ns_far2) || (it_) == F3_MAXIT - 1) failed_ = true;                                   \
-    else last_ = w_ * w_ < 0.25 * p.ns_tol2;      /* one more iteration is the last: no check needed */     \
+    if (w_ < L.nrm[8]) done_ = true;              /* ||R|| below the tolerance BEFORE the update just made */ \
+    else if (!(w_ < L.nrm[9]) || (it_) == F3_MAXIT - 1) failed_ = true;                                    \
+    else last_ = w_ * w_ < L.nrm[10];             /* one more iteration is the last: no check needed */     \
   } while (0)
 
 // The direct symmetric sweep of ONE 32 x 32 image (in place, A <- A^-1) by the four VECTOR waves -- one per SIMD, so that a pivot

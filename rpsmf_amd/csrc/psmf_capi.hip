@@ -6,6 +6,7 @@
 #include <chrono>
 #include "psmf_block.hip"
 #include "psmf_blk3.hip"
+#include "psmf_blk16.hip"
 #include "psmf_bulk.hip"
 
 #include <rccl/rccl.h>
@@ -39,11 +40,11 @@ constexpr int kGramWG = 128;
 // Environment switches ("Switches"): read ONCE per handle, at psmf_create -- tests flip them between
 // handles of one process; nothing on the per-block host path calls getenv.
 struct Switches {
-  bool block_mfma = true, bulk2 = true, filter3 = true, filter4 = true, block_dual = true, block_flags = true, block_chain = true, block_pipe = true;
+  bool block_mfma = true, bulk2 = true, filter3 = true, filter4 = true, filter6 = true, block_dual = true, block_flags = true, block_chain = true, block_pipe = true;
   bool force_collective = false;
   static bool off(const char* name) { const char* e = getenv(name); return e && atoi(e) == 0; }
   void read() {
-    block_mfma = !off("PSMF_BLOCK_MFMA"); bulk2 = !off("PSMF_BULK2"); filter3 = !off("PSMF_FILTER3"); filter4 = !off("PSMF_FILTER4"); block_dual = !off("PSMF_BLOCK_DUAL");
+    block_mfma = !off("PSMF_BLOCK_MFMA"); bulk2 = !off("PSMF_BULK2"); filter3 = !off("PSMF_FILTER3"); filter4 = !off("PSMF_FILTER4"); filter6 = !off("PSMF_FILTER6"); block_dual = !off("PSMF_BLOCK_DUAL");
     block_flags = !off("PSMF_BLOCK_FLAGS"); block_chain = !off("PSMF_BLOCK_CHAIN"); block_pipe = !off("PSMF_BLOCK_PIPE");
     force_collective = getenv("PSMF_FORCE_COLLECTIVE") != nullptr;
   }
@@ -316,6 +317,9 @@ bool blk_simpl_ok(const psmf_filter* h) {
          !h->sp.q_sched;
 }
 
+// filter6 (psmf_blk16.hip): the general block filter for r <= 14, role-specialised (whatever the kernels above do not take)
+bool blk_small_ok(const psmf_filter* h) { return h->sw.filter6 && h->cfg.r <= psmf::F6_RMAX; }
+
 void launch_blk_filter(psmf_filter* h, const psmf::BlockParams& b, hipStream_t stream = nullptr) {
   if (!stream) stream = h->stream;
   if (blk_simpl_ok(h)) {
@@ -342,6 +346,10 @@ void launch_blk_filter(psmf_filter* h, const psmf::BlockParams& b, hipStream_t s
     return;
   }
   const size_t lds = psmf::blk_filter_lds_bytes();
+  if (blk_small_ok(h)) {
+    hipLaunchKernelGGL(psmf::psmf_blk_filter6, dim3(1), dim3(psmf::WG), lds, stream, b);
+    return;
+  }
   switch (h->geo.rpad) {
     case 8: hipLaunchKernelGGL(psmf::psmf_blk_filter<8>, dim3(1), dim3(psmf::WG), lds, stream, b); break;
     case 16: hipLaunchKernelGGL(psmf::psmf_blk_filter<16>, dim3(1), dim3(psmf::WG), lds, stream, b); break;
@@ -780,6 +788,7 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
       h->streams_concurrent = res == 1;
     }
     const size_t flds = psmf::blk_filter_lds_bytes();
+    CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_filter6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_filter<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_filter<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_filter<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
@@ -1253,7 +1262,7 @@ int psmf_filter_kernel(psmf_handle h) {
   if (blk_dual_ok(h) && blk_use_filter3(h)) return h->cfg.r > 16 ? 3 : 4;
   if (blk_seq_ok(h)) return h->cfg.r > 16 ? 5 : 6;
   if (blk_dual_ok(h)) return 2;
-  return 1;
+  return blk_small_ok(h) ? 8 : 1;
 }
 
 int psmf_counters(psmf_handle h, int64_t* out8, int reset) {

@@ -1,0 +1,79 @@
+// Single-wave r x r routines on a 16 x 16 float64 tile in the MFMA output layout (lane l: column lr = l & 15, rows lk + 4 q,
+// lk = l >> 4) -- used by the masked small-shape column loop (psmf_impute3.hip) and by the small-rank block filter (psmf_blk16.hip).
+//
+// Cost model of a wave that has its SIMD to itself (measured with knock-outs of a pivot round, tools/impute_prof.hip): it issues
+// one instruction per 4-8 cycles whatever the instruction is -- a float64 VALU operation ~8, a 32-bit one ~4, a 16x16x4 float64
+// MFMA ~76 including the wait for its result -- so these routines are written for INSTRUCTION COUNT: lane predicates are kept as
+// 0.0 / 1.0 multipliers in VGPRs (a select of a double is two v_cndmask plus, in a kernel that has run out of SGPRs, the reload
+// of its lane mask from a spilled SGPR pair: two v_readlane), and the kernels that use them ask for at most 256 registers per
+// wave (amdgpu_waves_per_eu(2)) so that the compiler selects the MFMAs with VGPR accumulators (with 512 on offer it puts them in
+// AGPRs: 16 copies and a 16-cycle stall per pivot round).
+#pragma once
+#include "psmf_blk3.hip"      // readlane_f64, DPP sums, f64x4
+
+namespace psmf {
+
+// Per-lane constants of wave_sweep16m as numbers (lane: column lr = l & 15, rows lk + 4 q, lk = l >> 4); round j pivots on
+// rows / columns 2 j, 2 j + 1, which are register A[j >> 1] of the lane rows lk = 2 (j & 1), 2 (j & 1) + 1.
+struct Sw16K {
+  double pc0[8], pc1[8];   // lr == 2 j, lr == 2 j + 1
+  double fnp[8];           // 1 - pc0 - pc1: not a pivot column
+  double sg[8];            // lanes of the pivot rows: +1 at the pivot columns, -1 elsewhere; other lanes 0
+  double fpiv[2], fnpiv[2];   // lanes that hold the pivot rows (lk >> 1 == j & 1), and 1 - that
+  double fu, fw;           // lk even (row 2 j of the pair) / odd (row 2 j + 1)
+};
+__device__ __forceinline__ void sw16k_init(Sw16K& c, const int lk, const int lr) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    c.pc0[j] = lr == 2 * j ? 1.0 : 0.0;
+    c.pc1[j] = lr == 2 * j + 1 ? 1.0 : 0.0;
+    c.fnp[j] = 1.0 - c.pc0[j] - c.pc1[j];
+    const double piv = (lk >> 1) == (j & 1) ? 1.0 : 0.0;
+    c.sg[j] = piv * (2.0 * (c.pc0[j] + c.pc1[j]) - 1.0);
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) { c.fpiv[h] = (lk >> 1) == h ? 1.0 : 0.0; c.fnpiv[h] = 1.0 - c.fpiv[h]; }
+  c.fu = (lk & 1) == 0 ? 1.0 : 0.0;
+  c.fw = 1.0 - c.fu;
+}
+
+// wave_sweep16 (psmf_impute.hip) with the lane predicates as multipliers: A <- -A^-1 of the leading r2 x r2 block by 2 x 2
+// SPD block pivots, the rank-2 update of a round on the matrix cores, the pivot block by v_readlane.
+//   Ki = K^-1 of the pivot block;  t_j = Ki [u_j; w_j] (u, w = rows 2 j, 2 j + 1);  the MFMA's B operand holds -t in the
+//   pivot rows' lanes (+Ki at the pivot columns, whose C input is zeroed), its A operand the pivot rows as they stand
+//   (= the pivot columns, by symmetry);  afterwards the pivot rows are overwritten with t (-Ki inside the block).
+__device__ __forceinline__ void wave_sweep16m(double (&A)[4], const int r2, const Sw16K& c, bool& bad) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    if (2 * j < r2) {                              // uniform
+      const int k = 2 * j, h = j & 1, kq = j >> 1, b0 = h << 5, b1 = b0 + 16;
+      const double rk = A[kq];
+      const double ka = readlane_f64(rk, b0 | k), kb = readlane_f64(rk, b0 | (k + 1)), ke = readlane_f64(rk, b1 | (k + 1));
+      const double det = ka * ke - kb * kb;
+      bad |= !(ka > 0.0) | !(det > 0.0);
+      // 1 / det: v_rcp_f64 (~1e-8) and ONE cubic step x (1 + e + e^2), e = 1 - det x -- three dependent operations
+      // instead of the four of two Newton steps (this chain is the round's critical path)
+      const double x0 = __builtin_amdgcn_rcp(det);
+      const double e1 = fma(-det, x0, 1.0);
+      const double dinv = fma(x0 * e1, 1.0 + e1, x0);
+      // u_j (even row of the pair) and w_j (odd row) in both rows of each pair
+      const unsigned lo = __double2loint(rk), hi = __double2hiint(rk);
+      const auto l2 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+      const auto h2 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+      const double uj = __hiloint2double(h2[0], l2[0]), wj = __hiloint2double(h2[1], l2[1]);
+      // det * (row of Ki that belongs to this lane's pivot row): even row [ke, -kb], odd row [-kb, ka]
+      const double cu = c.fu * ke - c.fw * kb, cw = c.fw * ka - c.fu * kb;
+      const double u1 = fma(uj, c.fnp[j], c.pc0[j]), w1 = fma(wj, c.fnp[j], c.pc1[j]);     // pivot columns: unit vectors -> the entries of Ki
+      const double pre = fma(cu, u1, cw * w1) * c.sg[j];       // everything of the B operand but 1 / det
+      const double aop = rk * c.fpiv[h];
+      const double bop = pre * dinv;
+      f64x4 acc = {c.fnp[j] * A[0], c.fnp[j] * A[1], c.fnp[j] * A[2], c.fnp[j] * A[3]};
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop, acc, 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) A[q] = acc[q];
+      A[kq] = fma(acc[kq], c.fnpiv[h], -bop);      // the pivot rows: t; pivot block: -Ki
+    }
+  }
+}
+
+}  // namespace psmf
