@@ -30,8 +30,12 @@ def build_library(force=False, verbose=True):
         return LIB_PATH
     os.makedirs(LIB_DIR, exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    # -amdgpu-mfma-vgpr-form: MFMAs with VGPR accumulators in every kernel.  By default the compiler takes that form only
+    # when a wave is limited to 256 registers (512-thread workgroups); the 256-thread kernels got accumulators in AGPRs and a
+    # copy in and out around every dependent MFMA.  With the flag they keep all 512 registers AND the short form, and what
+    # does not fit the 256 VGPRs is parked in AGPRs (one instruction) instead of scratch memory.
     cmd = [hipcc, "-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-Wno-unused-value",
-           "-I", os.path.join(ROOT, "include"), "-o", LIB_PATH] + SOURCES + ["-L/opt/rocm/lib", "-lrccl",
+           "-mllvm", "-amdgpu-mfma-vgpr-form", "-I", os.path.join(ROOT, "include"), "-o", LIB_PATH] + SOURCES + ["-L/opt/rocm/lib", "-lrccl",
            "-Wl,-rpath,/opt/rocm/lib"]
     if verbose:
         print(" ".join(cmd), flush=True)

@@ -27,7 +27,7 @@ namespace psmf {
 
 constexpr int F6_RMAX = 14;
 
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2))) void psmf_blk_filter6(BlockParams b) {
+__global__ __launch_bounds__(WG) void psmf_blk_filter6(BlockParams b) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* sm = reinterpret_cast<double*>(smem_raw);
   const StepParams& p = b.sp;
@@ -122,10 +122,12 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2))) void ps
   __syncthreads();
 
   double s_last = 0.0, eta_last = 0.0, N_last = 0.0, phi = 1.0, omega = 1.0, ee_last = 0.0;
+  BLK_T0();
   for (int jb = 0; jb < b.nb; ++jb) {
     const long long kstep = b.k0 + jb + 1;   // 1-based step index
     // ---- mu_bar = f(theta, mu, k), F = df/dx (psmf.py:104-115; psmf_dyn.hip) ----
     dyn_forward<WG>(pd, (double)kstep, s_mu, s_mub, s_f, sF, RS, s_val, s_tp, sT, tid);     // ends with a barrier
+    BLK_T(0);
     // PSMFIter reads Q[k], R[k] of the step (psmf.py:115,123,141): scalar schedules (never with rPSMF's running Q, R)
     const double qs = p.q_sched ? p.q_sched[kstep - p.series_t0] : 1.0;
     if (p.rho_sched) rho = p.rho_sched[kstep - p.series_t0];
@@ -191,6 +193,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2))) void ps
       //  this wave's outstanding global stores)
       asm volatile("" ::: "memory");
       if (lane == 0) __hip_atomic_store(s_flag, jb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      BLK_T(1);
       if (p.coef_update) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) A[q] = Pb[q] + fpad[q];
@@ -237,7 +240,9 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2))) void ps
         }
       }
     }
+    BLK_T(2);
     __syncthreads();                                     // ---- A | B
+    BLK_T(3);
     if (wv == 0) {
       // ================= phase B, matrix wave =================
       const double ee = s_sc[6];
@@ -253,6 +258,7 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2))) void ps
         for (int q = 0; q < 4; ++q)
           A[q] = fma(kappa, Gm[q], fpad[q] - finq[q] * A[q]) + (faugc[q] * (kappa * hrow[q]) + faugr[q] * khc);
         wave_sweep16m(A, r2, swk, bad);                 // [[-P+, kappa P+ h], [., 1 - kappa^2 h'P+h]]
+        BLK_T(4);
 #pragma unroll
         for (int q = 0; q < 4; ++q) Pp[q] = -finq[q] * A[q];
         const double a_c = rq_c == 0 ? A[0] : (rq_c == 1 ? A[1] : (rq_c == 2 ? A[2] : A[3]));
@@ -300,11 +306,13 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2))) void ps
         }
       }
       s_last = s; eta_last = eta; N_last = N; ee_last = ee;
+      BLK_T(5);
       if (has_bw) __syncthreads();                       // (the barrier that ends dyn_backward on the other waves)
     } else {
       // ================= phase B, waves 1-3: gradsum += J_theta^T g_f =================
       if (has_bw) dyn_backward<WG - 64>(pd, (double)kstep, s_mu, s_gf, s_val, s_tp, tid - 64);        // ends with a barrier
     }
+    BLK_T(6);
     __syncthreads();           // the step's mu, A, K A are complete; every read of s_mu, s_w, s_h, s_a, s_Ka is done
     if (tid < r) {
       const double mu_new = s_munew[tid];
@@ -314,7 +322,9 @@ __global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2))) void ps
     __syncthreads();
     // PSMFRecursive: optimiser step on theta every update_every observations (psmf.py:299-304)
     if (p.recursive && p.n_theta > 0 && (kstep % p.update_every) == 0) dyn_adam_step<WG>(pd, kstep, tid);
+    BLK_T(7);
   }
+  BLK_TOUT();
 
   // ---- block end: coefficients and state back to memory ----
   for (int idx = tid; idx < RB * r; idx += WG) { const int m = idx / r; b.Acoef[idx] = sA[m * RS + (idx - m * r)]; }

@@ -399,7 +399,7 @@ __device__ __forceinline__ void impute3_wave(const ImputeParams& p) {
 // amdgpu_waves_per_eu(2): at most 256 registers per wave, which is what makes the compiler select the MFMAs with VGPR
 // accumulators (see the header)
 template <int NG>
-__global__ __launch_bounds__(WG) __attribute__((amdgpu_waves_per_eu(2))) void psmf_impute_kernel3(ImputeParams p) {
+__global__ __launch_bounds__(WG) void psmf_impute_kernel3(ImputeParams p) {
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (wv == 0) impute3_wave<0, NG>(p);
   else if (wv == 1) impute3_wave<1, NG>(p);

@@ -196,7 +196,9 @@ def test_config_D_full_length_seed_vs_oracle(robust):
     res = impute.impute_batch(Yint, M, Mm, C0, X0, V, Q, 10.0, P, 2, 2, robust=robust, lambda0=1.8)
     # float64 on both sides; 6e5 sequential steps of a contracting filter: agreement stays at round-off level
     assert relerr(res["Epred"][0], ep[0, 1:]) < 1e-8 and relerr(res["Efull"][0], ef[0, 1:]) < 1e-8
-    assert abs(res["inside"][0] - ib) < 1e-9
+    # coverage = a COUNT of held-out entries inside the band over their number (2.2 million here): an entry within round-off of
+    # a band edge may fall on either side (the two sides sum the masked Gram in different orders) -- at most two such entries
+    assert abs(res["inside"][0] - ib) * float(Mm[0].sum()) < 2.5
     assert relerr(res["C"][0], st["C"]) < 1e-7 and relerr(res["X"][0], st["X"]) < 1e-7
 
 
