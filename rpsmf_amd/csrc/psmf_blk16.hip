@@ -27,13 +27,148 @@ namespace psmf {
 
 constexpr int F6_RMAX = 14;
 
-__global__ __launch_bounds__(WG) void psmf_blk_filter6(BlockParams b) {
+// dyn_forward / dyn_backward (psmf_dyn.hip) for the trigonometric kinds at r <= 14, theta in LDS: the same sums in the same
+// order, but with 16-wide index maps (thread = (term or row, column): no integer division by the runtime r) and every LDS
+// operand of a sum loaded before the first use.  (The generic loops wait for one LDS round trip per term of every sum and divide
+// twice per element: 5 600 + 6 000 cycles of a 17 000-cycle FourierBasis step, tools/blk16_prof.hip.)  Needs s_val, s_tp zero
+// beyond column r, s_gf zero beyond r, and finite values in the 256 doubles behind theta (the caller clears them).
+// th, g: theta and the gradient sum AS LDS ARRAYS (through StepParams they are generic pointers: flat loads)
+__device__ __forceinline__ void f6_dyn_forward(const StepParams& p, const double* th, const double tk, const double* s_x, double* s_mub, double* s_fd,
+                                               double* sF, const int ldf, double* s_val, double* s_tp, double* s_part, const int tid) {
+  // tid = 0 .. 191: waves 1-3 (the matrix wave only keeps the barrier count, f6_dyn_barriers)
+  const int r = p.r, kind = p.dyn_kind, flags = p.dyn_flags, N = p.dyn_terms;
+  const int nt = dyn_n_terms(kind, N);
+  const int t = tid >> 4, j = tid & 15;
+  const bool act = t < nt && j < r;
+  const DynTerm d = dyn_term(kind, flags, N, r, min(t, nt - 1));
+  if (act) {
+    const double c = d.c_off >= 0 ? th[d.c_off + j] : 1.0;
+    double sn, cs;
+    dyn_sincospi(2.0 * th[d.b_off + j] * tk + (c * s_x[j]) * 0.31830988618379067154, sn, cs);
+    s_val[t * RM + j] = d.is_cos ? cs : sn;
+    s_tp[t * RM + j] = d.is_cos ? -sn : cs;
+  }
+  __syncthreads();
+  const bool dense = dyn_dense(kind, flags);
+  if (!dense && kind != DYN_FOURIER) {      // one term, no matrix: mu_bar and the diagonal of F straight from the trig values
+    if (tid < r) {
+      s_mub[tid] = s_val[tid];
+      s_fd[tid] = s_tp[tid] * (d.c_off >= 0 ? th[d.c_off + tid] : 1.0);      // (t = 0 for these threads)
+    }
+    __syncthreads();
+    return;
+  }
+  if (act) {      // the term's share of mu_bar_i, i = j
+    double a;
+    if (d.m_off >= 0) {
+      const double* row = th + d.m_off + j * r;
+      double mv[F6_RMAX], sv[F6_RMAX];
+#pragma unroll
+      for (int q = 0; q < F6_RMAX; ++q) { mv[q] = row[q]; sv[q] = s_val[t * RM + q]; }     // (columns >= r: finite times zero)
+      a = 0.0;
+#pragma unroll
+      for (int q = 0; q < F6_RMAX; ++q) a += mv[q] * sv[q];
+    } else {
+      a = s_val[t * RM + j];
+    }
+    s_part[t * RM + j] = a;
+  }
+  if (dense) {    // F[i][j], thread = element
+#pragma unroll
+   for (int k = 0; k < 2; ++k) {
+    const int idx = tid + 192 * k, i = idx >> 4;
+    if (i < r && j < r) {
+      double mv[DYN_MAX_TERMS], dv[DYN_MAX_TERMS];
+#pragma unroll
+      for (int tt = 0; tt < DYN_MAX_TERMS; ++tt) {
+        mv[tt] = 0.0; dv[tt] = 0.0;
+        if (tt < nt) {
+          const DynTerm dt = dyn_term(kind, flags, N, r, tt);
+          dv[tt] = s_tp[tt * RM + j] * (dt.c_off >= 0 ? th[dt.c_off + j] : 1.0);
+          mv[tt] = dt.m_off >= 0 ? th[dt.m_off + i * r + j] : ((i == j) ? 1.0 : 0.0);
+        }
+      }
+      double a = 0.0;
+#pragma unroll
+      for (int tt = 0; tt < DYN_MAX_TERMS; ++tt)
+        if (tt < nt) a += mv[tt] * dv[tt];
+      sF[i * ldf + j] = a;
+    }
+   }
+  }
+  __syncthreads();
+  if (tid < r) {
+    double a = 0.0, fd = 0.0;
+    for (int tt = 0; tt < nt; ++tt) {
+      const DynTerm dt = dyn_term(kind, flags, N, r, tt);
+      a += s_part[tt * RM + tid];
+      if (dt.m_off < 0) fd += s_tp[tt * RM + tid] * (dt.c_off >= 0 ? th[dt.c_off + tid] : 1.0);
+    }
+    s_mub[tid] = a;
+    if (!dense) s_fd[tid] = fd;
+  }
+  __syncthreads();
+}
+
+// barriers of dyn_forward / f6_dyn_forward for a wave that takes no part in it
+__device__ __forceinline__ int f6_dyn_barriers(const StepParams& p) {
+  if (p.dyn_kind == DYN_RANDOM_WALK || p.dyn_kind == DYN_SCALED_WALK) return 1;
+  return (!dyn_dense(p.dyn_kind, p.dyn_flags) && p.dyn_kind != DYN_FOURIER) ? 2 : 3;
+}
+
+// gradsum += J_theta^T g_f on NTH = 192 threads (tid3 = 0 .. 191); ends with a barrier
+__device__ __forceinline__ void f6_dyn_backward(const StepParams& p, const double* th, double* g, const double tk, const double* s_x,
+                                                const double* s_gf, const double* s_val, const double* s_tp, const int tid3) {
+  const int r = p.r, kind = p.dyn_kind, flags = p.dyn_flags, N = p.dyn_terms;
+  const int nt = dyn_n_terms(kind, N);
+  // d/dM_t[i][j] = g_f[i] trig_t(arg_tj): thread = element (i, j), every term
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int idx = tid3 + 192 * k, i = idx >> 4, j = idx & 15;
+    if (i < r && j < r) {
+      const double gi = s_gf[i];
+#pragma unroll
+      for (int tt = 0; tt < DYN_MAX_TERMS; ++tt)
+        if (tt < nt) {
+          const DynTerm dt = dyn_term(kind, flags, N, r, tt);
+          if (dt.m_off >= 0) g[dt.m_off + i * r + j] += gi * s_val[tt * RM + j];
+        }
+    }
+  }
+  // d/db_t[j], d/dc_t[j] = (M_t^T g_f)_j trig_t'(arg_tj) {2 pi k, x_j}: thread = (t, j)
+  const int t = tid3 >> 4, j = tid3 & 15;
+  if (t < nt && j < r) {
+    const DynTerm d = dyn_term(kind, flags, N, r, t);
+    double u;
+    if (d.m_off >= 0) {
+      double mv[F6_RMAX], gv[F6_RMAX];
+#pragma unroll
+      for (int i = 0; i < F6_RMAX; ++i) { mv[i] = th[d.m_off + i * r + j]; gv[i] = s_gf[i]; }     // (rows >= r: finite times zero)
+      u = 0.0;
+#pragma unroll
+      for (int i = 0; i < F6_RMAX; ++i) u += mv[i] * gv[i];
+    } else {
+      u = s_gf[j];
+    }
+    const double ut = u * s_tp[t * RM + j];
+    g[d.b_off + j] += ut * (2.0 * M_PI * tk);
+    if (d.c_off >= 0) g[d.c_off + j] += ut * s_x[j];
+  }
+  __syncthreads();
+}
+
+// ROLE: the wave's role as a compile-time constant (0 matrix wave, 1 coefficient wave, 2 the other two): one program per role,
+// each holding only its own registers.  With the wave index as a run-time value the matrix wave's ~170 registers of state and
+// lane constants were live across the all-thread dynamics code of every wave and were moved out and back around it each step.
+template <int ROLE>
+__device__ __forceinline__ void f6_program(const BlockParams& b) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* sm = reinterpret_cast<double*>(smem_raw);
   const StepParams& p = b.sp;
   DevState* st = p.st;
   const int r = p.r, tid = threadIdx.x;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, lk = lane >> 4, lr = lane & 15;
+  constexpr int wv = ROLE;
+  const int lane = tid & 63, lk = lane >> 4, lr = lane & 15;
   const int r2 = r + (r & 1);
   const double dd = (double)p.d;
   // ---- LDS carve: psmf_blk_filter's (blk_filter_lds_bytes), so that assemble_K and the dynamics see the arrays they know ----
@@ -80,6 +215,11 @@ __global__ __launch_bounds__(WG) void psmf_blk_filter6(BlockParams b) {
   if (tid == 0) { *errflag = 0; *s_flag = 0; }
   if (tid < RM) { s_mub[tid] = 0.0; s_h[tid] = 0.0; s_w[tid] = 0.0; s_f[tid] = 1.0; s_munew[tid] = 0.0; s_gf[tid] = 0.0; }
   for (int idx = tid; idx < (RM / 2) * RS; idx += WG) sF[idx] = 0.0;        // wave 0 reads whole 16 x 16 tiles: zero outside r x r
+  for (int idx = tid; idx < DYN_MAX_TERMS * RM; idx += WG) { s_val[idx] = 0.0; s_tp[idx] = 0.0; }
+  if (th_lds && tid < 256 && p.n_theta + tid < BLK_TH_CAP) { s_theta[p.n_theta + tid] = 0.0; s_grad[p.n_theta + tid] = 0.0; }
+  // the 16-wide dynamics (f6_dyn_forward / f6_dyn_backward): trigonometric kinds with theta in LDS
+  const int nbar_fwd = f6_dyn_barriers(p);
+  const bool trig16 = th_lds && (p.dyn_kind == DYN_COS_PHASE || p.dyn_kind == DYN_SINUSOID || p.dyn_kind == DYN_FOURIER);
   if (tid < r) s_mu[tid] = st->mu[tid];
   // ---- wave 0: V, P, Q, G as 16 x 16 tiles (element (lk + 4 q, lr)); the lane predicates as multipliers ----
   double Vm[4] = {0.0, 0.0, 0.0, 0.0}, Pm[4] = {0.0, 0.0, 0.0, 0.0}, Qm[4] = {0.0, 0.0, 0.0, 0.0}, Gm[4] = {0.0, 0.0, 0.0, 0.0};
@@ -109,11 +249,12 @@ __global__ __launch_bounds__(WG) void psmf_blk_filter6(BlockParams b) {
   double rho = st->rho, lam = st->lam;
   bool bad = false;
   __syncthreads();
-  // A_0 = [I; 0], K A_0 = first r columns of K, G_0 = K[0:r, 0:r] (exact Gram of the stored C)
-  for (int idx = tid; idx < RB * r; idx += WG) {
-    const int m = idx / r, c = idx - m * r;
-    sA[m * RS + c] = (m == c) ? 1.0 : 0.0;
-    sKA[m * RS + c] = sK[m * RB + c];
+  // A_0 = [I; 0], K A_0 = first r columns of K, G_0 = K[0:r, 0:r] (exact Gram of the stored C); columns r .. RS - 1 zero (the
+  // row loops below run over F6_RMAX columns)
+  for (int idx = tid; idx < RB * RS; idx += WG) {
+    const int m = idx / RS, c = idx - m * RS;
+    sA[idx] = (m == c && c < r) ? 1.0 : 0.0;
+    sKA[idx] = c < r ? sK[m * RB + c] : 0.0;
   }
   if (wv == 0) {
 #pragma unroll
@@ -126,7 +267,10 @@ __global__ __launch_bounds__(WG) void psmf_blk_filter6(BlockParams b) {
   for (int jb = 0; jb < b.nb; ++jb) {
     const long long kstep = b.k0 + jb + 1;   // 1-based step index
     // ---- mu_bar = f(theta, mu, k), F = df/dx (psmf.py:104-115; psmf_dyn.hip) ----
-    dyn_forward<WG>(pd, (double)kstep, s_mu, s_mub, s_f, sF, RS, s_val, s_tp, sT, tid);     // ends with a barrier
+    // (waves 1-3; the matrix wave keeps its registers and only joins the barriers)
+    if (wv == 0) { for (int q = 0; q < nbar_fwd; ++q) __syncthreads(); }
+    else if (trig16) f6_dyn_forward(p, s_theta, (double)kstep, s_mu, s_mub, s_f, sF, RS, s_val, s_tp, sT, tid - 64);     // both end with a barrier
+    else dyn_forward<WG - 64>(pd, (double)kstep, s_mu, s_mub, s_f, sF, RS, s_val, s_tp, sT, tid - 64);
     BLK_T(0);
     // PSMFIter reads Q[k], R[k] of the step (psmf.py:115,123,141): scalar schedules (never with rPSMF's running Q, R)
     const double qs = p.q_sched ? p.q_sched[kstep - p.series_t0] : 1.0;
@@ -203,10 +347,12 @@ __global__ __launch_bounds__(WG) void psmf_blk_filter6(BlockParams b) {
       // ================= phase A, coefficient wave: lane = coefficient row =================
       const int m = lane;
       double pb = 0.0, pk = 0.0;
-      for (int c = 0; c < r; ++c) {
-        const double mu_c = s_mub[c];
-        pb = fma(sA[m * RS + c], mu_c, pb);
-        pk = fma(sKA[m * RS + c], mu_c, pk);
+      {
+        double av[F6_RMAX], kv[F6_RMAX], mv[F6_RMAX];
+#pragma unroll
+        for (int c = 0; c < F6_RMAX; ++c) { av[c] = sA[m * RS + c]; kv[c] = sKA[m * RS + c]; mv[c] = s_mub[c]; }   // (zero beyond r)
+#pragma unroll
+        for (int c = 0; c < F6_RMAX; ++c) { pb = fma(av[c], mv[c], pb); pk = fma(kv[c], mv[c], pk); }
       }
       const double am = (m == r + jb ? 1.0 : 0.0) - pb;
       const double kam = sK[m * RB + r + jb] - pk;
@@ -215,9 +361,12 @@ __global__ __launch_bounds__(WG) void psmf_blk_filter6(BlockParams b) {
       b.Bcoef[(size_t)jb * RB + m] = pb;
       // h = A^T Ka: column j = lr, the sixteen rows 16 lk .. 16 lk + 15 per lane, then across the four lane rows
       double ph = 0.0;
-      if (lr < r) {
-#pragma unroll 4
-        for (int mm = 0; mm < 16; ++mm) ph = fma(sA[(16 * lk + mm) * RS + lr], s_Ka[16 * lk + mm], ph);
+      {
+        double av[16], kv[16];
+#pragma unroll
+        for (int mm = 0; mm < 16; ++mm) { av[mm] = sA[(16 * lk + mm) * RS + lr]; kv[mm] = s_Ka[16 * lk + mm]; }   // (columns >= r: zero)
+#pragma unroll
+        for (int mm = 0; mm < 16; ++mm) ph = fma(av[mm], kv[mm], ph);
       }
       const double hj = xor32_sum_f64(xor16_sum_f64(ph));
       if (lane < 16) s_h[lane] = hj;
@@ -299,18 +448,21 @@ __global__ __launch_bounds__(WG) void psmf_blk_filter6(BlockParams b) {
       {
         const int m = lane;
         const double am = s_a[m] * invN, km = s_Ka[m] * invN;
-        for (int c = 0; c < r; ++c) {
-          const double wc = s_w[c];
-          sA[m * RS + c] = fma(am, wc, sA[m * RS + c]);
-          sKA[m * RS + c] = fma(km, wc, sKA[m * RS + c]);
-        }
+        double av[F6_RMAX], kv[F6_RMAX], wc[F6_RMAX];
+#pragma unroll
+        for (int c = 0; c < F6_RMAX; ++c) { av[c] = sA[m * RS + c]; kv[c] = sKA[m * RS + c]; wc[c] = s_w[c]; }     // (w is zero beyond r)
+#pragma unroll
+        for (int c = 0; c < F6_RMAX; ++c) { sA[m * RS + c] = fma(am, wc[c], av[c]); sKA[m * RS + c] = fma(km, wc[c], kv[c]); }
       }
       s_last = s; eta_last = eta; N_last = N; ee_last = ee;
       BLK_T(5);
       if (has_bw) __syncthreads();                       // (the barrier that ends dyn_backward on the other waves)
     } else {
       // ================= phase B, waves 1-3: gradsum += J_theta^T g_f =================
-      if (has_bw) dyn_backward<WG - 64>(pd, (double)kstep, s_mu, s_gf, s_val, s_tp, tid - 64);        // ends with a barrier
+      if (has_bw) {                                       // both end with a barrier
+        if (trig16) f6_dyn_backward(p, s_theta, s_grad, (double)kstep, s_mu, s_gf, s_val, s_tp, tid - 64);
+        else dyn_backward<WG - 64>(pd, (double)kstep, s_mu, s_gf, s_val, s_tp, tid - 64);
+      }
     }
     BLK_T(6);
     __syncthreads();           // the step's mu, A, K A are complete; every read of s_mu, s_w, s_h, s_a, s_Ka is done
@@ -321,7 +473,10 @@ __global__ __launch_bounds__(WG) void psmf_blk_filter6(BlockParams b) {
     }
     __syncthreads();
     // PSMFRecursive: optimiser step on theta every update_every observations (psmf.py:299-304)
-    if (p.recursive && p.n_theta > 0 && (kstep % p.update_every) == 0) dyn_adam_step<WG>(pd, kstep, tid);
+    if (p.recursive && p.n_theta > 0 && (kstep % p.update_every) == 0) {
+      if (wv == 0) __syncthreads();
+      else dyn_adam_step<WG - 64>(pd, kstep, tid - 64);        // ends with a barrier
+    }
     BLK_T(7);
   }
   BLK_TOUT();
@@ -353,6 +508,13 @@ __global__ __launch_bounds__(WG) void psmf_blk_filter6(BlockParams b) {
     if (*errflag && st->err == 0) st->err = (int)(b.k0 + 1);
     st->ns_valid = 0;          // nothing the two-inversion kernels carry from block to block describes this state
   }
+}
+
+__global__ __launch_bounds__(WG) void psmf_blk_filter6(BlockParams b) {
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (w == 0) f6_program<0>(b);
+  else if (w == 1) f6_program<1>(b);
+  else f6_program<2>(b);
 }
 
 }  // namespace psmf
