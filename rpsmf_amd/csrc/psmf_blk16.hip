@@ -41,6 +41,66 @@ __device__ __forceinline__ void f6_dyn_forward(const StepParams& p, const double
   const int t = tid >> 4, j = tid & 15;
   const bool act = t < nt && j < r;
   const DynTerm d = dyn_term(kind, flags, N, r, min(t, nt - 1));
+  const bool dense = dyn_dense(kind, flags);
+  if (dense && nt <= 4) {
+    // At most four terms: the (term, column) pairs fit ONE wave, which then needs no barrier between the trig values, the
+    // matrix-vector products and the sum over the terms (LDS operations of a wave complete in order; the terms of a row sit in the
+    // four 16-lane rows of the wave: two lane swaps).  The other two waves form F meanwhile.  Two barriers instead of three.
+    if (tid < 64) {
+      double a = 0.0;
+      if (act) {
+        const double c = d.c_off >= 0 ? th[d.c_off + j] : 1.0;
+        double sn, cs;
+        dyn_sincospi(2.0 * th[d.b_off + j] * tk + (c * s_x[j]) * 0.31830988618379067154, sn, cs);
+        s_val[t * RM + j] = d.is_cos ? cs : sn;
+        s_tp[t * RM + j] = d.is_cos ? -sn : cs;
+      }
+      asm volatile("" ::: "memory");
+      if (act) {
+        if (d.m_off >= 0) {
+          const double* row = th + d.m_off + j * r;
+          double mv[F6_RMAX], sv[F6_RMAX];
+#pragma unroll
+          for (int q = 0; q < F6_RMAX; ++q) { mv[q] = row[q]; sv[q] = s_val[t * RM + q]; }     // (columns >= r: finite times zero)
+#pragma unroll
+          for (int q = 0; q < F6_RMAX; ++q) a += mv[q] * sv[q];
+        } else {
+          a = s_val[t * RM + j];
+        }
+      }
+      const double mb = xor32_sum_f64(xor16_sum_f64(a));          // sum over the terms (lane rows)
+      if (tid < r) s_mub[tid] = mb;
+    }
+    __syncthreads();
+    if (tid >= 64) {          // F[i][j], thread = element: eight rows per pass.  Straight-line over four term slots -- a slot
+      // beyond nt points at the zero tail behind theta -- so that the twelve LDS operands of an element are all in flight before
+      // the first is used (with a uniform branch per term each waited for its own round trip: 2 350 of the step's 12 100 cycles).
+      int mo[4], co[4];
+      bool cg[4];
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        const DynTerm dt = dyn_term(kind, flags, N, r, tt);
+        mo[tt] = tt < nt ? dt.m_off : p.n_theta;       // (dense, trigonometric: every term has a matrix)
+        cg[tt] = tt >= nt || dt.c_off >= 0;
+        co[tt] = tt < nt ? (dt.c_off >= 0 ? dt.c_off : 0) : p.n_theta;
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int idx = (tid - 64) + 128 * k, i = idx >> 4;
+        if (i < r && j < r) {
+          double mv[4], tp[4], cj[4];
+#pragma unroll
+          for (int tt = 0; tt < 4; ++tt) { mv[tt] = th[mo[tt] + i * r + j]; tp[tt] = s_tp[tt * RM + j]; cj[tt] = th[co[tt] + j]; }
+          double a = 0.0;
+#pragma unroll
+          for (int tt = 0; tt < 4; ++tt) a += mv[tt] * (tp[tt] * (cg[tt] ? cj[tt] : 1.0));
+          sF[i * ldf + j] = a;
+        }
+      }
+    }
+    __syncthreads();
+    return;
+  }
   if (act) {
     const double c = d.c_off >= 0 ? th[d.c_off + j] : 1.0;
     double sn, cs;
@@ -49,7 +109,6 @@ __device__ __forceinline__ void f6_dyn_forward(const StepParams& p, const double
     s_tp[t * RM + j] = d.is_cos ? -sn : cs;
   }
   __syncthreads();
-  const bool dense = dyn_dense(kind, flags);
   if (!dense && kind != DYN_FOURIER) {      // one term, no matrix: mu_bar and the diagonal of F straight from the trig values
     if (tid < r) {
       s_mub[tid] = s_val[tid];
@@ -110,10 +169,12 @@ __device__ __forceinline__ void f6_dyn_forward(const StepParams& p, const double
   __syncthreads();
 }
 
-// barriers of dyn_forward / f6_dyn_forward for a wave that takes no part in it
-__device__ __forceinline__ int f6_dyn_barriers(const StepParams& p) {
+// barriers of dyn_forward (trig16 = false) / f6_dyn_forward for a wave that takes no part in it
+__device__ __forceinline__ int f6_dyn_barriers(const StepParams& p, const bool trig16) {
   if (p.dyn_kind == DYN_RANDOM_WALK || p.dyn_kind == DYN_SCALED_WALK) return 1;
-  return (!dyn_dense(p.dyn_kind, p.dyn_flags) && p.dyn_kind != DYN_FOURIER) ? 2 : 3;
+  const bool dense = dyn_dense(p.dyn_kind, p.dyn_flags);
+  if (trig16 && dense && dyn_n_terms(p.dyn_kind, p.dyn_terms) <= 4) return 2;
+  return (!dense && p.dyn_kind != DYN_FOURIER) ? 2 : 3;
 }
 
 // gradsum += J_theta^T g_f on NTH = 192 threads (tid3 = 0 .. 191); ends with a barrier
@@ -122,6 +183,23 @@ __device__ __forceinline__ void f6_dyn_backward(const StepParams& p, const doubl
   const int r = p.r, kind = p.dyn_kind, flags = p.dyn_flags, N = p.dyn_terms;
   const int nt = dyn_n_terms(kind, N);
   // d/dM_t[i][j] = g_f[i] trig_t(arg_tj): thread = element (i, j), every term
+  if (nt <= 4) {        // straight-line over four term slots (a slot beyond nt: the zero tail behind the gradient sums), loads first
+    int mo[4];
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) { const DynTerm dt = dyn_term(kind, flags, N, r, tt); mo[tt] = (tt < nt && dt.m_off >= 0) ? dt.m_off : p.n_theta; }
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int idx = tid3 + 192 * k, i = idx >> 4, j = idx & 15;
+      if (i < r && j < r) {
+        const double gi = s_gf[i];
+        double gv[4], sv[4];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) { gv[tt] = g[mo[tt] + i * r + j]; sv[tt] = s_val[tt * RM + j]; }
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) g[mo[tt] + i * r + j] = fma(gi, sv[tt], gv[tt]);
+      }
+    }
+  } else {
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int idx = tid3 + 192 * k, i = idx >> 4, j = idx & 15;
@@ -134,6 +212,7 @@ __device__ __forceinline__ void f6_dyn_backward(const StepParams& p, const doubl
           if (dt.m_off >= 0) g[dt.m_off + i * r + j] += gi * s_val[tt * RM + j];
         }
     }
+  }
   }
   // d/db_t[j], d/dc_t[j] = (M_t^T g_f)_j trig_t'(arg_tj) {2 pi k, x_j}: thread = (t, j)
   const int t = tid3 >> 4, j = tid3 & 15;
@@ -218,8 +297,8 @@ __device__ __forceinline__ void f6_program(const BlockParams& b) {
   for (int idx = tid; idx < DYN_MAX_TERMS * RM; idx += WG) { s_val[idx] = 0.0; s_tp[idx] = 0.0; }
   if (th_lds && tid < 256 && p.n_theta + tid < BLK_TH_CAP) { s_theta[p.n_theta + tid] = 0.0; s_grad[p.n_theta + tid] = 0.0; }
   // the 16-wide dynamics (f6_dyn_forward / f6_dyn_backward): trigonometric kinds with theta in LDS
-  const int nbar_fwd = f6_dyn_barriers(p);
   const bool trig16 = th_lds && (p.dyn_kind == DYN_COS_PHASE || p.dyn_kind == DYN_SINUSOID || p.dyn_kind == DYN_FOURIER);
+  const int nbar_fwd = f6_dyn_barriers(p, trig16);
   if (tid < r) s_mu[tid] = st->mu[tid];
   // ---- wave 0: V, P, Q, G as 16 x 16 tiles (element (lk + 4 q, lr)); the lane predicates as multipliers ----
   double Vm[4] = {0.0, 0.0, 0.0, 0.0}, Pm[4] = {0.0, 0.0, 0.0, 0.0}, Qm[4] = {0.0, 0.0, 0.0, 0.0}, Gm[4] = {0.0, 0.0, 0.0, 0.0};

@@ -14,8 +14,8 @@
 //   * lane predicates as NUMBERS in VGPRs (0.0 / 1.0 multipliers, computed once): a select of a double is two v_cndmask
 //     plus, here, the reload of its lane mask from a spilled SGPR pair (two v_readlane) -- the kernel had 1 200 of those;
 //     a multiply-add is one instruction.  wave_sweep16m: 45 instructions per 2 x 2 pivot round instead of ~110.
-//   * MFMAs in VGPR form (amdgpu_waves_per_eu(2): with 512 registers per wave on offer the compiler puts the accumulators in
-//     AGPRs -- 16 copies and a 16-cycle stall per pivot round).
+//   * MFMAs in VGPR form (the build flag -amdgpu-mfma-vgpr-form: with 512 registers per wave on offer the compiler otherwise puts
+//     the accumulators in AGPRs -- 16 copies and a 16-cycle stall per pivot round).
 //   * C, the scalars, W and P + Q are double-buffered by column parity: what a column's tail writes is the NEXT column's
 //     slot, so the only barriers are "residual / w / s ready" and "end of column".
 //   * the sweep of M_t runs on the matrix AUGMENTED with kappa b = kappa C^T e (row / column r2 of the 16 x 16 tile, which the
@@ -396,8 +396,6 @@ __device__ __forceinline__ void impute3_wave(const ImputeParams& p) {
   IMP_TOUT();
 }
 
-// amdgpu_waves_per_eu(2): at most 256 registers per wave, which is what makes the compiler select the MFMAs with VGPR
-// accumulators (see the header)
 template <int NG>
 __global__ __launch_bounds__(WG) void psmf_impute_kernel3(ImputeParams p) {
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

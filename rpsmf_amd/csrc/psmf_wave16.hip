@@ -5,9 +5,9 @@
 // one instruction per 4-8 cycles whatever the instruction is -- a float64 VALU operation ~8, a 32-bit one ~4, a 16x16x4 float64
 // MFMA ~76 including the wait for its result -- so these routines are written for INSTRUCTION COUNT: lane predicates are kept as
 // 0.0 / 1.0 multipliers in VGPRs (a select of a double is two v_cndmask plus, in a kernel that has run out of SGPRs, the reload
-// of its lane mask from a spilled SGPR pair: two v_readlane), and the kernels that use them ask for at most 256 registers per
-// wave (amdgpu_waves_per_eu(2)) so that the compiler selects the MFMAs with VGPR accumulators (with 512 on offer it puts them in
-// AGPRs: 16 copies and a 16-cycle stall per pivot round).
+// of its lane mask from a spilled SGPR pair: two v_readlane), and the library is built with -mllvm -amdgpu-mfma-vgpr-form
+// (rpsmf_amd/build.py) so that the 256-thread kernels get their MFMAs with VGPR accumulators (left to itself the compiler, with 512
+// registers per wave on offer, puts them in AGPRs: 16 copies and a 16-cycle stall per pivot round).
 #pragma once
 #include "psmf_blk3.hip"      // readlane_f64, DPP sums, f64x4
 
