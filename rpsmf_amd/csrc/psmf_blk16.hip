@@ -14,8 +14,8 @@
 //      wave 1 (coefficient wave, lane = coefficient row): b = A mu_bar, Ka, a, h = A^T Ka, e'e; then, when wave 0 has
 //        published w and N (LDS flag), the likelihood gradient g_f                                                 | barrier
 //   B  wave 0: kappa G - (-Pbar^-1), augmented with kappa h in row / column r2 -> second sweep: P+ AND kappa P+ h (= mu - mu_bar)
-//        AND 1 - kappa^2 h'P+h in one go; omega, phi; V, P, G, Q updates in registers; rank-1 updates of A and K A
-//      waves 1-3: gradsum += J_theta^T g_f (dyn_backward on 192 threads)                                            | barrier
+//        AND 1 - kappa^2 h'P+h in one go; omega, phi; V, P, G, Q updates in registers
+//      wave 1: rank-1 updates of A and K A;  waves 1-3: gradsum += J_theta^T g_f (dyn_backward on 192 threads)      | barrier
 //   mu, in-loop Adam (all waves)
 // Same recursion and float64 arithmetic as psmf_blk_filter (summation orders differ).  r <= 14: the augmented column needs
 // r2 < 16.  PSMF_FILTER6=0 sends these ranks back to psmf_blk_filter.
@@ -43,36 +43,18 @@ __device__ __forceinline__ void f6_dyn_forward(const StepParams& p, const double
   const DynTerm d = dyn_term(kind, flags, N, r, min(t, nt - 1));
   const bool dense = dyn_dense(kind, flags);
   if (dense && nt <= 4) {
-    // At most four terms: the (term, column) pairs fit ONE wave, which then needs no barrier between the trig values, the
-    // matrix-vector products and the sum over the terms (LDS operations of a wave complete in order; the terms of a row sit in the
-    // four 16-lane rows of the wave: two lane swaps).  The other two waves form F meanwhile.  Two barriers instead of three.
-    if (tid < 64) {
-      double a = 0.0;
-      if (act) {
-        const double c = d.c_off >= 0 ? th[d.c_off + j] : 1.0;
-        double sn, cs;
-        dyn_sincospi(2.0 * th[d.b_off + j] * tk + (c * s_x[j]) * 0.31830988618379067154, sn, cs);
-        s_val[t * RM + j] = d.is_cos ? cs : sn;
-        s_tp[t * RM + j] = d.is_cos ? -sn : cs;
-      }
-      asm volatile("" ::: "memory");
-      if (act) {
-        if (d.m_off >= 0) {
-          const double* row = th + d.m_off + j * r;
-          double mv[F6_RMAX], sv[F6_RMAX];
-#pragma unroll
-          for (int q = 0; q < F6_RMAX; ++q) { mv[q] = row[q]; sv[q] = s_val[t * RM + q]; }     // (columns >= r: finite times zero)
-#pragma unroll
-          for (int q = 0; q < F6_RMAX; ++q) a += mv[q] * sv[q];
-        } else {
-          a = s_val[t * RM + j];
-        }
-      }
-      const double mb = xor32_sum_f64(xor16_sum_f64(a));          // sum over the terms (lane rows)
-      if (tid < r) s_mub[tid] = mb;
+    // At most four terms: the (term, column) pairs fit ONE wave -- the trig values, then (behind the one barrier F needs anyway)
+    // the matrix-vector products and the sum over the terms without another (the terms of a row sit in the four 16-lane rows of
+    // the wave: two lane swaps).  Two barriers instead of three.
+    if (tid < 64 && act) {
+      const double c = d.c_off >= 0 ? th[d.c_off + j] : 1.0;
+      double sn, cs;
+      dyn_sincospi(2.0 * th[d.b_off + j] * tk + (c * s_x[j]) * 0.31830988618379067154, sn, cs);
+      s_val[t * RM + j] = d.is_cos ? cs : sn;
+      s_tp[t * RM + j] = d.is_cos ? -sn : cs;
     }
     __syncthreads();
-    if (tid >= 64) {          // F[i][j], thread = element: eight rows per pass.  Straight-line over four term slots -- a slot
+    {                         // F[i][j], thread = element, twelve rows per pass.  Straight-line over four term slots -- a slot
       // beyond nt points at the zero tail behind theta -- so that the twelve LDS operands of an element are all in flight before
       // the first is used (with a uniform branch per term each waited for its own round trip: 2 350 of the step's 12 100 cycles).
       int mo[4], co[4];
@@ -86,7 +68,7 @@ __device__ __forceinline__ void f6_dyn_forward(const StepParams& p, const double
       }
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
-        const int idx = (tid - 64) + 128 * k, i = idx >> 4;
+        const int idx = tid + 192 * k, i = idx >> 4;
         if (i < r && j < r) {
           double mv[4], tp[4], cj[4];
 #pragma unroll
@@ -97,6 +79,23 @@ __device__ __forceinline__ void f6_dyn_forward(const StepParams& p, const double
           sF[i * ldf + j] = a;
         }
       }
+    }
+    if (tid < 64) {           // mu_bar: the terms' matrix-vector products (lane = (term, row)), then the sum over the lane rows
+      double a = 0.0;
+      if (act) {
+        if (d.m_off >= 0) {
+          const double* row = th + d.m_off + j * r;
+          double mv[F6_RMAX], sv[F6_RMAX];
+#pragma unroll
+          for (int q = 0; q < F6_RMAX; ++q) { mv[q] = row[q]; sv[q] = s_val[t * RM + q]; }     // (columns >= r: finite times zero)
+#pragma unroll
+          for (int q = 0; q < F6_RMAX; ++q) a += mv[q] * sv[q];
+        } else {
+          a = s_val[t * RM + j];
+        }
+      }
+      const double mb = xor32_sum_f64(xor16_sum_f64(a));
+      if (tid < r) s_mub[tid] = mb;
     }
     __syncthreads();
     return;
@@ -214,8 +213,9 @@ __device__ __forceinline__ void f6_dyn_backward(const StepParams& p, const doubl
     }
   }
   }
-  // d/db_t[j], d/dc_t[j] = (M_t^T g_f)_j trig_t'(arg_tj) {2 pi k, x_j}: thread = (t, j)
-  const int t = tid3 >> 4, j = tid3 & 15;
+  // d/db_t[j], d/dc_t[j] = (M_t^T g_f)_j trig_t'(arg_tj) {2 pi k, x_j}: thread = (t, j), starting on the SECOND of the three waves
+  // (the first one has the rank-1 updates of the coefficient matrices in this phase)
+  const int t = ((tid3 + 128) % 192) >> 4, j = tid3 & 15;
   if (t < nt && j < r) {
     const DynTerm d = dyn_term(kind, flags, N, r, t);
     double u;
@@ -523,20 +523,21 @@ __device__ __forceinline__ void f6_program(const BlockParams& b) {
         Gm[q] += finq[q] * (fma(hrow[q], wj, wrow[q] * (hcol * invN)) + ew * (wrow[q] * wj));
         Qm[q] *= qscale;
       }
-      // rank-1 updates of the coefficient matrices, lane = row
-      {
+      s_last = s; eta_last = eta; N_last = N; ee_last = ee;
+      BLK_T(5);
+      if (has_bw) __syncthreads();                       // (the barrier that ends dyn_backward on the other waves)
+    } else {
+      // ================= phase B, wave 1: rank-1 updates of the coefficient matrices (lane = row) =================
+      if (wv == 1) {
         const int m = lane;
-        const double am = s_a[m] * invN, km = s_Ka[m] * invN;
+        const double iN = s_sc[3];
+        const double am = s_a[m] * iN, km = s_Ka[m] * iN;
         double av[F6_RMAX], kv[F6_RMAX], wc[F6_RMAX];
 #pragma unroll
         for (int c = 0; c < F6_RMAX; ++c) { av[c] = sA[m * RS + c]; kv[c] = sKA[m * RS + c]; wc[c] = s_w[c]; }     // (w is zero beyond r)
 #pragma unroll
         for (int c = 0; c < F6_RMAX; ++c) { sA[m * RS + c] = fma(am, wc[c], av[c]); sKA[m * RS + c] = fma(km, wc[c], kv[c]); }
       }
-      s_last = s; eta_last = eta; N_last = N; ee_last = ee;
-      BLK_T(5);
-      if (has_bw) __syncthreads();                       // (the barrier that ends dyn_backward on the other waves)
-    } else {
       // ================= phase B, waves 1-3: gradsum += J_theta^T g_f =================
       if (has_bw) {                                       // both end with a barrier
         if (trig16) f6_dyn_backward(p, s_theta, s_grad, (double)kstep, s_mu, s_gf, s_val, s_tp, tid - 64);
