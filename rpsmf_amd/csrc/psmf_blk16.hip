@@ -8,13 +8,14 @@
 // (tools/blkgen_prof.hip).  Here the r x r state lives in ONE wave's registers as 16 x 16 tiles in the MFMA output layout and
 // the stages that do not depend on each other run side by side on different waves:
 //   dynamics forward (all waves, psmf_dyn.hip)                                                               | barriers inside
-//   A  wave 0 (matrix wave): w = V mu_bar, s, Pbar = F P F^T + Q (eight float64 MFMAs, operands straight from the
-//        registers: P and V are symmetric, so a tile in the output layout IS the A operand of its k-blocks), <G, Pbar>,
-//        eta, N, kappa -- published -- and the first sweep, -Pbar^-1 (wave_sweep16m: no LDS, no barrier)
-//      wave 1 (coefficient wave, lane = coefficient row): b = A mu_bar, Ka, a, h = A^T Ka, e'e; then, when wave 0 has
-//        published w and N (LDS flag), the likelihood gradient g_f                                                 | barrier
+//   A  wave 0 (matrix wave): Pbar = F P F^T + Q (eight float64 MFMAs, operands straight from the registers: P is symmetric,
+//        so a tile in the output layout IS the A operand of its k-blocks), <G, Pbar>, eta -- published -- and the first
+//        sweep, -Pbar^-1 (wave_sweep16m: no LDS, no barrier)
+//      wave 2 (V wave): w = V mu_bar, s; with wave 0's eta: N, kappa -- published
+//      wave 1 (coefficient wave, lane = coefficient row): b = A mu_bar, Ka, a, h = A^T Ka, e'e; then, when w and N are
+//        there (LDS flags), the likelihood gradient g_f                                                            | barrier
 //   B  wave 0: kappa G - (-Pbar^-1), augmented with kappa h in row / column r2 -> second sweep: P+ AND kappa P+ h (= mu - mu_bar)
-//        AND 1 - kappa^2 h'P+h in one go; omega, phi; V, P, G, Q updates in registers
+//        AND 1 - kappa^2 h'P+h in one go; omega, phi; P, G, Q updates in registers;  wave 2: V
 //      wave 1: rank-1 updates of A and K A;  waves 1-3: gradsum += J_theta^T g_f (dyn_backward on 192 threads)      | barrier
 //   mu, in-loop Adam (all waves)
 // Same recursion and float64 arithmetic as psmf_blk_filter (summation orders differ).  r <= 14: the augmented column needs
@@ -236,7 +237,7 @@ __device__ __forceinline__ void f6_dyn_backward(const StepParams& p, const doubl
   __syncthreads();
 }
 
-// ROLE: the wave's role as a compile-time constant (0 matrix wave, 1 coefficient wave, 2 the other two): one program per role,
+// ROLE: the wave's role as a compile-time constant (0 matrix wave, 1 coefficient wave, 2 V wave, 3 the fourth): one program per role,
 // each holding only its own registers.  With the wave index as a run-time value the matrix wave's ~170 registers of state and
 // lane constants were live across the all-thread dynamics code of every wave and were moved out and back around it each step.
 template <int ROLE>
@@ -263,8 +264,9 @@ __device__ __forceinline__ void f6_program(const BlockParams& b) {
   double* s_mu = s_munew + RM;
   double* s_a = s_mu + RM;            // RB
   double* s_Ka = s_a + RB;            // RB
-  double* s_sc = s_Ka + RB;           // (8 RB:) 0 s, 1 eta, 2 N, 3 1 / N, 4 kappa, 5 lambda of the step, 6 e'e
-  int* s_flag = reinterpret_cast<int*>(s_sc + 16);     // number of steps whose s_w / s_sc[0..5] wave 0 has published
+  double* s_sc = s_Ka + RB;           // (8 RB:) 0 s, 1 eta, 2 N, 3 1 / N, 4 kappa, 5 lambda of the step, 6 e'e, 7 rho of the step
+  int* s_flag = reinterpret_cast<int*>(s_sc + 16);     // number of steps whose w, s, N, 1 / N, kappa wave 2 has published
+  int* s_flagA = s_flag + 1;                           // ... whose eta, lambda, rho wave 0 has published
   double* rowbuf = s_sc + 8 * RB;     // 4 * RM (unused here)
   double* s4 = rowbuf + 4 * RM;       // 4 (+ errflag)
   int* errflag = reinterpret_cast<int*>(s4 + 4);
@@ -291,7 +293,7 @@ __device__ __forceinline__ void f6_program(const BlockParams& b) {
   } else {
     assemble_K<WG>(b, sK, sA, sKA, r, tid);
   }
-  if (tid == 0) { *errflag = 0; *s_flag = 0; }
+  if (tid == 0) { *errflag = 0; *s_flag = 0; *s_flagA = 0; }
   if (tid < RM) { s_mub[tid] = 0.0; s_h[tid] = 0.0; s_w[tid] = 0.0; s_f[tid] = 1.0; s_munew[tid] = 0.0; s_gf[tid] = 0.0; }
   for (int idx = tid; idx < (RM / 2) * RS; idx += WG) sF[idx] = 0.0;        // wave 0 reads whole 16 x 16 tiles: zero outside r x r
   for (int idx = tid; idx < DYN_MAX_TERMS * RM; idx += WG) { s_val[idx] = 0.0; s_tp[idx] = 0.0; }
@@ -300,7 +302,7 @@ __device__ __forceinline__ void f6_program(const BlockParams& b) {
   const bool trig16 = th_lds && (p.dyn_kind == DYN_COS_PHASE || p.dyn_kind == DYN_SINUSOID || p.dyn_kind == DYN_FOURIER);
   const int nbar_fwd = f6_dyn_barriers(p, trig16);
   if (tid < r) s_mu[tid] = st->mu[tid];
-  // ---- wave 0: V, P, Q, G as 16 x 16 tiles (element (lk + 4 q, lr)); the lane predicates as multipliers ----
+  // ---- wave 0: P, Q, G, wave 2: V as 16 x 16 tiles (element (lk + 4 q, lr)); the lane predicates as multipliers ----
   double Vm[4] = {0.0, 0.0, 0.0, 0.0}, Pm[4] = {0.0, 0.0, 0.0, 0.0}, Qm[4] = {0.0, 0.0, 0.0, 0.0}, Gm[4] = {0.0, 0.0, 0.0, 0.0};
   double finq[4], fpad[4], faugc[4], faugr[4], fxr[4];
   int trx[4];
@@ -316,10 +318,13 @@ __device__ __forceinline__ void f6_program(const BlockParams& b) {
     trx[q] = (lr >> 2) * 64 + (lr & 3) * 16 + i;      // the transposed element in a tile image
     if (wv == 0) {
       const int idx = in ? i * r + lr : 0;
-      const double lv = st->V[idx], lq = st->Q[idx], lp = st->P[idx];
-      Vm[q] = in ? lv : 0.0;
+      const double lq = st->Q[idx], lp = st->P[idx];
       Qm[q] = in ? lq : 0.0;
       Pm[q] = in ? lp : 0.0;
+    }
+    if (wv == 2) {
+      const double lv = st->V[in ? i * r + lr : 0];
+      Vm[q] = in ? lv : 0.0;
     }
   }
   const int rq_c = r2 >> 2, ln_c = ((r2 & 3) << 4) | r2;       // where element (r2, r2) sits
@@ -359,17 +364,7 @@ __device__ __forceinline__ void f6_program(const BlockParams& b) {
     if (wv == 0) {
       // ================= phase A, matrix wave =================
 #pragma unroll
-      for (int q = 0; q < 4; ++q) mb[q] = s_mub[lk + 4 * q];         // mu_bar of this lane's rows = the B operand of V mu_bar
-      {
-        f64x4 a0 = {0.0, 0.0, 0.0, 0.0}, a1 = {0.0, 0.0, 0.0, 0.0};
-        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vm[0], mb[0], a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vm[1], mb[1], a1, 0, 0, 0);
-        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vm[2], mb[2], a0, 0, 0, 0);
-        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vm[3], mb[3], a1, 0, 0, 0);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) wrow[q] = a0[q] + a1[q];          // w_i = (V mu_bar)_i, i = lk + 4 q, in every column
-      }
-      s = xor32_sum_f64(xor16_sum_f64(fma(mb[0], wrow[0], mb[1] * wrow[1]) + fma(mb[2], wrow[2], mb[3] * wrow[3])));
+      for (int q = 0; q < 4; ++q) mb[q] = s_mub[lk + 4 * q];         // mu_bar of this lane's rows (for mu = mu_bar + kappa P+ h)
       if (p.pbar_predict) {
         if (dense) {
           // Pbar = F P F^T + Q: T = P F^T, then F T
@@ -404,24 +399,43 @@ __device__ __forceinline__ void f6_program(const BlockParams& b) {
         const double tr = fma(Gm[0], Pb[0], Gm[1] * Pb[1]) + fma(Gm[2], Pb[2], Gm[3] * Pb[3]);
         eta += wave_sum_f64_dpp(tr) / dd;
       }
-      N = s + eta;
-      invN = fast_rcp(N);
-      kappa = fast_rcp(rho + s);
-      if (lr == 0) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) s_w[lk + 4 * q] = wrow[q];
-      }
-      if (lane == 0) { s_sc[0] = s; s_sc[1] = eta; s_sc[2] = N; s_sc[3] = invN; s_sc[4] = kappa; s_sc[5] = lam; }
+      if (lane == 0) { s_sc[1] = eta; s_sc[5] = lam; s_sc[7] = rho; }
       // (LDS operations of one wave complete in program order: the flag needs no release fence -- which would also wait for
       //  this wave's outstanding global stores)
       asm volatile("" ::: "memory");
-      if (lane == 0) __hip_atomic_store(s_flag, jb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (lane == 0) __hip_atomic_store(s_flagA, jb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       BLK_T(1);
       if (p.coef_update) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) A[q] = Pb[q] + fpad[q];
         wave_sweep16m(A, r2, swk, bad);                 // -Pbar^-1
       }
+    } else if (wv == 2) {
+      // ================= phase A, V wave: w = V mu_bar, s; N, kappa when wave 0's eta is there =================
+#pragma unroll
+      for (int q = 0; q < 4; ++q) mb[q] = s_mub[lk + 4 * q];         // mu_bar of this lane's rows = the B operand of V mu_bar
+      {
+        f64x4 a0 = {0.0, 0.0, 0.0, 0.0}, a1 = {0.0, 0.0, 0.0, 0.0};
+        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vm[0], mb[0], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vm[1], mb[1], a1, 0, 0, 0);
+        a0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vm[2], mb[2], a0, 0, 0, 0);
+        a1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Vm[3], mb[3], a1, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) wrow[q] = a0[q] + a1[q];          // w_i = (V mu_bar)_i, i = lk + 4 q, in every column
+      }
+      s = xor32_sum_f64(xor16_sum_f64(fma(mb[0], wrow[0], mb[1] * wrow[1]) + fma(mb[2], wrow[2], mb[3] * wrow[3])));
+      if (lr == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s_w[lk + 4 * q] = wrow[q];
+      }
+      while (__hip_atomic_load(s_flagA, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < jb + 1) __builtin_amdgcn_s_sleep(1);
+      asm volatile("" ::: "memory");
+      N = s + s_sc[1];
+      invN = fast_rcp(N);
+      kappa = fast_rcp(s_sc[7] + s);
+      if (lane == 0) { s_sc[0] = s; s_sc[2] = N; s_sc[3] = invN; s_sc[4] = kappa; }
+      asm volatile("" ::: "memory");
+      if (lane == 0) __hip_atomic_store(s_flag, jb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     } else if (wv == 1) {
       // ================= phase A, coefficient wave: lane = coefficient row =================
       const int m = lane;
@@ -474,9 +488,10 @@ __device__ __forceinline__ void f6_program(const BlockParams& b) {
     if (wv == 0) {
       // ================= phase B, matrix wave =================
       const double ee = s_sc[6];
+      s = s_sc[0]; N = s_sc[2]; invN = s_sc[3]; kappa = s_sc[4];
       double hrow[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) hrow[q] = s_h[lk + 4 * q];
+      for (int q = 0; q < 4; ++q) { hrow[q] = s_h[lk + 4 * q]; wrow[q] = s_w[lk + 4 * q]; }
       const double hcol = s_h[lr], wcol = s_w[lr];
       double Pp[4], quad = kappa * ee;
       if (p.coef_update) {
@@ -503,22 +518,20 @@ __device__ __forceinline__ void f6_program(const BlockParams& b) {
           for (int q = 0; q < 4; ++q) s_munew[lk + 4 * q] = mb[q];
         }
       }
-      double vscale = 1.0, pscale = 1.0, qscale = 1.0;
+      double pscale = 1.0, qscale = 1.0;
       phi = 1.0; omega = 1.0;
       if (p.robust) {
         const double ild = fast_rcp(lam + dd);
         phi = (lam + ee * invN) * ild;
         omega = (lam + quad) * ild;
-        vscale = p.alpha * phi;
         if (p.coef_update) { pscale = p.beta * omega; qscale = omega; }
         rho *= omega;
         if (!p.fixed_lambda) lam += dd;
       }
-      // V, P, G, Q of the step (psmf.py:150-170; G: the tracked Gram of C)
+      // P, G, Q of the step (psmf.py:150-170; G: the tracked Gram of C)
       const double wj = wcol * invN, ew = ee * invN;
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        Vm[q] = vscale * fma(-(wrow[q] * wcol), invN, Vm[q]);       // (w_i w_j first: bitwise symmetric)
         Pm[q] = pscale * Pp[q];
         Gm[q] += finq[q] * (fma(hrow[q], wj, wrow[q] * (hcol * invN)) + ew * (wrow[q] * wj));
         Qm[q] *= qscale;
@@ -527,6 +540,14 @@ __device__ __forceinline__ void f6_program(const BlockParams& b) {
       BLK_T(5);
       if (has_bw) __syncthreads();                       // (the barrier that ends dyn_backward on the other waves)
     } else {
+      // ================= phase B, wave 2: V of the step (psmf.py:166-170, rpsmf.py: phi) =================
+      if (wv == 2) {
+        double vscale = 1.0;
+        if (p.robust) { const double lm = s_sc[5]; vscale = p.alpha * ((lm + s_sc[6] * invN) * fast_rcp(lm + dd)); }
+        const double wcol = s_w[lr];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Vm[q] = vscale * fma(-(wrow[q] * wcol), invN, Vm[q]);       // (w_i w_j first: bitwise symmetric)
+      }
       // ================= phase B, wave 1: rank-1 updates of the coefficient matrices (lane = row) =================
       if (wv == 1) {
         const int m = lane;
@@ -571,13 +592,19 @@ __device__ __forceinline__ void f6_program(const BlockParams& b) {
       const int i = lk + 4 * q;
       if (i < r && lr < r) {
         const int idx = i * r + lr;
-        st->V[idx] = Vm[q];
         st->P[idx] = Pm[q];
         st->Q[idx] = Qm[q];
         st->G[idx] = Gm[q];
       }
     }
     if (bad) *errflag = 1;
+  }
+  if (wv == 2) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = lk + 4 * q;
+      if (i < r && lr < r) st->V[i * r + lr] = Vm[q];
+    }
   }
   if (tid < r) st->mu[tid] = s_mu[tid];
   __syncthreads();
@@ -594,7 +621,8 @@ __global__ __launch_bounds__(WG) void psmf_blk_filter6(BlockParams b) {
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (w == 0) f6_program<0>(b);
   else if (w == 1) f6_program<1>(b);
-  else f6_program<2>(b);
+  else if (w == 2) f6_program<2>(b);
+  else f6_program<3>(b);
 }
 
 }  // namespace psmf
