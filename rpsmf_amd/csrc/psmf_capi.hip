@@ -302,7 +302,13 @@ bool blk_dual_ok(const psmf_filter* h) {
 
 // filter4 (psmf_blk4.hip): the role-specialised kernel for diagonal-Jacobian dynamics -- cos-phase, unscaled sinusoid, and the
 // random walk when R_k / Q_k schedules keep it off filter3 -- full filter, Q = q I, r <= 32; the recursive classes included
+// filter6 (psmf_blk16.hip): the general block filter for r <= 14, role-specialised -- whatever filter3s / filter5 do not take,
+// INCLUDING what filter4s would (measured at r = 10, d = 2e4: cos-phase full filter 117 k timesteps/s on filter4s, 316 k on
+// filter6; its recursive form 196 k against 214 k)
+bool blk_small_ok(const psmf_filter* h) { return h->sw.filter6 && h->cfg.r <= psmf::F6_RMAX; }
+
 bool blk_seq_ok(const psmf_filter* h) {
+  if (blk_small_ok(h)) return false;
   const int kd = h->cfg.dyn_kind;
   const bool diag_dyn = kd == PSMF_DYN_RANDOM_WALK || kd == PSMF_DYN_COS_PHASE || (kd == PSMF_DYN_SINUSOID && !(h->cfg.dyn_flags & 1));
   return h->sw.filter4 && h->sw.filter3 && h->sw.block_dual && h->q_iso && h->cfg.coef_update && h->cfg.pbar_predict && h->cfg.eta_full && diag_dyn &&
@@ -316,9 +322,6 @@ bool blk_simpl_ok(const psmf_filter* h) {
   return h->sw.filter4 && h->sw.filter3 && !h->cfg.coef_update && !h->cfg.eta_full && !h->cfg.pbar_predict && diag_dyn && h->cfg.r <= 32 &&
          !h->sp.q_sched;
 }
-
-// filter6 (psmf_blk16.hip): the general block filter for r <= 14, role-specialised (whatever the kernels above do not take)
-bool blk_small_ok(const psmf_filter* h) { return h->sw.filter6 && h->cfg.r <= psmf::F6_RMAX; }
 
 void launch_blk_filter(psmf_filter* h, const psmf::BlockParams& b, hipStream_t stream = nullptr) {
   if (!stream) stream = h->stream;

@@ -15,6 +15,8 @@ cases = [
     ("cos-phase simplified r=20 (ExperimentSynthetic)", dict(r=20, dyn_kind=_capi.DYN_COS_PHASE, coef_update=False, eta_full=False, pbar_predict=False)),
     ("Fourier N=2 r=10 (ExperimentBeijing)", dict(r=10, dyn_kind=_capi.DYN_FOURIER, dyn_terms=2)),
     ("recursive cos-phase r=20 (in-loop Adam)", dict(r=20, dyn_kind=_capi.DYN_COS_PHASE, recursive=True)),
+    ("cos-phase r=10 full filter", dict(r=10, dyn_kind=_capi.DYN_COS_PHASE)),
+    ("recursive cos-phase r=10", dict(r=10, dyn_kind=_capi.DYN_COS_PHASE, recursive=True)),
     ("Fourier N=1 r=14", dict(r=14, dyn_kind=_capi.DYN_FOURIER, dyn_terms=1)),
     ("Fourier N=2 r=10, rPSMF", dict(r=10, dyn_kind=_capi.DYN_FOURIER, dyn_terms=2, robust=True)),
     ("scaled walk r=10", dict(r=10, dyn_kind=_capi.DYN_SCALED_WALK)),
