@@ -170,21 +170,25 @@ DYN_CASES = [
     ("cos-phase full", dict(), "psmf_blk_filter4", 20, 88, 1e-6),
     ("cos-phase simplified", dict(coef_update=False, eta_full=False, pbar_predict=False), "psmf_blk_filter5", 20, 176, 1e-9),
     ("cos-phase simplified r=32", dict(coef_update=False, eta_full=False, pbar_predict=False), "psmf_blk_filter5", 32, 128, 1e-9),
+    # the small-rank general kernel: a dense Jacobian (FourierBasis, N = 1: 2 r^2 + 4 r parameters) and the full cos-phase filter
+    ("FourierBasis r=10", dict(dyn_kind="fourier", dyn_terms=1), "psmf_blk_filter6", 10, 144, 1e-8),
+    ("cos-phase full r=9", dict(), "psmf_blk_filter6", 9, 96, 1e-6),
 ]
 
 
 @pytest.mark.parametrize("robust", [False, True], ids=["PSMF", "rPSMF"])
 @pytest.mark.parametrize("name,extra,kernel,r,T,tol", DYN_CASES, ids=[c[0] for c in DYN_CASES])
 def test_shards_of_the_diagonal_dynamics_kernels_equal_unsharded(name, extra, kernel, r, T, tol, robust):
-    """psmf_blk_filter4 / psmf_blk_filter5 under a host communicator: the cross-Gram K of every block is summed over the
+    """psmf_blk_filter4 / psmf_blk_filter5 / psmf_blk_filter6 under a host communicator: the cross-Gram K of every block is summed over the
     shards, theta and the gradient sum are replicated (bit-identical), the gathered C and y_hat equal the unsharded run."""
     c = _capi()
     d = 3001
-    extra = dict(extra, dyn_kind=c.DYN_COS_PHASE)
+    kind = c.DYN_FOURIER if extra.get("dyn_kind") == "fourier" else c.DYN_COS_PHASE
+    extra = dict(extra, dyn_kind=kind)
     Y = O.synthetic_series(d, r, T, 77 + r, noise="t" if robust else "normal", dtype=np.float64)
     rng = np.random.default_rng(5 + r)
     C0 = 0.1 * rng.standard_normal((d, r))
-    theta = 0.05 + 0.1 * rng.random(r)
+    theta = 0.05 + 0.1 * rng.random(c.dyn_n_theta(kind, r, 0, extra.get("dyn_terms", 0)))
     st0 = (0.1 * np.eye(r), np.eye(r), 0.1 * np.eye(r), np.zeros(r))
     kw = dict(engine="block", storage="f64", robust=robust, extra=extra, theta=theta, want_kernel=kernel)
     ref_s, ref_y, _ = _run(c, 0, d, r, Y, C0, st0, T, **kw)
