@@ -249,6 +249,44 @@ def run_synthetic_simplified(_capi, d=10_000, r=20, T=5_000, robust=False, passe
             "value": T / dt, "unit": "timesteps/s", "us_per_timestep": 1e6 * dt / T, "kernel": geo["filter_kernel"], "parity_vs_cpu_oracle": par}
 
 
+def run_fourier_config(_capi, d=10_000, r=10, T=5_000, N=2, passes=3):
+    """ExperimentBeijing's dynamics family (beijing_psmf.py:97-140: full PSMF filter, f = FourierBasis, r = 10) at config B's d and
+    T: throughput of the small-rank block filter (psmf_blk_filter6) and parity (state and theta gradient) against the oracle run on
+    the same callable (complex-step derivatives) over the first 200 timesteps."""
+    from oracle import psmf_oracle as O
+    from rpsmf_amd import nonlinearities as NL
+
+    seed = 35861
+    nl = NL.FourierBasis(r, N=N)
+    series = Series(d, r, T, seed, 0, d, False)
+    st0 = init_state(d, r, seed)
+    theta0 = 0.1 * np.random.default_rng(seed + 1).random(nl.n_params)          # beijing_psmf.py:117: theta0 = 0.1 * rand
+    f = _capi.DeviceFilter(d, r, storage="f32", dyn_kind=nl.device_kind, dyn_flags=nl.device_flags, dyn_terms=nl.device_terms)
+    for a, Yc in series.chunks(chunk=1000):
+        f.upload_series(Yc, t0=a, T_total=T)
+    reset = lambda: f.set_state(st0["C"], st0["V"], st0["P"], st0["Q"], st0["mu"], rho=st0["rho"], lambda0=st0["lam"], theta=theta0)
+    n_par = 200
+    Y = np.vstack([Yc for _, Yc in series.chunks(chunk=n_par)][:1])[:n_par].astype(np.float64)
+    st = O.State(C=st0["C"].copy(), V=st0["V"].copy(), mu=st0["mu"].copy(), P=st0["P"].copy(), Q=st0["Q"].copy(), rho=st0["rho"], lam=st0["lam"],
+                 theta=theta0.copy(), gradsum=np.zeros(nl.n_params))
+    st, _, _ = O.run_epoch(st, Y, O.Mode(robust=False), O.CallableDyn(nl, nl.n_params))
+    reset(); f.zero_gradsum()
+    f.run(0, n_par)
+    s = f.get_state()
+    rel = lambda a, b_: float(np.max(np.abs(a - b_)) / np.max(np.abs(b_)))
+    par = dict(steps=n_par, C=rel(s["C"], st.C), V=rel(s["V"], st.V), P=rel(s["P"], st.P), mu=rel(s["mu"], st.mu), gradsum=rel(s["gradsum"], st.gradsum))
+    reset(); f.run(0, T); reset(); f.sync()
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        f.run(0, T, sync=False)
+    f.sync()
+    dt = (time.perf_counter() - t0) / passes
+    geo = f.geometry()
+    f.close()
+    return {"workload": f"PSMF full filter, f = FourierBasis(N={N}) ({nl.n_params} parameters), d={d} r={r} T={T}, f32 storage, 1 GPU",
+            "value": T / dt, "unit": "timesteps/s", "us_per_timestep": 1e6 * dt / T, "kernel": geo["filter_kernel"], "parity_vs_cpu_oracle": par}
+
+
 def run_impute_config(seeds=50, n=295_719, d=19, r=10, n_par=3000, variants=(False, True)):
     """Config D: masked filter, gas-sensor shape (the CSV is not in the reference checkout: synthetic stand-in of the same
     shape), 40 % missing, `seeds` replicas in one launch; parity of replica 0 on an n_par-column prefix against the oracle."""
@@ -570,6 +608,10 @@ def main():
                     other["ExperimentSynthetic_hooks"] = run_synthetic_simplified(_capi)
                 except Exception as e:
                     other["ExperimentSynthetic_hooks"] = {"error": repr(e)}
+                try:
+                    other["ExperimentBeijing_dynamics"] = run_fourier_config(_capi)
+                except Exception as e:
+                    other["ExperimentBeijing_dynamics"] = {"error": repr(e)}
                 try:
                     other["D"] = run_impute_config()
                 except Exception as e:
