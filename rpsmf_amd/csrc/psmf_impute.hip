@@ -19,6 +19,7 @@
 #include "../../include/psmf_hip.h"
 #include "psmf_kernels.hip"
 #include "psmf_blk3.hip"      // DPP row sums, readlane helpers
+#include "psmf_wave16.hip"    // wave_sweep16m: the single-wave sweep with the lane predicates as multipliers (round 3)
 
 #include <cmath>
 #include <cstring>
@@ -362,7 +363,8 @@ __global__ __launch_bounds__(WG) void psmf_impute_kernel(ImputeParams p) {
 //       lane) -- <G, P + Q>, eta, N, phi                                                                  | barrier 3
 //   P3b wave 0 alone, NO barrier: the two symmetric sweep inversions of the reference's Woodbury form (PSMF.py:30-36)
 //       with the 16 x 16 matrix in its registers -- the rank-2 update of a pivot round is one float64 MFMA, the pivot
-//       block travels by v_readlane (wave_sweep16) -- then x_t = x_p + kappa P+ C^T e (four MFMAs), omega, P, Q
+//       block travels by v_readlane (wave_sweep16; since the end of round 3 its multiplier form, wave_sweep16m of
+//       psmf_wave16.hip) -- then x_t = x_p + kappa P+ C^T e (four MFMAs), omega, P, Q
 //   P4  meanwhile waves 1-3: rank-1 updates of C and V (they need N, phi only); then every row owner: bands, metrics | barrier 4
 // P, Q, rho, lambda live in wave 0's registers for the whole run; x is double-buffered in LDS.
 // Measured on the config-D shape (d = 19, r = 10): tools/impute_prof.hip.
@@ -478,6 +480,8 @@ __device__ __forceinline__ void impute2_wave(const ImputeParams& p) {
   }
   double rho = p.rho0, lam = p.lambda0;
   double qv = p.Q0[0], iqv = 1.0;     // running q of Q = q I and its reciprocal (parallel inversions)
+  Sw16K swk;                          // (waves 0, 1: the lane constants of wave_sweep16m)
+  if (WV < 2) sw16k_init(swk, lk, lr);
   bool bad = false;
   unsigned long long nmiss_l = 0;
   int cur = 0;
@@ -502,7 +506,7 @@ __device__ __forceinline__ void impute2_wave(const ImputeParams& p) {
         double A[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) A[q] = inq[q] ? Pm[q] + ((lk + 4 * q) == lr ? qv : 0.0) : (((lk + 4 * q) == lr) ? 1.0 : 0.0);
-        wave_sweep16(A, r2, lk, lr, bad);          // -(P + q I)^-1
+        wave_sweep16m(A, r2, swk, bad);          // -(P + q I)^-1
 #pragma unroll
         for (int q = 0; q < 4; ++q) sW[q * 64 + lane] = inq[q] ? ((lk + 4 * q) == lr ? qv : 0.0) + qv * qv * A[q] : 0.0;
         iqv = 1.0 / qv;
@@ -658,7 +662,7 @@ __device__ __forceinline__ void impute2_wave(const ImputeParams& p) {
         double A[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) A[q] = inq[q] ? Lb[q] + kap * G[q] + ((lk + 4 * q) == lr ? iqt : 0.0) : (((lk + 4 * q) == lr) ? 1.0 : 0.0);
-        wave_sweep16(A, r2, lk, lr, bad);
+        wave_sweep16m(A, r2, swk, bad);
 #pragma unroll
         for (int q = 0; q < 4; ++q) sW[q * 64 + lane] = inq[q] ? -A[q] : 0.0;      // read after barrier 4 + barrier 2 of the next column
       } else if (wv == 0) {
@@ -670,11 +674,11 @@ __device__ __forceinline__ void impute2_wave(const ImputeParams& p) {
         } else {
 #pragma unroll
           for (int q = 0; q < 4; ++q) A[q] = inq[q] ? PP[q] : (((lk + 4 * q) == lr) ? 1.0 : 0.0);
-          wave_sweep16(A, r2, lk, lr, bad);                // -(P + Q)^-1
+          wave_sweep16m(A, r2, swk, bad);                // -(P + Q)^-1
 #pragma unroll
           for (int q = 0; q < 4; ++q) A[q] = inq[q] ? kappa * G[q] - A[q] : (((lk + 4 * q) == lr) ? 1.0 : 0.0);
         }
-        wave_sweep16(A, r2, lk, lr, bad);                // -P+
+        wave_sweep16m(A, r2, swk, bad);                // -P+
         // z = P+ b on the matrix cores: A[q] (symmetric) is the A operand of k-block q as it stands; b_i sits in Bq[q] of the
         // lanes lr == lb (column r of the augmented tile / column 0 of the second one): as the B operand it makes column lb
         // of the product z -- no shuffle of b to the columns, no row sums (4 x 12 DPP instructions)
