@@ -18,6 +18,10 @@
 //        AND 1 - kappa^2 h'P+h in one go; omega, phi; P, G, Q updates in registers;  wave 2: V
 //      wave 1: rank-1 updates of A and K A;  waves 1-3: gradsum += J_theta^T g_f (dyn_backward on 192 threads)      | barrier
 //   mu, in-loop Adam (all waves)
+// Random walk with Q = q I (b.dual6; the default model at these ranks): the two inversions of a step are made independent as in
+// the two-inversion kernels (psmf_block.hip, psmf_blk_filter2's header) -- wave 3 forms W_k = (M_k / beta + I / q_k)^-1 beside wave
+// 0's inversion of M_k = Lbar_k + kappa G, and both take Lbar_{k+1} = (I / q_k - W_k / q_k^2) / omega_k from it: one sweep on the path
+// instead of two.
 // Same recursion and float64 arithmetic as psmf_blk_filter (summation orders differ).  r <= 14: the augmented column needs
 // r2 < 16.  PSMF_FILTER6=0 sends these ranks back to psmf_blk_filter.
 #pragma once
@@ -272,6 +276,7 @@ __device__ __forceinline__ void f6_program(const BlockParams& b) {
   int* errflag = reinterpret_cast<int*>(s4 + 4);
   double* sF = s4 + 6;                // RM/2 x RS: dense Jacobian
   double* sPm = sF + (RM / 2) * RS;
+  double* sW = sPm;                   // dual: W_{k-1} as a tile image (256 of the 272 doubles; s_sc 8: 1 / omega_{k-1}, 9: 1 / q_{k-1}, 10: 1 / q_k)
   double* sT = sPm + (RM / 2) * RS;   // scratch of the dynamics
   double* s_val = sT + (RM / 2) * RS; // DYN_MAX_TERMS x RM
   double* s_tp = s_val + DYN_MAX_TERMS * RM;
@@ -282,6 +287,7 @@ __device__ __forceinline__ void f6_program(const BlockParams& b) {
   const bool dense = dyn_dense(p.dyn_kind, p.dyn_flags);
   const bool th_lds = p.n_theta > 0 && p.n_theta <= BLK_TH_CAP;
   const bool has_bw = p.n_theta > 0 && p.dyn_kind != DYN_RANDOM_WALK;
+  const bool dual = b.dual6 != 0;
   StepParams pd = p;                  // what the dynamics see: theta / gradsum in LDS when they fit
   if (th_lds) { pd.theta = s_theta; pd.gradsum = s_grad; }
 
@@ -304,13 +310,14 @@ __device__ __forceinline__ void f6_program(const BlockParams& b) {
   if (tid < r) s_mu[tid] = st->mu[tid];
   // ---- wave 0: P, Q, G, wave 2: V as 16 x 16 tiles (element (lk + 4 q, lr)); the lane predicates as multipliers ----
   double Vm[4] = {0.0, 0.0, 0.0, 0.0}, Pm[4] = {0.0, 0.0, 0.0, 0.0}, Qm[4] = {0.0, 0.0, 0.0, 0.0}, Gm[4] = {0.0, 0.0, 0.0, 0.0};
-  double finq[4], fpad[4], faugc[4], faugr[4], fxr[4];
+  double finq[4], fdg[4], fpad[4], faugc[4], faugr[4], fxr[4];
   int trx[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int i = lk + 4 * q;
     const bool in = i < r && lr < r;
     finq[q] = in ? 1.0 : 0.0;
+    fdg[q] = (in && i == lr) ? 1.0 : 0.0;
     fpad[q] = (!in && i == lr) ? 1.0 : 0.0;
     faugc[q] = (lr == r2 && i < r) ? 1.0 : 0.0;       // column r2: kappa h_i
     faugr[q] = (i == r2 && lr < r) ? 1.0 : 0.0;       // row r2: kappa h_j
@@ -329,7 +336,8 @@ __device__ __forceinline__ void f6_program(const BlockParams& b) {
   }
   const int rq_c = r2 >> 2, ln_c = ((r2 & 3) << 4) | r2;       // where element (r2, r2) sits
   Sw16K swk;
-  if (wv == 0) sw16k_init(swk, lk, lr);
+  if (wv == 0 || wv == 3) sw16k_init(swk, lk, lr);
+  double qv = st->Q[0], iqv = 1.0 / st->Q[0];      // dual: the running q of Q = q I and its reciprocal (wave 0)
   double rho = st->rho, lam = st->lam;
   bool bad = false;
   __syncthreads();
@@ -340,9 +348,23 @@ __device__ __forceinline__ void f6_program(const BlockParams& b) {
     sA[idx] = (m == c && c < r) ? 1.0 : 0.0;
     sKA[idx] = c < r ? sK[m * RB + c] : 0.0;
   }
-  if (wv == 0) {
+  if (wv == 0 || (wv == 3 && dual)) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) Gm[q] = finq[q] != 0.0 ? sK[(lk + 4 * q) * RB + lr] : 0.0;
+  }
+  if (wv == 3 && dual) {
+    // Lbar_1 = (P + q I)^-1 by one sweep, handed over as the W that reproduces it: W = q I - q^2 Lbar (omega = 1)
+    double A0[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = lk + 4 * q;
+      const double lp = st->P[finq[q] != 0.0 ? i * r + lr : 0];
+      A0[q] = finq[q] * lp + fdg[q] * qv + fpad[q];
+    }
+    wave_sweep16m(A0, r2, swk, bad);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sW[q * 64 + lane] = fdg[q] * qv + finq[q] * qv * qv * A0[q];
+    if (lane == 0) { s_sc[8] = 1.0; s_sc[9] = iqv; s_sc[10] = iqv; }
   }
   __syncthreads();
 
@@ -365,7 +387,13 @@ __device__ __forceinline__ void f6_program(const BlockParams& b) {
       // ================= phase A, matrix wave =================
 #pragma unroll
       for (int q = 0; q < 4; ++q) mb[q] = s_mub[lk + 4 * q];         // mu_bar of this lane's rows (for mu = mu_bar + kappa P+ h)
-      if (p.pbar_predict) {
+      double Lb[4] = {0.0, 0.0, 0.0, 0.0};
+      if (dual) {
+        // Pbar = P + q I (only <G, Pbar> needs it); Lbar_k from W_{k-1}
+        const double k1 = s_sc[8] * s_sc[9], k2 = k1 * s_sc[9];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { Pb[q] = fma(fdg[q], qv, Pm[q]); Lb[q] = fma(-k2, sW[q * 64 + lane], fma(fdg[q], k1, fpad[q])); }
+      } else if (p.pbar_predict) {
         if (dense) {
           // Pbar = F P F^T + Q: T = P F^T, then F T
           double Fr[4];
@@ -405,7 +433,10 @@ __device__ __forceinline__ void f6_program(const BlockParams& b) {
       asm volatile("" ::: "memory");
       if (lane == 0) __hip_atomic_store(s_flagA, jb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       BLK_T(1);
-      if (p.coef_update) {
+      if (dual) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) A[q] = Lb[q];         // (kappa G and the augmented column are added in phase B)
+      } else if (p.coef_update) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) A[q] = Pb[q] + fpad[q];
         wave_sweep16m(A, r2, swk, bad);                 // -Pbar^-1
@@ -436,6 +467,14 @@ __device__ __forceinline__ void f6_program(const BlockParams& b) {
       if (lane == 0) { s_sc[0] = s; s_sc[2] = N; s_sc[3] = invN; s_sc[4] = kappa; }
       asm volatile("" ::: "memory");
       if (lane == 0) __hip_atomic_store(s_flag, jb + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    } else if (wv == 3) {
+      // ================= phase A, W wave (dual): Lbar_k from W_{k-1}, and the scalars wave 0 rewrites in phase B =================
+      if (dual) {
+        const double k1 = s_sc[8] * s_sc[9], k2 = k1 * s_sc[9];
+        kappa = s_sc[10];                                   // (1 / q_k, parked in `kappa` until phase B)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) A[q] = fma(-k2, sW[q * 64 + lane], fma(fdg[q], k1, fpad[q]));
+      }
     } else if (wv == 1) {
       // ================= phase A, coefficient wave: lane = coefficient row =================
       const int m = lane;
@@ -499,7 +538,7 @@ __device__ __forceinline__ void f6_program(const BlockParams& b) {
         const double khc = kappa * hcol;
 #pragma unroll
         for (int q = 0; q < 4; ++q)
-          A[q] = fma(kappa, Gm[q], fpad[q] - finq[q] * A[q]) + (faugc[q] * (kappa * hrow[q]) + faugr[q] * khc);
+          A[q] = fma(kappa, Gm[q], dual ? A[q] : fpad[q] - finq[q] * A[q]) + (faugc[q] * (kappa * hrow[q]) + faugr[q] * khc);
         wave_sweep16m(A, r2, swk, bad);                 // [[-P+, kappa P+ h], [., 1 - kappa^2 h'P+h]]
         BLK_T(4);
 #pragma unroll
@@ -528,6 +567,12 @@ __device__ __forceinline__ void f6_program(const BlockParams& b) {
         rho *= omega;
         if (!p.fixed_lambda) lam += dd;
       }
+      if (dual) {          // for the next step's Lbar: 1 / omega_k, 1 / q_k (the q W_k is formed with), 1 / q_{k+1}
+        const double io = p.robust ? fast_rcp(omega) : 1.0;
+        if (lane == 0) { s_sc[8] = io; s_sc[9] = iqv; s_sc[10] = iqv * io; }
+        iqv *= io;
+        qv *= qscale;
+      }
       // P, G, Q of the step (psmf.py:150-170; G: the tracked Gram of C)
       const double wj = wcol * invN, ew = ee * invN;
 #pragma unroll
@@ -547,6 +592,24 @@ __device__ __forceinline__ void f6_program(const BlockParams& b) {
         const double wcol = s_w[lr];
 #pragma unroll
         for (int q = 0; q < 4; ++q) Vm[q] = vscale * fma(-(wrow[q] * wcol), invN, Vm[q]);       // (w_i w_j first: bitwise symmetric)
+      }
+      // ================= phase B, W wave (dual): W_k = (M_k / beta + I / q_k)^-1, M_k = Lbar_k + kappa G; its own copy of G =================
+      if (wv == 3 && dual) {
+        const double iqt = kappa, kap = s_sc[4], iN = s_sc[3], ee = s_sc[6];
+        const double ib = p.robust ? fast_rcp(p.beta) : 1.0;
+        double hrow[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { hrow[q] = s_h[lk + 4 * q]; wrow[q] = s_w[lk + 4 * q]; }
+        const double hcol = s_h[lr], wcol = s_w[lr];
+        // (A holds Lbar_k + the identity padding: scaling the padding by 1 / beta is harmless, it is swept on its own)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) A[q] = fma(ib, fma(kap, Gm[q], A[q]), fdg[q] * iqt);
+        wave_sweep16m(A, r2, swk, bad);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sW[q * 64 + lane] = -finq[q] * A[q];       // read behind the barrier that ends the step
+        const double wj = wcol * iN, ew = ee * iN;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Gm[q] += finq[q] * (fma(hrow[q], wj, wrow[q] * (hcol * iN)) + ew * (wrow[q] * wj));
       }
       // ================= phase B, wave 1: rank-1 updates of the coefficient matrices (lane = row) =================
       if (wv == 1) {
@@ -599,6 +662,7 @@ __device__ __forceinline__ void f6_program(const BlockParams& b) {
     }
     if (bad) *errflag = 1;
   }
+  if (wv == 3 && bad) *errflag = 1;
   if (wv == 2) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {

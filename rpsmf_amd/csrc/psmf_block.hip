@@ -73,6 +73,7 @@ struct BlockParams {
   double* Acoef0;         // 2 x RB x RM
   double* Bcoef0;         // 2 x RB x RB
   const double* XG0;      // 2 x (RB + XGB) x XGB
+  int dual6;              // psmf_blk_filter6: random walk, Q = q I, full filter, no schedules -> the two inversions of a step side by side
 };
 
 // ---- hand-off through device flags -------------------------------------------------------------------------------

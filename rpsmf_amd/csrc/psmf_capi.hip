@@ -40,11 +40,11 @@ constexpr int kGramWG = 128;
 // Environment switches ("Switches"): read ONCE per handle, at psmf_create -- tests flip them between
 // handles of one process; nothing on the per-block host path calls getenv.
 struct Switches {
-  bool block_mfma = true, bulk2 = true, filter3 = true, filter4 = true, filter6 = true, block_dual = true, block_flags = true, block_chain = true, block_pipe = true;
+  bool block_mfma = true, bulk2 = true, filter3 = true, filter4 = true, filter6 = true, filter6_dual = false, block_dual = true, block_flags = true, block_chain = true, block_pipe = true;
   bool force_collective = false;
   static bool off(const char* name) { const char* e = getenv(name); return e && atoi(e) == 0; }
   void read() {
-    block_mfma = !off("PSMF_BLOCK_MFMA"); bulk2 = !off("PSMF_BULK2"); filter3 = !off("PSMF_FILTER3"); filter4 = !off("PSMF_FILTER4"); filter6 = !off("PSMF_FILTER6"); block_dual = !off("PSMF_BLOCK_DUAL");
+    block_mfma = !off("PSMF_BLOCK_MFMA"); bulk2 = !off("PSMF_BULK2"); filter3 = !off("PSMF_FILTER3"); filter4 = !off("PSMF_FILTER4"); filter6 = !off("PSMF_FILTER6"); filter6_dual = getenv("PSMF_FILTER6_DUAL") && atoi(getenv("PSMF_FILTER6_DUAL")) != 0; block_dual = !off("PSMF_BLOCK_DUAL");
     block_flags = !off("PSMF_BLOCK_FLAGS"); block_chain = !off("PSMF_BLOCK_CHAIN"); block_pipe = !off("PSMF_BLOCK_PIPE");
     force_collective = getenv("PSMF_FORCE_COLLECTIVE") != nullptr;
   }
@@ -291,7 +291,8 @@ void launch_blk_xgram(psmf_filter* h, const psmf::BlockParams& x, double* xg, hi
   hipLaunchKernelGGL(psmf::psmf_blk_xreduce, dim3((int)(xg_elems / 128)), dim3(128), 0, stream, x, xg, (int)psmf::BLK_GRAM_WG);
 }
 
-bool blk_use_filter3(const psmf_filter* h) { return h->sw.filter3; }
+bool blk_small_dual(const psmf_filter* h);
+bool blk_use_filter3(const psmf_filter* h) { return h->sw.filter3 && !blk_small_dual(h); }
 
 bool blk_dual_ok(const psmf_filter* h) {
   // The two-inversion kernels (filter3, filter3s, filter2) read rho and q ONCE per block: per-step R_k / Q_k schedules
@@ -306,6 +307,9 @@ bool blk_dual_ok(const psmf_filter* h) {
 // INCLUDING what filter4s would (measured at r = 10, d = 2e4: cos-phase full filter 117 k timesteps/s on filter4s, 316 k on
 // filter6; its recursive form 196 k against 214 k)
 bool blk_small_ok(const psmf_filter* h) { return h->sw.filter6 && h->cfg.r <= psmf::F6_RMAX; }
+
+// ... and, with PSMF_FILTER6_DUAL=1, the default model too (random walk, Q = q I: filter3s otherwise)
+bool blk_small_dual(const psmf_filter* h) { return h->sw.filter6_dual && blk_small_ok(h) && blk_dual_ok(h); }
 
 bool blk_seq_ok(const psmf_filter* h) {
   if (blk_small_ok(h)) return false;
@@ -332,6 +336,12 @@ void launch_blk_filter(psmf_filter* h, const psmf::BlockParams& b, hipStream_t s
   if (!(blk_dual_ok(h) && blk_use_filter3(h)) && blk_seq_ok(h)) {
     if (h->cfg.r > 16) hipLaunchKernelGGL(psmf::psmf_blk_filter4, dim3(1), dim3(psmf::F3_NT), psmf::blk_filter3_lds_bytes(), stream, b);
     else hipLaunchKernelGGL(psmf::psmf_blk_filter4s, dim3(1), dim3(psmf::F3_NT), psmf::blk_filter3_lds_bytes(), stream, b);
+    return;
+  }
+  if (blk_small_dual(h)) {        // random walk, Q = q I at r <= 14: filter6 with the two inversions side by side
+    psmf::BlockParams b2 = b;
+    b2.dual6 = 1;
+    hipLaunchKernelGGL(psmf::psmf_blk_filter6, dim3(1), dim3(psmf::WG), psmf::blk_filter_lds_bytes(), stream, b2);
     return;
   }
   if (blk_dual_ok(h) && blk_use_filter3(h)) {
@@ -1262,6 +1272,7 @@ int psmf_filter_kernel(psmf_handle h) {
   if (!h) return PSMF_ERR_ARG;
   if (h->engine != 2) return 0;
   if (blk_simpl_ok(h)) return 7;
+  if (blk_small_dual(h)) return 8;
   if (blk_dual_ok(h) && blk_use_filter3(h)) return h->cfg.r > 16 ? 3 : 4;
   if (blk_seq_ok(h)) return h->cfg.r > 16 ? 5 : 6;
   if (blk_dual_ok(h)) return 2;

@@ -146,3 +146,29 @@ def test_small_rank_schedules_with_a_dense_jacobian_and_vs_general_kernel():
     for k in ("C", "V", "mu", "P", "gradsum"):
         assert relerr(s[k], s1[k]) < 1e-9, k
     assert relerr(yp, yp1) < 1e-9
+
+
+@pytest.mark.parametrize("robust", [False, True], ids=["PSMF", "rPSMF"])
+@pytest.mark.parametrize("r", [1, 2, 7, 12, 14])
+def test_small_rank_random_walk_inversions_side_by_side(r, robust):
+    """PSMF_FILTER6_DUAL=1: the default model (random walk, Q = q I) at r <= 14 on psmf_blk_filter6 with W_k = (M_k / beta + I / q_k)^-1
+    formed beside P+_k = M_k^-1 (one sweep on the path of a step instead of two); rPSMF: q, rho, lambda run with omega."""
+    c = _capi()
+    d, T = 260, 130           # three blocks, the last one ragged; two runs
+    nl = NL.RandomWalk()
+    rng = np.random.default_rng(40 + r)
+    Y = O.synthetic_series(d, r, T, 9 + r, noise="t" if robust else "normal", dtype=np.float64)
+    C0 = 0.1 * rng.standard_normal((d, r))
+    V0, P0, Q = 0.1 * np.eye(r), np.eye(r), 0.1 * np.eye(r)
+    mu0 = 0.2 * rng.standard_normal(r)
+    st = O.State(C=C0, V=V0, mu=mu0, P=P0, Q=Q, rho=1.0, lam=1.8)
+    st, Yp, _ = O.run_epoch(st, Y, O.Mode(robust=robust), O.RandomWalkDyn(), want_grad=False)
+    os.environ["PSMF_FILTER6_DUAL"] = "1"
+    try:
+        s, yp = _device(c, nl, d, r, Y, C0, V0, P0, Q, mu0, np.zeros(0), T, robust, FULL)
+    finally:
+        os.environ.pop("PSMF_FILTER6_DUAL", None)
+    tol = 1e-7 if robust else 1e-9
+    for k in ("C", "V", "mu", "P"):
+        assert relerr(s[k], getattr(st, k)) < tol, k
+    assert relerr(yp, Yp) < tol and relerr(s["Q"], st.Q) < tol

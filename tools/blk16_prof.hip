@@ -1,6 +1,6 @@
 // GPU-box diagnostic: per-stage cycles per wave of the small-rank block filter psmf_blk_filter6 (stamps via PSMF_BLK_STAMPS).
 //   hipcc -O3 --offload-arch=gfx950 -I include -o tools/bin/blk16_prof tools/blk16_prof.hip
-//   tools/bin/blk16_prof [r] [kind: 0 rw, 1 cos-phase, 4 fourier] [terms] [recursive]
+//   tools/bin/blk16_prof [r] [kind: 0 rw, 1 cos-phase, 4 fourier] [terms] [recursive] [dual: 1 = the two inversions side by side (random walk)]
 #define PSMF_BLK_STAMPS 1
 #include "../rpsmf_amd/csrc/psmf_blk16.hip"
 #include <cstdio>
@@ -9,7 +9,7 @@
 using namespace psmf;
 
 int main(int argc, char** argv) {
-  const int r = argc > 1 ? atoi(argv[1]) : 20, kind = argc > 2 ? atoi(argv[2]) : 1, terms = argc > 3 ? atoi(argv[3]) : 1, rec = argc > 4 ? atoi(argv[4]) : 0;
+  const int r = argc > 1 ? atoi(argv[1]) : 20, kind = argc > 2 ? atoi(argv[2]) : 1, terms = argc > 3 ? atoi(argv[3]) : 1, rec = argc > 4 ? atoi(argv[4]) : 0, dual = argc > 5 ? atoi(argv[5]) : 0;
   const int nb = (64 - r < 48) ? 64 - r : 48;
   DevState* st; hipMalloc((void**)&st, sizeof(DevState)); hipMemset(st, 0, sizeof(DevState));
   std::vector<double> I(r * r, 0.0), Q(r * r, 0.0); for (int i = 0; i < r; ++i) { I[i * r + i] = 1.0; Q[i * r + i] = 0.1; }
@@ -36,7 +36,7 @@ int main(int argc, char** argv) {
   BlockParams b{}; b.sp.st = st; b.sp.r = r; b.sp.d = dd; b.sp.d_local = dd; b.sp.use_ns = 1; b.sp.coef_update = 1; b.sp.eta_full = 1; b.sp.pbar_predict = 1;
   b.sp.alpha = b.sp.beta = 1.0; b.sp.dyn_kind = kind; b.sp.dyn_flags = 3; b.sp.dyn_terms = terms; b.sp.n_theta = nth; b.sp.theta = th; b.sp.gradsum = th + cap; b.sp.adam_m = th + 2 * cap; b.sp.adam_v = th + 3 * cap;
   b.sp.recursive = rec; b.sp.update_every = 1; b.sp.lr = 1e-3; b.sp.b1 = 0.9; b.sp.b2 = 0.999;
-  b.K = dK; b.Acoef = dA; b.Bcoef = dB; b.Kpart = dKp; b.k0 = 0; b.nb = nb;
+  b.dual6 = dual; b.K = dK; b.Acoef = dA; b.Bcoef = dB; b.Kpart = dKp; b.k0 = 0; b.nb = nb;
   const size_t lds = blk_filter_lds_bytes();
   hipFuncSetAttribute((const void*)psmf_blk_filter6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   auto go = [&]() { psmf_blk_filter6<<<1, WG, lds>>>(b); };
