@@ -244,7 +244,9 @@ __device__ __forceinline__ void f6_dyn_backward(const StepParams& p, const doubl
 // ROLE: the wave's role as a compile-time constant (0 matrix wave, 1 coefficient wave, 2 V wave, 3 the fourth): one program per role,
 // each holding only its own registers.  With the wave index as a run-time value the matrix wave's ~170 registers of state and
 // lane constants were live across the all-thread dynamics code of every wave and were moved out and back around it each step.
-template <int ROLE>
+// DUAL (compile-time as well: the extra selects cost the other configurations 4-5 % as run-time branches): the random walk's two
+// inversions side by side, b.dual6.
+template <int ROLE, bool DUAL>
 __device__ __forceinline__ void f6_program(const BlockParams& b) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* sm = reinterpret_cast<double*>(smem_raw);
@@ -287,7 +289,7 @@ __device__ __forceinline__ void f6_program(const BlockParams& b) {
   const bool dense = dyn_dense(p.dyn_kind, p.dyn_flags);
   const bool th_lds = p.n_theta > 0 && p.n_theta <= BLK_TH_CAP;
   const bool has_bw = p.n_theta > 0 && p.dyn_kind != DYN_RANDOM_WALK;
-  const bool dual = b.dual6 != 0;
+  constexpr bool dual = DUAL;
   StepParams pd = p;                  // what the dynamics see: theta / gradsum in LDS when they fit
   if (th_lds) { pd.theta = s_theta; pd.gradsum = s_grad; }
 
@@ -683,10 +685,19 @@ __device__ __forceinline__ void f6_program(const BlockParams& b) {
 
 __global__ __launch_bounds__(WG) void psmf_blk_filter6(BlockParams b) {
   const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if (w == 0) f6_program<0>(b);
-  else if (w == 1) f6_program<1>(b);
-  else if (w == 2) f6_program<2>(b);
-  else f6_program<3>(b);
+  if (w == 0) f6_program<0, false>(b);
+  else if (w == 1) f6_program<1, false>(b);
+  else if (w == 2) f6_program<2, false>(b);
+  else f6_program<3, false>(b);
+}
+
+// the random walk with Q = q I (PSMF_FILTER6_DUAL=1)
+__global__ __launch_bounds__(WG) void psmf_blk_filter6d(BlockParams b) {
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (w == 0) f6_program<0, true>(b);
+  else if (w == 1) f6_program<1, true>(b);
+  else if (w == 2) f6_program<2, true>(b);
+  else f6_program<3, true>(b);
 }
 
 }  // namespace psmf

@@ -40,11 +40,11 @@ constexpr int kGramWG = 128;
 // Environment switches ("Switches"): read ONCE per handle, at psmf_create -- tests flip them between
 // handles of one process; nothing on the per-block host path calls getenv.
 struct Switches {
-  bool block_mfma = true, bulk2 = true, filter3 = true, filter4 = true, filter6 = true, filter6_dual = false, block_dual = true, block_flags = true, block_chain = true, block_pipe = true;
+  bool block_mfma = true, bulk2 = true, filter3 = true, filter4 = true, filter6 = true, filter6_dual = true, block_dual = true, block_flags = true, block_chain = true, block_pipe = true;
   bool force_collective = false;
   static bool off(const char* name) { const char* e = getenv(name); return e && atoi(e) == 0; }
   void read() {
-    block_mfma = !off("PSMF_BLOCK_MFMA"); bulk2 = !off("PSMF_BULK2"); filter3 = !off("PSMF_FILTER3"); filter4 = !off("PSMF_FILTER4"); filter6 = !off("PSMF_FILTER6"); filter6_dual = getenv("PSMF_FILTER6_DUAL") && atoi(getenv("PSMF_FILTER6_DUAL")) != 0; block_dual = !off("PSMF_BLOCK_DUAL");
+    block_mfma = !off("PSMF_BLOCK_MFMA"); bulk2 = !off("PSMF_BULK2"); filter3 = !off("PSMF_FILTER3"); filter4 = !off("PSMF_FILTER4"); filter6 = !off("PSMF_FILTER6"); filter6_dual = !off("PSMF_FILTER6_DUAL"); block_dual = !off("PSMF_BLOCK_DUAL");
     block_flags = !off("PSMF_BLOCK_FLAGS"); block_chain = !off("PSMF_BLOCK_CHAIN"); block_pipe = !off("PSMF_BLOCK_PIPE");
     force_collective = getenv("PSMF_FORCE_COLLECTIVE") != nullptr;
   }
@@ -308,7 +308,7 @@ bool blk_dual_ok(const psmf_filter* h) {
 // filter6; its recursive form 196 k against 214 k)
 bool blk_small_ok(const psmf_filter* h) { return h->sw.filter6 && h->cfg.r <= psmf::F6_RMAX; }
 
-// ... and, with PSMF_FILTER6_DUAL=1, the default model too (random walk, Q = q I: filter3s otherwise)
+// ... and the default model too (random walk, Q = q I; PSMF_FILTER6_DUAL=0: filter3s), psmf_blk_filter6d
 bool blk_small_dual(const psmf_filter* h) { return h->sw.filter6_dual && blk_small_ok(h) && blk_dual_ok(h); }
 
 bool blk_seq_ok(const psmf_filter* h) {
@@ -341,7 +341,7 @@ void launch_blk_filter(psmf_filter* h, const psmf::BlockParams& b, hipStream_t s
   if (blk_small_dual(h)) {        // random walk, Q = q I at r <= 14: filter6 with the two inversions side by side
     psmf::BlockParams b2 = b;
     b2.dual6 = 1;
-    hipLaunchKernelGGL(psmf::psmf_blk_filter6, dim3(1), dim3(psmf::WG), psmf::blk_filter_lds_bytes(), stream, b2);
+    hipLaunchKernelGGL(psmf::psmf_blk_filter6d, dim3(1), dim3(psmf::WG), psmf::blk_filter_lds_bytes(), stream, b2);
     return;
   }
   if (blk_dual_ok(h) && blk_use_filter3(h)) {
@@ -802,6 +802,7 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
     }
     const size_t flds = psmf::blk_filter_lds_bytes();
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_filter6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
+    CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_filter6d, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_filter<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_filter<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_filter<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));

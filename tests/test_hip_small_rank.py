@@ -68,8 +68,6 @@ MODES = {"full": FULL, "no_update": dict(coef_update=False, eta_full=True, pbar_
 @pytest.mark.parametrize("r", [1, 2, 5, 10, 13, 14])
 @pytest.mark.parametrize("name,make", KINDS, ids=[k[0] for k in KINDS])
 def test_small_rank_kinds_vs_oracle(name, make, r, robust):
-    if name == "random_walk" and not robust:
-        pytest.skip("the plain random walk runs on filter3s")
     c = _capi()
     d, T = 260, 70            # two blocks of 48: the second one ragged; and two runs (the state carried between launches)
     nl = make(r)
@@ -85,8 +83,7 @@ def test_small_rank_kinds_vs_oracle(name, make, r, robust):
     dyn = O.CallableDyn(nl, nl.n_params) if nl.n_params else O.RandomWalkDyn()
     st = O.State(C=C0, V=V0, mu=mu0, P=P0, Q=Q, rho=1.0, lam=1.8, theta=theta.copy(), gradsum=np.zeros(nl.n_params))
     st, Yp, _ = O.run_epoch(st, Y, O.Mode(robust=robust), dyn, want_grad=bool(nl.n_params))
-    iso = np.array_equal(Q, Q[0, 0] * np.eye(r))              # (r = 1: every Q is)
-    want = "psmf_blk_filter3s" if (name == "random_walk" and iso) else "psmf_blk_filter6"
+    want = "psmf_blk_filter6"
     s, yp = _device(c, nl, d, r, Y, C0, V0, P0, Q, mu0, theta, T, robust, FULL, want=want)
     tol = 1e-7 if robust else 1e-8
     for k in ("C", "V", "mu", "P"):
@@ -151,8 +148,9 @@ def test_small_rank_schedules_with_a_dense_jacobian_and_vs_general_kernel():
 @pytest.mark.parametrize("robust", [False, True], ids=["PSMF", "rPSMF"])
 @pytest.mark.parametrize("r", [1, 2, 7, 12, 14])
 def test_small_rank_random_walk_inversions_side_by_side(r, robust):
-    """PSMF_FILTER6_DUAL=1: the default model (random walk, Q = q I) at r <= 14 on psmf_blk_filter6 with W_k = (M_k / beta + I / q_k)^-1
-    formed beside P+_k = M_k^-1 (one sweep on the path of a step instead of two); rPSMF: q, rho, lambda run with omega."""
+    """The default model (random walk, Q = q I) at r <= 14 on psmf_blk_filter6d with W_k = (M_k / beta + I / q_k)^-1 formed beside
+    P+_k = M_k^-1 (one sweep on the path of a step instead of two); rPSMF: q, rho, lambda run with omega.  And the same run with
+    PSMF_FILTER6_DUAL=0 (filter3s): the two kernels agree."""
     c = _capi()
     d, T = 260, 130           # three blocks, the last one ragged; two runs
     nl = NL.RandomWalk()
@@ -163,12 +161,15 @@ def test_small_rank_random_walk_inversions_side_by_side(r, robust):
     mu0 = 0.2 * rng.standard_normal(r)
     st = O.State(C=C0, V=V0, mu=mu0, P=P0, Q=Q, rho=1.0, lam=1.8)
     st, Yp, _ = O.run_epoch(st, Y, O.Mode(robust=robust), O.RandomWalkDyn(), want_grad=False)
-    os.environ["PSMF_FILTER6_DUAL"] = "1"
-    try:
-        s, yp = _device(c, nl, d, r, Y, C0, V0, P0, Q, mu0, np.zeros(0), T, robust, FULL)
-    finally:
-        os.environ.pop("PSMF_FILTER6_DUAL", None)
+    s, yp = _device(c, nl, d, r, Y, C0, V0, P0, Q, mu0, np.zeros(0), T, robust, FULL)
     tol = 1e-7 if robust else 1e-9
     for k in ("C", "V", "mu", "P"):
         assert relerr(s[k], getattr(st, k)) < tol, k
     assert relerr(yp, Yp) < tol and relerr(s["Q"], st.Q) < tol
+    os.environ["PSMF_FILTER6_DUAL"] = "0"
+    try:
+        s3, yp3 = _device(c, nl, d, r, Y, C0, V0, P0, Q, mu0, np.zeros(0), T, robust, FULL, want="psmf_blk_filter3s")
+    finally:
+        os.environ.pop("PSMF_FILTER6_DUAL", None)
+    for k in ("C", "V", "mu", "P"):
+        assert relerr(s[k], s3[k]) < 10 * tol, k

@@ -39,7 +39,8 @@ int main(int argc, char** argv) {
   b.dual6 = dual; b.K = dK; b.Acoef = dA; b.Bcoef = dB; b.Kpart = dKp; b.k0 = 0; b.nb = nb;
   const size_t lds = blk_filter_lds_bytes();
   hipFuncSetAttribute((const void*)psmf_blk_filter6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  auto go = [&]() { psmf_blk_filter6<<<1, WG, lds>>>(b); };
+  hipFuncSetAttribute((const void*)psmf_blk_filter6d, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  auto go = [&]() { if (dual) psmf_blk_filter6d<<<1, WG, lds>>>(b); else psmf_blk_filter6<<<1, WG, lds>>>(b); };
   for (int it = 0; it < 20; ++it) go();
   hipDeviceSynchronize();
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
