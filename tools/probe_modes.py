@@ -9,7 +9,7 @@ d, T = 20000, 2000
 cases = [
     ("random walk r=32 (filter3)", dict(r=32)),
     ("random walk r=20 (filter3, masked)", dict(r=20)),
-    ("random walk r=12 (filter3s)", dict(r=12)),
+    ("random walk r=12 (filter6d; filter3s with PSMF_FILTER6_DUAL=0)", dict(r=12)),
     ("rPSMF r=20", dict(r=20, robust=True)),
     ("cos-phase r=20 (general blocked kernel)", dict(r=20, dyn_kind=_capi.DYN_COS_PHASE)),
     ("cos-phase simplified r=20 (ExperimentSynthetic)", dict(r=20, dyn_kind=_capi.DYN_COS_PHASE, coef_update=False, eta_full=False, pbar_predict=False)),
