@@ -37,8 +37,33 @@ constexpr int F6_RMAX = 14;
 // operand of a sum loaded before the first use.  (The generic loops wait for one LDS round trip per term of every sum and divide
 // twice per element: 5 600 + 6 000 cycles of a 17 000-cycle FourierBasis step, tools/blk16_prof.hip.)  Needs s_val, s_tp zero
 // beyond column r, s_gf zero beyond r, and finite values in the 256 doubles behind theta (the caller clears them).
+// What the Jacobian stage of f6_dyn_forward reads from theta, per thread: the elements M_t[i][j] of its (at most two) matrix
+// elements and the gains c_t[j], four term slots each.  theta does not change inside a block unless the optimiser runs in the time
+// loop (PSMFRecursive), so waves 1-3 load these ONCE per block (f6_jac_cache) instead of twelve LDS operands per element per step.
+struct F6Jac {
+  double m[2][4], c[4];
+  bool on;
+};
+__device__ __forceinline__ void f6_jac_cache(F6Jac& jc, const StepParams& p, const double* th, const int tid) {
+  const int r = p.r, kind = p.dyn_kind, flags = p.dyn_flags, N = p.dyn_terms, j = tid & 15;
+  const int nt = dyn_n_terms(kind, N);
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt) {
+    const DynTerm dt = dyn_term(kind, flags, N, r, tt);
+    const int mo = tt < nt ? dt.m_off : p.n_theta;                              // (a slot beyond nt: the zero tail behind theta)
+    const int co = tt < nt ? (dt.c_off >= 0 ? dt.c_off : 0) : p.n_theta;
+    const bool cg = tt >= nt || dt.c_off >= 0;
+    jc.c[tt] = cg ? th[co + j] : 1.0;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int i = (tid + 192 * k) >> 4;
+      jc.m[k][tt] = (i < r && j < r) ? th[mo + i * r + j] : 0.0;
+    }
+  }
+}
+
 // th, g: theta and the gradient sum AS LDS ARRAYS (through StepParams they are generic pointers: flat loads)
-__device__ __forceinline__ void f6_dyn_forward(const StepParams& p, const double* th, const double tk, const double* s_x, double* s_mub, double* s_fd,
+__device__ __forceinline__ void f6_dyn_forward(const StepParams& p, const double* th, const F6Jac& jc, const double tk, const double* s_x, double* s_mub, double* s_fd,
                                                double* sF, const int ldf, double* s_val, double* s_tp, double* s_part, const int tid) {
   // tid = 0 .. 191: waves 1-3 (the matrix wave only keeps the barrier count, f6_dyn_barriers)
   const int r = p.r, kind = p.dyn_kind, flags = p.dyn_flags, N = p.dyn_terms;
@@ -71,6 +96,21 @@ __device__ __forceinline__ void f6_dyn_forward(const StepParams& p, const double
         cg[tt] = tt >= nt || dt.c_off >= 0;
         co[tt] = tt < nt ? (dt.c_off >= 0 ? dt.c_off : 0) : p.n_theta;
       }
+      if (jc.on) {            // theta fixed for the block: M_t[i][j], c_t[j] from registers
+        double tp[4];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) tp[tt] = s_tp[tt * RM + j] * jc.c[tt];
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int idx = tid + 192 * k, i = idx >> 4;
+          if (i < r && j < r) {
+            double a = 0.0;
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) a += jc.m[k][tt] * tp[tt];
+            sF[i * ldf + j] = a;
+          }
+        }
+      } else {
 #pragma unroll
       for (int k = 0; k < 2; ++k) {
         const int idx = tid + 192 * k, i = idx >> 4;
@@ -83,6 +123,7 @@ __device__ __forceinline__ void f6_dyn_forward(const StepParams& p, const double
           for (int tt = 0; tt < 4; ++tt) a += mv[tt] * (tp[tt] * (cg[tt] ? cj[tt] : 1.0));
           sF[i * ldf + j] = a;
         }
+      }
       }
     }
     if (tid < 64) {           // mu_bar: the terms' matrix-vector products (lane = (term, row)), then the sum over the lane rows
@@ -370,6 +411,12 @@ __device__ __forceinline__ void f6_program(const BlockParams& b) {
   }
   __syncthreads();
 
+  F6Jac jac;
+  jac.on = false;
+  if (wv != 0 && trig16 && dense && !p.recursive && dyn_n_terms(p.dyn_kind, p.dyn_terms) <= 4) {
+    f6_jac_cache(jac, p, s_theta, tid - 64);
+    jac.on = true;
+  }
   double s_last = 0.0, eta_last = 0.0, N_last = 0.0, phi = 1.0, omega = 1.0, ee_last = 0.0;
   BLK_T0();
   for (int jb = 0; jb < b.nb; ++jb) {
@@ -377,7 +424,7 @@ __device__ __forceinline__ void f6_program(const BlockParams& b) {
     // ---- mu_bar = f(theta, mu, k), F = df/dx (psmf.py:104-115; psmf_dyn.hip) ----
     // (waves 1-3; the matrix wave keeps its registers and only joins the barriers)
     if (wv == 0) { for (int q = 0; q < nbar_fwd; ++q) __syncthreads(); }
-    else if (trig16) f6_dyn_forward(p, s_theta, (double)kstep, s_mu, s_mub, s_f, sF, RS, s_val, s_tp, sT, tid - 64);     // both end with a barrier
+    else if (trig16) f6_dyn_forward(p, s_theta, jac, (double)kstep, s_mu, s_mub, s_f, sF, RS, s_val, s_tp, sT, tid - 64);     // both end with a barrier
     else dyn_forward<WG - 64>(pd, (double)kstep, s_mu, s_mub, s_f, sF, RS, s_val, s_tp, sT, tid - 64);
     BLK_T(0);
     // PSMFIter reads Q[k], R[k] of the step (psmf.py:115,123,141): scalar schedules (never with rPSMF's running Q, R)
