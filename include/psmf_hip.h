@@ -195,7 +195,7 @@ int psmf_geometry(psmf_handle h, int32_t* out7);
 /* Which kernel advances the r x r / coefficient-space state with the handle's present configuration (mode flags, dynamics, the Q
  * last uploaded, schedules, switches): 0 = per-step engine (psmf_sweep_solve + psmf_serial), 1 = psmf_blk_filter (general blocked
  * kernel), 2 = psmf_blk_filter2, 3 = psmf_blk_filter3, 4 = psmf_blk_filter3s, 5 = psmf_blk_filter4, 6 = psmf_blk_filter4s, 7 = psmf_blk_filter5,
- * 8 = psmf_blk_filter6 (the general kernel's configurations at r <= 14).
+ * 8 = psmf_blk_filter6 / psmf_blk_filter6d (every configuration at r <= 16 but the simplified hooks).
  * (New: diagnostics for tests and bench.py -- the reference has one code path, pypsmf/psmf/psmf.py:90-102.) */
 int psmf_filter_kernel(psmf_handle h);
 /* diagnostics of the blocked engine's r x r inversions since the last reset: out[0] = timesteps inverted by

@@ -1,5 +1,5 @@
 // psmf_blk_filter6: the general block filter (psmf_blk_filter, psmf_block.hip -- any dynamics kind, any hook configuration,
-// R_k / Q_k schedules, rPSMF, in-loop Adam) for ranks r <= 14, role-specialised.
+// R_k / Q_k schedules, rPSMF, in-loop Adam) for ranks r <= 16, role-specialised.
 //
 // psmf_blk_filter runs every stage of a timestep on all 256 threads with a workgroup barrier after each: at r = 10
 // (ExperimentBeijing: FourierBasis, beijing_psmf.py:97-140) a step was 26 800 cycles, 8 500 of them the two LDS sweep
@@ -22,17 +22,17 @@
 // the two-inversion kernels (psmf_block.hip, psmf_blk_filter2's header) -- wave 3 forms W_k = (M_k / beta + I / q_k)^-1 beside wave
 // 0's inversion of M_k = Lbar_k + kappa G, and both take Lbar_{k+1} = (I / q_k - W_k / q_k^2) / omega_k from it: one sweep on the path
 // instead of two.
-// Same recursion and float64 arithmetic as psmf_blk_filter (summation orders differ).  r <= 14: the augmented column needs
-// r2 < 16.  PSMF_FILTER6=0 sends these ranks back to psmf_blk_filter.
+// Same recursion and float64 arithmetic as psmf_blk_filter (summation orders differ).  r <= 16 (at r = 15, 16 the tile has no column left
+// for the augmentation: kappa P+ h is then a product of four more MFMAs).  PSMF_FILTER6=0 sends these ranks back to psmf_blk_filter.
 #pragma once
 #include "psmf_blk3.hip"
 #include "psmf_wave16.hip"
 
 namespace psmf {
 
-constexpr int F6_RMAX = 14;
+constexpr int F6_RMAX = 16;
 
-// dyn_forward / dyn_backward (psmf_dyn.hip) for the trigonometric kinds at r <= 14, theta in LDS: the same sums in the same
+// dyn_forward / dyn_backward (psmf_dyn.hip) for the trigonometric kinds at r <= 16, theta in LDS: the same sums in the same
 // order, but with 16-wide index maps (thread = (term or row, column): no integer division by the runtime r) and every LDS
 // operand of a sum loaded before the first use.  (The generic loops wait for one LDS round trip per term of every sum and divide
 // twice per element: 5 600 + 6 000 cycles of a 17 000-cycle FourierBasis step, tools/blk16_prof.hip.)  Needs s_val, s_tp zero
@@ -592,11 +592,32 @@ __device__ __forceinline__ void f6_program(const BlockParams& b) {
         BLK_T(4);
 #pragma unroll
         for (int q = 0; q < 4; ++q) Pp[q] = -finq[q] * A[q];
-        const double a_c = rq_c == 0 ? A[0] : (rq_c == 1 ? A[1] : (rq_c == 2 ? A[2] : A[3]));
-        quad += readlane_f64(a_c, ln_c) - 1.0;          // kappa e'e - kappa^2 h'P+h  (psmf.py:155-165)
-        if (lr == r2) {
+        if (r2 < 16) {
+          const double a_c = rq_c == 0 ? A[0] : (rq_c == 1 ? A[1] : (rq_c == 2 ? A[2] : A[3]));
+          quad += readlane_f64(a_c, ln_c) - 1.0;          // kappa e'e - kappa^2 h'P+h  (psmf.py:155-165)
+          if (lr == r2) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) s_munew[lk + 4 * q] = fma(fxr[q], A[q], mb[q]);      // mu = mu_bar + kappa P+ h
+            for (int q = 0; q < 4; ++q) s_munew[lk + 4 * q] = fma(fxr[q], A[q], mb[q]);      // mu = mu_bar + kappa P+ h
+          }
+        } else {
+          // r = 15, 16: no tile column left for the augmentation -- kappa P+ h as a product (the swept tile, symmetric, is the A
+          // operand of its k-blocks; kappa h of the lane's rows in every column the B operand), then kappa^2 h'P+h
+          double kh[4];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) kh[q] = kappa * hrow[q];
+          f64x4 z0 = {0.0, 0.0, 0.0, 0.0}, z1 = {0.0, 0.0, 0.0, 0.0};
+          z0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A[0], kh[0], z0, 0, 0, 0);
+          z1 = __builtin_amdgcn_mfma_f64_16x16x4f64(A[1], kh[1], z1, 0, 0, 0);
+          z0 = __builtin_amdgcn_mfma_f64_16x16x4f64(A[2], kh[2], z0, 0, 0, 0);
+          z1 = __builtin_amdgcn_mfma_f64_16x16x4f64(A[3], kh[3], z1, 0, 0, 0);
+          double dz[4], part = 0.0;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { dz[q] = -fxr[q] * (z0[q] + z1[q]); part = fma(kh[q], dz[q], part); }      // (kappa P+ h)_i, i = lk + 4 q
+          quad -= xor32_sum_f64(xor16_sum_f64(part));
+          if (lr == 0) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s_munew[lk + 4 * q] = mb[q] + dz[q];
+          }
         }
       } else {
 #pragma unroll

@@ -303,7 +303,7 @@ bool blk_dual_ok(const psmf_filter* h) {
 
 // filter4 (psmf_blk4.hip): the role-specialised kernel for diagonal-Jacobian dynamics -- cos-phase, unscaled sinusoid, and the
 // random walk when R_k / Q_k schedules keep it off filter3 -- full filter, Q = q I, r <= 32; the recursive classes included
-// filter6 (psmf_blk16.hip): the general block filter for r <= 14, role-specialised -- whatever filter3s / filter5 do not take,
+// filter6 (psmf_blk16.hip): the general block filter for r <= 16, role-specialised -- whatever filter3s / filter5 do not take,
 // INCLUDING what filter4s would (measured at r = 10, d = 2e4: cos-phase full filter 117 k timesteps/s on filter4s, 316 k on
 // filter6; its recursive form 196 k against 214 k)
 bool blk_small_ok(const psmf_filter* h) { return h->sw.filter6 && h->cfg.r <= psmf::F6_RMAX; }
@@ -338,7 +338,7 @@ void launch_blk_filter(psmf_filter* h, const psmf::BlockParams& b, hipStream_t s
     else hipLaunchKernelGGL(psmf::psmf_blk_filter4s, dim3(1), dim3(psmf::F3_NT), psmf::blk_filter3_lds_bytes(), stream, b);
     return;
   }
-  if (blk_small_dual(h)) {        // random walk, Q = q I at r <= 14: filter6 with the two inversions side by side
+  if (blk_small_dual(h)) {        // random walk, Q = q I at r <= 16: filter6 with the two inversions side by side
     psmf::BlockParams b2 = b;
     b2.dual6 = 1;
     hipLaunchKernelGGL(psmf::psmf_blk_filter6d, dim3(1), dim3(psmf::WG), psmf::blk_filter_lds_bytes(), stream, b2);

@@ -499,7 +499,7 @@ def test_start_predictor_saves_iterations_not_accuracy(r, storage, robust):
             f.set_state(C0, V0, P0, Q, np.zeros(r), rho=1.0, lambda0=1.8)
             if f.geometry()["filter_kernel"] == "psmf_blk_filter6":
                 f.close()
-                pytest.skip("r <= 14: the sweep-based small-rank kernel, no Newton-Schulz iteration to predict a start for")
+                pytest.skip("r <= 16: the sweep-based small-rank kernel, no Newton-Schulz iteration to predict a start for")
             f.counters(reset=True)
             f.run(0, T)
             res[mode] = (f.get_state(), f.counters())

@@ -118,7 +118,7 @@ CASES = [
     ("block", "f64", 3001, 32, 150, 3, None),
     ("block", "f32", 4096, 32, 200, 2, None),                       # the bench.py path: filter3 chain + streaming bulk kernels
     ("block", "f32", 6000, 20, 180, 3, None),                       # r < 32: three column tiles, 44-step blocks
-    ("block", "f64", 1500, 12, 130, 2, None),                       # r <= 14: the small-rank kernel (psmf_blk_filter6d), blocks of 48
+    ("block", "f64", 1500, 12, 130, 2, None),                       # r <= 16: the small-rank kernel (psmf_blk_filter6d), blocks of 48
     ("block", "f64", 2000, 32, 100, 2, {"PSMF_BLOCK_PIPE": "0"}),    # one block after the other: all-reduce of K per block
     ("block", "f64", 2000, 32, 140, 2, {"PSMF_FILTER3": "0"}),       # two-halves filter kernel (psmf_blk_filter2)
     ("step", "f64", 1001, 9, 60, 2, None),                          # per-step engine: r + 1 doubles per timestep

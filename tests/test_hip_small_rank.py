@@ -1,5 +1,5 @@
-"""psmf_blk_filter6 (psmf_blk16.hip), the block filter of ranks r <= 14: ranks 1 ... 14 (even / odd: the identity-padded pivot,
-the augmented column at r2), every dynamics kind and flag set incl. > 4 terms (the generic term loops), the hook configurations,
+"""psmf_blk_filter6 (psmf_blk16.hip), the block filter of ranks r <= 16: ranks 1 ... 16 (even / odd: the identity-padded pivot,
+the augmented column at r2; 15, 16: no column left for it), every dynamics kind and flag set incl. > 4 terms (the generic term loops), the hook configurations,
 rPSMF, a general Q, R_k / Q_k schedules with a dense Jacobian, two blocks and a ragged last block -- against the oracle on the
 same callables, and against the general one-group kernel (PSMF_FILTER6=0) on the same inputs.  GPU only: `pytest -m gpu`."""
 
@@ -65,7 +65,7 @@ MODES = {"full": FULL, "no_update": dict(coef_update=False, eta_full=True, pbar_
 
 
 @pytest.mark.parametrize("robust", [False, True], ids=["PSMF", "rPSMF"])
-@pytest.mark.parametrize("r", [1, 2, 5, 10, 13, 14])
+@pytest.mark.parametrize("r", [1, 2, 5, 10, 13, 14, 15, 16])
 @pytest.mark.parametrize("name,make", KINDS, ids=[k[0] for k in KINDS])
 def test_small_rank_kinds_vs_oracle(name, make, r, robust):
     c = _capi()
@@ -146,7 +146,7 @@ def test_small_rank_schedules_with_a_dense_jacobian_and_vs_general_kernel():
 
 
 @pytest.mark.parametrize("robust", [False, True], ids=["PSMF", "rPSMF"])
-@pytest.mark.parametrize("r", [1, 2, 7, 12, 14])
+@pytest.mark.parametrize("r", [1, 2, 7, 12, 14, 15, 16])
 def test_small_rank_random_walk_inversions_side_by_side(r, robust):
     """The default model (random walk, Q = q I) at r <= 14 on psmf_blk_filter6d with W_k = (M_k / beta + I / q_k)^-1 formed beside
     P+_k = M_k^-1 (one sweep on the path of a step instead of two); rPSMF: q, rho, lambda run with omega.  And the same run with

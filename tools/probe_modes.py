@@ -21,7 +21,8 @@ cases = [
     ("Fourier N=2 r=10, rPSMF", dict(r=10, dyn_kind=_capi.DYN_FOURIER, dyn_terms=2, robust=True)),
     ("scaled walk r=10", dict(r=10, dyn_kind=_capi.DYN_SCALED_WALK)),
     ("recursive sinusoid r=6 (in-loop Adam)", dict(r=6, dyn_kind=_capi.DYN_SINUSOID, dyn_flags=3, recursive=True)),
-    ("Fourier N=2 r=16 (general blocked kernel)", dict(r=16, dyn_kind=_capi.DYN_FOURIER, dyn_terms=2)),
+    ("Fourier N=2 r=16", dict(r=16, dyn_kind=_capi.DYN_FOURIER, dyn_terms=2)),
+    ("Fourier N=1 r=20 (general blocked kernel)", dict(r=20, dyn_kind=_capi.DYN_FOURIER, dyn_terms=1)),
     ("per-step engine r=32 f64", dict(r=32, engine="step", storage="f64")),
     ("per-step engine r=40 f64", dict(r=40, storage="f64")),
 ]
