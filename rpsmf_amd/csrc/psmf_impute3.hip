@@ -1,11 +1,11 @@
-// Version 3 of the masked column loop, for the small shapes of ExperimentImpute (d <= 32 rows, r <= 14; config D: 19 x 10).
+// Version 3 of the masked column loop, for the small shapes of ExperimentImpute (d <= 80 rows, r <= 14; config D: 19 x 10).
 //
 // Everything in this loop is a chain of dependent r x r steps run by single waves, each alone on its SIMD: such a wave
 // issues one instruction per 5-7 cycles whatever the instruction is, so a column costs what its critical wave has
 // INSTRUCTIONS (tools/impute_prof.hip, and the instruction counts of the stamped segments in the ISA).  Version 2 spent
 // them on moving data between waves and on selects; this version removes both:
 //   * every wave forms the masked augmented Gram ITSELF: with d <= 32 it is at most eight float64 MFMAs (16x16x4, one per
-//     group of four rows), and its output layout is the layout the sweep and the trace <G, P + Q> want.  Version 2 spread
+//     group of four rows; twenty at d = 80, still less than the exchange it replaces), and its output layout is the layout the sweep and the trace <G, P + Q> want.  Version 2 spread
 //     the MFMAs over three waves, exchanged partial tiles through LDS and had wave 0 reduce them and hand eta, N, phi to
 //     the others (two barriers, ~2 700 cycles of wave 0's chain per column).  The augmented columns e and 1 are STORED in
 //     the zero padding of C's LDS rows (columns r2, r2 + 1; r2 = r rounded up to even), so the operands are b = row,
@@ -36,8 +36,8 @@
 
 namespace psmf {
 
-inline bool impute3_ok(int d, int r) { return d <= 32 && r <= IR - 2; }
-inline int impute3_groups(int d) { return d <= 12 ? 3 : (d <= 20 ? 5 : 8); }     // template parameter NG: 4 NG rows of LDS
+inline bool impute3_ok(int d, int r) { return d <= 80 && r <= IR - 2; }
+inline int impute3_groups(int d) { return d <= 12 ? 3 : (d <= 20 ? 5 : (d <= 32 ? 8 : (d <= 48 ? 12 : 20))); }     // template parameter NG: 4 NG rows of LDS
 
 inline size_t impute3_lds_bytes(int d, int r) {
   const size_t d4 = 4 * (size_t)impute3_groups(d);
@@ -121,8 +121,13 @@ __device__ __forceinline__ void impute3_wave(const ImputeParams& p) {
   bool bad = false;
   unsigned long long nmiss_l = 0;
   int cur = 0;
-  const int row = min(lane & 31, d - 1), half = lane >> 5;     // wave 2: two lanes per row (columns 8 half .. 8 half + 7)
-  const bool rown = WV == 2 && lane < d;
+  // rows: d <= 32 (NG <= 8): wave 2, two lanes per row (columns 8 half .. 8 half + 7); wider shapes: one lane per row, rows
+  // 0 .. 63 on wave 2 and 64 .. 79 on wave 1 (which has nothing else to do in that phase)
+  constexpr bool WIDE = NG > 8;
+  constexpr bool ROWS = WV == 2 || (WIDE && WV == 1);       // this wave owns rows
+  const int rowi = WIDE ? (WV == 1 ? 64 + lane : lane) : (lane & 31);       // this lane's row
+  const int row = min(rowi, d - 1), half = WIDE ? 0 : lane >> 5;
+  const bool rown = ROWS && rowi < d && (WIDE || lane < 32);
   __syncthreads();
   IMP_T0();
   for (int it = 0; it < p.n_iter; ++it) {
@@ -169,7 +174,7 @@ __device__ __forceinline__ void impute3_wave(const ImputeParams& p) {
     // prefetch column 0 (wave 2; unconditional loads, row index clamped -- see version 2)
     double ny = 0.0;
     uint8_t nm = 0, nmm = 0;
-    if (WV == 2) { ny = Yorg[row]; nm = Mk[row]; nmm = Mm[row]; }
+    if (ROWS) { ny = Yorg[row]; nm = Mk[row]; nmm = Mm[row]; }
     for (int t = 0; t < n; ++t) {
       const double* sxc = sx + cur * IR;
       double* sxn = sx + (cur ^ 1) * IR;
@@ -196,19 +201,29 @@ __device__ __forceinline__ void impute3_wave(const ImputeParams& p) {
           for (int q = 0; q < 4; ++q) xc[q] = sxc[lk + 4 * q];
         }
       }
-      if (WV == 2) {
+      if (ROWS) {
         yv = ny; mv = nm; mmv = nmm;
-        double cr[8], xr[8];
+        if (WIDE) {
+          double cr[IR], xr[IR];
 #pragma unroll
-        for (int l = 0; l < 8; ++l) { cr[l] = sCc[row * IR + 8 * half + l]; xr[l] = sxc[8 * half + l]; }   // (x is zero in the columns of e and 1)
-        double d0 = 0.0, d1 = 0.0;
+          for (int l = 0; l < IR; ++l) { cr[l] = sCc[row * IR + l]; xr[l] = sxc[l]; }   // (x is zero in the columns of e and 1)
+          double d0 = 0.0, d1 = 0.0;
 #pragma unroll
-        for (int l = 0; l < 8; l += 2) { d0 = fma(cr[l], xr[l], d0); d1 = fma(cr[l + 1], xr[l + 1], d1); }
-        yh = xor32_sum_f64(d0 + d1);
+          for (int l = 0; l < IR; l += 2) { d0 = fma(cr[l], xr[l], d0); d1 = fma(cr[l + 1], xr[l + 1], d1); }
+          yh = d0 + d1;
+        } else {
+          double cr[8], xr[8];
+#pragma unroll
+          for (int l = 0; l < 8; ++l) { cr[l] = sCc[row * IR + 8 * half + l]; xr[l] = sxc[8 * half + l]; }   // (x is zero in the columns of e and 1)
+          double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+          for (int l = 0; l < 8; l += 2) { d0 = fma(cr[l], xr[l], d0); d1 = fma(cr[l + 1], xr[l + 1], d1); }
+          yh = xor32_sum_f64(d0 + d1);
+        }
         const double mi = mv ? 1.0 : 0.0;
         const double yi = mv ? yv : 0.0;     // Y is 0 where unobserved (PSMF.py:147-148)
         const double ei = mi * (yi - yh);
-        if (rown) { se[lane] = ei; smk[lane] = mi; sCc[lane * IR + r2] = ei; }
+        if (rown) { se[rowi] = ei; smk[rowi] = mi; sCc[rowi * IR + r2] = ei; }
       }
       if (WV == 3) {
         double vr[4], xr[4];
@@ -222,7 +237,7 @@ __device__ __forceinline__ void impute3_wave(const ImputeParams& p) {
       IMP_T(0);
       solve_barrier<true>();                                          // ---- barrier 1
       IMP_T(1);
-      if (WV == 2) {       // next column's inputs: issued here, off the path to barrier 1, a whole column before their use
+      if (ROWS) {          // next column's inputs: issued here, off the path to barrier 1, a whole column before their use
         const size_t cbase = (size_t)min(t + 1, n - 1) * d;      // (the last column is simply loaded twice)
         ny = Yorg[cbase + row];
         nm = Mk[cbase + row];
@@ -237,7 +252,7 @@ __device__ __forceinline__ void impute3_wave(const ImputeParams& p) {
       }
       const double s = scc[0], rho_t = scc[8], lam_t = scc[9];
       double PPv[4] = {0.0, 0.0, 0.0, 0.0};
-      if (WV >= 2) {
+      if (WV >= 2 || ROWS) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) PPv[q] = sPP[cur * 256 + q * 64 + lane];
       }
@@ -253,11 +268,11 @@ __device__ __forceinline__ void impute3_wave(const ImputeParams& p) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) { Bq[q] = acc0[q] + acc1[q]; G[q] = finq[q] * Bq[q]; }   // b_i = (C^T e)_i: column r of rows i
       double ee = 0.0, msum = 0.0;
-      if (WV >= 2 || (WV == 0 && p.robust)) {
+      if (WV >= 2 || ROWS || (WV == 0 && p.robust)) {
         const double ee_r = rq_e == 0 ? Bq[0] : (rq_e == 1 ? Bq[1] : (rq_e == 2 ? Bq[2] : Bq[3]));
         ee = readlane_f64(ee_r, ln_e);
       }
-      if (WV >= 2) {
+      if (WV >= 2 || ROWS) {
         const double ms_r = rq_m == 0 ? Bq[0] : (rq_m == 1 ? Bq[1] : (rq_m == 2 ? Bq[2] : Bq[3]));
         msum = readlane_f64(ms_r, ln_m);
       }
@@ -265,7 +280,7 @@ __device__ __forceinline__ void impute3_wave(const ImputeParams& p) {
       const double kappa = tmf ? 1.0 : fast_rcp(sgd ? rho_t : rho_t + s);
       // eta, N, phi: the updating waves form them for themselves
       double eta = 0.0, N = 0.0, phi = 1.0;
-      if (WV >= 2) {
+      if (WV >= 2 || ROWS) {
         double tr = 0.0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) tr = fma(G[q], PPv[q], tr);
@@ -324,6 +339,23 @@ __device__ __forceinline__ void impute3_wave(const ImputeParams& p) {
           for (int q = 0; q < 4; ++q) sW[(cur ^ 1) * 256 + q * 64 + lane] = -finq[q] * A[q];
         }
         IMP_T(4);
+        // ---- (wide shapes) bands, metrics of the rows this wave owns ----
+        if (rown) {
+          const double band = p.sig * sqrt(p.robust ? (s * (mv ? 1.0 : 0.0) + eta) : (sgd ? eta : N));   // rPSMF.py:121-123 / PSMF.py:83-84 / MLESMF.py:81-82
+          const double lo = yh - band, hi = yh + band;
+          if (mmv) {
+            const double dl = yh - yv;
+            sse_pred += dl * dl;
+            nmiss_l += 1;
+            if (it == p.n_iter - 1 && !tmf && yv < hi && lo < yv) inside_l += 1;
+          }
+          if (p.want_bands) {
+            const size_t off = ((size_t)rep * n + t) * d + rowi;
+            p.Yrec[off] = yh;
+            p.YrecL[off] = lo;
+            p.YrecH[off] = hi;
+          }
+        }
       } else {
         // ---- waves 2, 3: rank-1 updates with N, phi of this column: C into the next column's buffer, V in place ----
         IMP_T(4);
@@ -357,7 +389,7 @@ __device__ __forceinline__ void impute3_wave(const ImputeParams& p) {
             if (it == p.n_iter - 1 && !tmf && yv < hi && lo < yv) inside_l += 1;
           }
           if (p.want_bands) {
-            const size_t off = ((size_t)rep * n + t) * d + lane;
+            const size_t off = ((size_t)rep * n + t) * d + rowi;
             p.Yrec[off] = yh;
             p.YrecL[off] = lo;
             p.YrecH[off] = hi;
@@ -407,7 +439,13 @@ __global__ __launch_bounds__(WG) void psmf_impute_kernel3(ImputeParams p) {
 
 inline const void* impute3_kernel(int d) {
   const int ng = impute3_groups(d);
-  return ng == 3 ? (const void*)psmf_impute_kernel3<3> : (ng == 5 ? (const void*)psmf_impute_kernel3<5> : (const void*)psmf_impute_kernel3<8>);
+  switch (ng) {
+    case 3: return (const void*)psmf_impute_kernel3<3>;
+    case 5: return (const void*)psmf_impute_kernel3<5>;
+    case 8: return (const void*)psmf_impute_kernel3<8>;
+    case 12: return (const void*)psmf_impute_kernel3<12>;
+    default: return (const void*)psmf_impute_kernel3<20>;
+  }
 }
 
 }  // namespace psmf

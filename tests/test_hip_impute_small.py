@@ -1,6 +1,6 @@
-"""The small-shape masked column loop (psmf_impute_kernel3: d <= 32, r <= 14 -- the shapes of ExperimentImpute) against the
+"""The small-shape masked column loop (psmf_impute_kernel3: d <= 80, r <= 14 -- the shapes of ExperimentImpute) against the
 CPU oracle and against version 2 of the loop (PSMF_IMPUTE_V3=0) on the same inputs: every method (PSMF, rPSMF, MLE-SMF, TMF),
-even and odd ranks, every LDS row-group instantiation (d <= 12, <= 20, <= 32), Q = q I (two inversions side by side) and a
+even and odd ranks, every LDS row-group instantiation (d <= 12, <= 20, <= 32, <= 48, <= 80), Q = q I (two inversions side by side) and a
 general Q (two sweeps in turn), rows / columns without observations, bands.  GPU only: `pytest -m gpu`."""
 
 import os
@@ -51,7 +51,8 @@ def _v2(fn):
             os.environ["PSMF_IMPUTE_V3"] = old
 
 
-SHAPES = [(19, 10), (19, 9), (7, 3), (12, 5), (16, 14), (20, 13), (21, 2), (32, 14), (25, 7), (2, 1)]
+SHAPES = [(19, 10), (19, 9), (7, 3), (12, 5), (16, 14), (20, 13), (21, 2), (32, 14), (25, 7), (2, 1),
+          (33, 5), (40, 7), (48, 14), (64, 14), (65, 3), (75, 10), (80, 13)]       # rows on one lane each; beyond 64 on a second wave
 
 
 @pytest.mark.parametrize("robust", [False, True], ids=["PSMF", "rPSMF"])
@@ -94,7 +95,7 @@ def test_small_shape_general_Q(robust):
     assert relerr(res["YrecL"][0], st["YrecL"]) < tol
 
 
-@pytest.mark.parametrize("d,r", [(19, 10), (9, 3), (30, 13)])
+@pytest.mark.parametrize("d,r", [(19, 10), (9, 3), (30, 13), (75, 10)])
 def test_small_shape_baseline_filters(d, r):
     """MLE-SMF and TMF (gradient step on C, no V) in the small-shape loop."""
     n = 150
