@@ -537,6 +537,7 @@ __global__ __launch_bounds__(WG) void psmf_blk_filter(BlockParams b) {
   }
   if (tid == 0) *errflag = 0;
   if (tid < RM) { s_mub[tid] = 0.0; s_h[tid] = 0.0; s_w[tid] = 0.0; s_f[tid] = 1.0; }
+  for (int idx = tid; idx < (RM / 2) * RS; idx += WG) sF[idx] = 0.0;      // the MFMA form of F P F^T reads whole 32 x 32 images
   if (tid < r) s_mu[tid] = st->mu[tid];
   double Vv[M], Pv[M], Gv[M], Qv[M];
   bool val[M];
@@ -576,7 +577,48 @@ __global__ __launch_bounds__(WG) void psmf_blk_filter(BlockParams b) {
     // ---- S2: Pbar, w = V mu_bar, <G, Pbar>, s, eta, N, kappa ----
     double Pb[M];
     double part = 0.0, gp = 0.0;
-    if (dense && p.pbar_predict) {
+    if (dense && p.pbar_predict && RPAD == 32) {
+      // Pbar = F P F^T + Q on the float64 matrix cores (round 3; this instantiation serves r = 17 ... 32): the four waves each
+      // form one 16 x 16 tile of T = P F^T and then of F T from zero-padded 32 x 32 LDS images, eight MFMAs per tile and
+      // product, every operand of a tile loaded before the first MFMA.  (As two r-long LDS loops per element the two products
+      // were 13 900 of a timestep's 53 500 cycles at r = 20, tools/blkgen_prof.hip.)
+      const int wv_ = tid >> 6, ln_ = tid & 63, ti_ = wv_ >> 1, tj_ = wv_ & 1, lr_ = ln_ & 15, lk_ = ln_ >> 4;
+#pragma unroll
+      for (int m = 0; m < M; ++m) sPm[ii[m] * RS + j] = val[m] ? Pv[m] : 0.0;      // (the thread grid covers the padded matrix)
+      __syncthreads();
+      {
+        double a[8], bq[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          a[q] = sPm[(16 * ti_ + lr_) * RS + 4 * q + lk_];         // P[i][k]
+          bq[q] = sF[(16 * tj_ + lr_) * RS + 4 * q + lk_];         // F^T[k][j] = F[j][k]  (F zero outside r x r)
+        }
+        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], bq[q], acc, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sT[(16 * ti_ + lk_ + 4 * q) * RS + 16 * tj_ + lr_] = acc[q];
+      }
+      __syncthreads();
+      {
+        double a[8], bq[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          a[q] = sF[(16 * ti_ + lr_) * RS + 4 * q + lk_];          // F[i][k]
+          bq[q] = sT[(4 * q + lk_) * RS + 16 * tj_ + lr_];         // T[k][j]
+        }
+        f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], bq[q], acc, 0, 0, 0);
+        __syncthreads();          // every read of the T image is done: the product goes back into it
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sT[(16 * ti_ + lk_ + 4 * q) * RS + 16 * tj_ + lr_] = acc[q];
+      }
+      __syncthreads();
+      // back to the element-per-thread layout, symmetrised (F P F^T is symmetric up to round-off; the sweep assumes exact symmetry)
+#pragma unroll
+      for (int m = 0; m < M; ++m) Pb[m] = val[m] ? 0.5 * (sT[ii[m] * RS + j] + sT[j * RS + ii[m]]) + qs * Qv[m] : 0.0;
+    } else if (dense && p.pbar_predict) {
       // Pbar = F P F^T + Q with a dense F: T = P F^T, then F T, through LDS images (odd row stride: conflict-free)
 #pragma unroll
       for (int m = 0; m < M; ++m)

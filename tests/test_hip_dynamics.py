@@ -57,6 +57,9 @@ KINDS = [
     ("fourier1", lambda r: NL.FourierBasis(r, N=1), 7),
     ("fourier3", lambda r: NL.FourierBasis(r, N=3), 4),
     ("cos_phase", lambda r: NL.CosPhase(r), 9),
+    ("fourier1_r20", lambda r: NL.FourierBasis(r, N=1), 20),      # dense Jacobians beyond the small-rank kernel: psmf_blk_filter<32>,
+    ("sinusoid_r27", lambda r: NL.Sinusoid(r), 27),               #   F P F^T on the matrix cores (odd rank: the zero padding of the images)
+    ("scaled_walk_bias_r32", lambda r: NL.ScaledWalk(r, bias=True), 32),
 ]
 
 
