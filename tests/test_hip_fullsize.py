@@ -309,3 +309,37 @@ def test_filter5_simplified_cos_phase_at_size(robust):
     if robust:
         assert relerr(s["rho"], st.rho) < TOL and relerr(s["lam"], st.lam) < 1e-12
     f.close()
+
+
+@pytest.mark.parametrize("robust", [False, True], ids=["PSMF", "rPSMF"])
+def test_filter6_fourier_and_random_walk_at_size(robust):
+    """The small-rank block filter at d = 20 000, f32 storage, T = 1 000: ExperimentBeijing's dynamics family (FourierBasis N = 2,
+    r = 10: beijing_psmf.py:97-140) -- state, predictions and the theta gradient against the oracle on the same callable -- and the
+    default model (random walk, r = 12) on the side-by-side form of the kernel."""
+    from rpsmf_amd import nonlinearities as NL
+
+    c = _capi()
+    d, T = 20_000, 1_000
+    for r, nl in ((10, NL.FourierBasis(10, N=2)), (12, NL.RandomWalk())):
+        Y, C0 = _bench_problem(d, r, T, robust)
+        rng = np.random.default_rng(7 + r)
+        theta0 = 0.1 * rng.random(nl.n_params)                                   # beijing_psmf.py:117
+        V0, P0, Q = 0.1 * np.eye(r), np.eye(r), 0.1 * np.eye(r)
+        mu0 = 0.2 * rng.standard_normal(r)
+        dyn = O.CallableDyn(nl, nl.n_params) if nl.n_params else O.RandomWalkDyn()
+        st = O.State(C=C0, V=V0, mu=mu0, P=P0, Q=Q, rho=1.0, lam=1.8, theta=theta0.copy(), gradsum=np.zeros(nl.n_params))
+        st, Yp, _ = O.run_epoch(st, Y.astype(np.float64), O.Mode(robust=robust), dyn, want_grad=bool(nl.n_params))
+        f = c.DeviceFilter(d, r, robust=robust, storage="f32", dyn_kind=nl.device_kind, dyn_flags=nl.device_flags, dyn_terms=nl.device_terms)
+        f.upload_series(Y)
+        f.set_state(C0, V0, P0, Q, mu0, rho=1.0, lambda0=1.8, theta=theta0 if nl.n_params else None)
+        assert f.geometry()["filter_kernel"] == "psmf_blk_filter6"
+        if nl.n_params:
+            f.zero_gradsum()
+        f.run(0, T)
+        s = f.get_state()
+        for name in ("C", "V", "mu", "P"):
+            assert relerr(s[name], getattr(st, name)) < TOL, (r, name, relerr(s[name], getattr(st, name)))
+        assert relerr(f.y_pred(0, T), Yp) < TOL
+        if nl.n_params:
+            assert relerr(s["gradsum"], st.gradsum) < 10 * TOL
+        f.close()
