@@ -313,13 +313,13 @@ def test_filter5_simplified_cos_phase_at_size(robust):
 
 @pytest.mark.parametrize("robust", [False, True], ids=["PSMF", "rPSMF"])
 def test_filter6_fourier_and_random_walk_at_size(robust):
-    """The small-rank block filter at d = 20 000, f32 storage, T = 400: ExperimentBeijing's dynamics family (FourierBasis N = 2,
+    """The small-rank block filter at d = 10 000, f32 storage, T = 300: ExperimentBeijing's dynamics family (FourierBasis N = 2,
     r = 10: beijing_psmf.py:97-140) -- state, predictions and the theta gradient against the oracle on the same callable -- and the
     default model (random walk, r = 12) on the side-by-side form of the kernel."""
     from rpsmf_amd import nonlinearities as NL
 
     c = _capi()
-    d, T = 20_000, 400          # (the oracle's complex-step Jacobians over 480 parameters set the price of this test)
+    d, T = 10_000, 300          # (the oracle's complex-step Jacobians over 480 parameters set the price of this test)
     for r, nl in ((10, NL.FourierBasis(10, N=2)), (12, NL.RandomWalk())):
         Y, C0 = _bench_problem(d, r, T, robust)
         rng = np.random.default_rng(7 + r)
