@@ -146,7 +146,6 @@ __device__ __forceinline__ void impute3_wave(const ImputeParams& p) {
         qv = p.Q0[0];
       }
       if (it == 0 || p.robust) {      // this column parity's slot of everything a column's tail publishes
-        double* scc = ssc + cur * 16;
         if (par) {
           // Lbar_0 = (P + q I)^-1 by one sweep, handed over as the W that reproduces it: W = q I - q^2 Lbar (omega = 1)
           double A[4];
