@@ -210,6 +210,7 @@ def run_filter_config(_capi, name, d, r, T, robust, passes=3):
     f.close()
     return {"workload": f"{'rPSMF' if robust else 'PSMF'} full filter d={d} r={r} T={T}, f32 storage, 1 GPU", "value": T / steady,
             "unit": "timesteps/s", "cold_pass_steps_per_s": T / cold, "us_per_timestep": 1e6 * steady / T, "engine": geo["engine"],
+            "kernel": geo.get("filter_kernel"),
             "parity_vs_cpu_oracle": par, "cpu_oracle_steps_per_s": n_par / dt_cpu,
             "hbm_frac_step_at_a_time": (T / steady) * 8.0 * d * (r + 1) / (HBM_PEAK_GBS * 1e9)}
 
@@ -604,6 +605,10 @@ def main():
                         other[name] = run_filter_config(_capi, name, 10_000, 20, 5_000, rob)
                     except Exception as e:
                         other[name] = {"error": repr(e)}
+                try:     # the default model at a small rank (r <= 16: psmf_blk_filter6d, two sweep inversions side by side)
+                    other["small_rank_r12"] = run_filter_config(_capi, "r12", 10_000, 12, 5_000, False)
+                except Exception as e:
+                    other["small_rank_r12"] = {"error": repr(e)}
                 try:
                     other["ExperimentSynthetic_hooks"] = run_synthetic_simplified(_capi)
                 except Exception as e:
