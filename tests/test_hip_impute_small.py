@@ -109,3 +109,31 @@ def test_small_shape_baseline_filters(d, r):
     res = impute.impute_batch(Yorig, M, Mmiss, C0, X0, np.eye(r), Q, 10.0, P, 2, 2, method="tmf")
     assert relerr(res["C"][0], st["C"]) < 1e-10 and relerr(res["X"][0], st["X"]) < 1e-9
     assert relerr(res["Epred"][0], ep[0, 1:]) < 1e-9 and relerr(res["Efull"][0], ef[0, 1:]) < 1e-9
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_small_shapes_drawn_at_random(seed):
+    """Shapes, ranks, methods and horizons drawn at random (fixed seeds) over the whole range of the small-shape loop -- d = 1 ... 80,
+    r = 1 ... 14, r > d included -- against the oracle."""
+    rng = np.random.default_rng(1000 + seed)
+    d, r, n = int(rng.integers(1, 81)), int(rng.integers(1, 15)), int(rng.integers(20, 120))
+    method = ["psmf", "rpsmf", "mle_smf", "tmf"][int(rng.integers(0, 4))]
+    Yorig, M, Mmiss, C0, X0 = _problem(d, n, r, 7000 + seed, empty_column=False)
+    V, Q, P = 2 * np.eye(r), 0.1 * np.eye(r), np.eye(r)
+    if method in ("psmf", "rpsmf"):
+        robust = method == "rpsmf"
+        ep, ef, ib, st = impute_filter(Yorig * M, C0, X0.copy(), M, Mmiss, V, Q, 10.0, P, 2, 2, Yorig, 0.0, robust=robust, lambda0=1.8,
+                                       return_state=True)
+        res = impute.impute_batch(Yorig, M, Mmiss, C0, X0, V, Q, 10.0, P, 2, 2, robust=robust, lambda0=1.8, want_bands=True)
+        tol = 1e-7 if (robust or r >= d) else 1e-9
+        assert _err(res["YrecL"][0], st["YrecL"]) < tol and abs(res["inside"][0] - ib) < 1e-12
+    elif method == "mle_smf":
+        ep, ef, ib, st = mle_smf_filter(Yorig * M, C0, X0.copy(), M, Mmiss, Q, 10.0, P, 2, 2, Yorig, 0.0, return_state=True)
+        res = impute.impute_batch(Yorig, M, Mmiss, C0, X0, np.eye(r), Q, 10.0, P, 2, 2, method="mle_smf", want_bands=True)
+        tol = 1e-8
+    else:
+        ep, ef, st = tmf_filter(Yorig * M, C0, X0.copy(), M, Mmiss, 2, Yorig, 0.0, return_state=True)
+        res = impute.impute_batch(Yorig, M, Mmiss, C0, X0, np.eye(r), Q, 10.0, P, 2, 2, method="tmf")
+        tol = 1e-8
+    assert _err(res["C"][0], st["C"]) < tol and _err(res["X"][0], st["X"]) < tol, (d, r, n, method)
+    assert _err(res["Epred"][0], ep[0, 1:]) < 1e-8 and _err(res["Efull"][0], ef[0, 1:]) < 1e-8
