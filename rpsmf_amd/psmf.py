@@ -147,6 +147,12 @@ def _content_hash(a):
         return hashlib.blake2b(a.data, digest_size=16).hexdigest()
 
 
+def _recognise_default():
+    import os
+
+    return os.environ.get("PSMF_RECOGNISE", "1").strip().lower() not in ("0", "false", "off", "no")
+
+
 def _as_scalar_if_uniform(rho):
     if np.ndim(rho) == 0:
         return float(rho)
@@ -161,7 +167,7 @@ class PSMFIter:
     robust = False
 
     def __init__(self, theta0, C0, V0, mu0, P0, Qs, Rs, nonlinearity, optim="adam", backend="hip",
-                 device=0, storage="auto", gram_refresh=0, engine="auto"):
+                 device=0, storage="auto", gram_refresh=0, engine="auto", recognise=None):
         assert optim in ["adam", "sgd"]
         if backend not in ("hip", "numpy"):
             raise ValueError("backend must be 'hip' or 'numpy'")
@@ -174,8 +180,13 @@ class PSMFIter:
         self.P0 = P0
         self._d, self._r = C0.shape
         self.nonlinearity = nonlinearity
+        # `recognise` (default: on, unless the environment says PSMF_RECOGNISE=0): may the constructor work out by PROBING what
+        # an undeclared hook override / a plain-function nonlinearity computes (modes.py)?  False = the strict behaviour:
+        # undeclared overrides raise TypeError, plain functions are host-stepped (correct for any callable).
+        self.recognise = _recognise_default() if recognise is None else bool(recognise)
         # (backend "hip": a plain function that IS one of the closed-form families runs inside the device loop, modes.py)
-        self._nl = wrap_nonlinearity(nonlinearity, np.asarray(theta0).size, rank=self._r if backend == "hip" else None)
+        self._nl = wrap_nonlinearity(nonlinearity, np.asarray(theta0).size,
+                                     rank=self._r if (backend == "hip" and self.recognise) else None)
         self._C = _StateDict()
         self._P = _StateDict()
         self._V = _StateDict()
@@ -381,10 +392,23 @@ class PSMFIter:
         recognised = False
         if over and not declared:
             # an experiment subclass written against the reference (synthetic_psmf.py:78-100): find out WHAT its hooks compute
-            # by running them on a small probe problem next to the library's statement of every device mode (modes.py)
-            from .modes import recognise_hip_mode
+            # by running them on small probe problems next to the library's statement of every device mode (modes.py)
+            from .modes import HookRecognitionWarning, recognise_hip_mode
 
+            if not self.recognise:
+                raise TypeError(
+                    f"{type(self).__name__} overrides {over} without declaring hip_mode, and recognition by probing is switched "
+                    "off (recognise=False / PSMF_RECOGNISE=0).  Declare the class attribute hip_mode, or use backend='numpy'.")
             mode = recognise_hip_mode(self)
+            if mode is not None:
+                import warnings
+
+                warnings.warn(
+                    f"{type(self).__name__}: the overridden hooks {over} were matched to the device mode {mode!r} by running them on "
+                    "probe problems (several sizes, step indices up to 10^5); the fused device loop executes that mode, NOT the "
+                    "Python hooks.  A hook whose behaviour depends on something the probes do not vary is not detected: declare "
+                    "`hip_mode` on the class to state the intent, or pass recognise=False / backend='numpy'.",
+                    HookRecognitionWarning, stacklevel=4)
             if mode is None:
                 raise TypeError(
                     f"{type(self).__name__} overrides {over}: the device back end can only fuse recognised hook "
@@ -444,14 +468,17 @@ class PSMFIter:
             R = {k: R for k in [0] + ks}
         if not isinstance(Q, dict):
             Q = {k: Q for k in [0] + ks}
-        k1 = 1 if 1 in R else min(R.keys())
+        # which R a step reads: the full filter R[k] (psmf.py:123,141); the simplified hooks R[k - 1]
+        # (synthetic_psmf.py:86-87: eta = tr(R[k-1]) / d).  The device applies rho_sched[k] at step k either way.
+        off = 1 if self.hip_mode == "simplified" else 0
+        k1 = (1 - off) if (1 - off) in R else min(R.keys())
         rho1 = self._rho_of(R[k1])
         Q1 = self._q_matrix(Q[1 if 1 in Q else min(Q.keys())])
         rho_s = q_s = None
         seen_R, seen_Q = {id(R[k1]): rho1}, {}
         kq1 = 1 if 1 in Q else min(Q.keys())
         for k in ks:
-            Rk = R.get(k, R[k1])          # (a dictionary without the step's key: the constant it was built from)
+            Rk = R.get(k - off, R[k1])    # (a dictionary without the step's key: the constant it was built from)
             if id(Rk) not in seen_R:
                 seen_R[id(Rk)] = self._rho_of(Rk)
             rk = seen_R[id(Rk)]
@@ -577,6 +604,7 @@ class PSMFIter:
         self._dev.zero_gradsum()
         self._dev.run(0, T)
         self._after_device_epoch(self._pull_state(T), T)
+        self._verify_recognised_nonlinearity(self._theta[i - 1], T)
 
     def _q_for_step(self, k, Q_running):
         """Q entering P_bar of step k: PSMFIter reads Q[k] (psmf.py:115); rPSMFIter its running Q_{k-1} (rpsmf.py:123)."""
@@ -627,6 +655,25 @@ class PSMFIter:
 
     def _after_device_epoch(self, s, T):
         pass
+
+    def _verify_recognised_nonlinearity(self, theta, T, ks=None):
+        """A plain callable that the constructor matched to a closed-form family (modes.recognise_nonlinearity) ran inside
+        the device loop as that family.  Re-check the match where it matters: at (theta, mu_{k-1}, k) for step indices spread
+        over the epoch just filtered (the mean history is on the device).  A mismatch means the epoch was filtered with the
+        wrong f: raise, naming the way out."""
+        fn = getattr(self._nl, "recognised_from", None)
+        if fn is None or T < 1:
+            return
+        from .modes import nonlinearity_mismatch
+
+        if ks is None:
+            ks = sorted({1, 2, T, *np.linspace(1, T, num=min(T, 24), dtype=int).tolist()})
+        for k in ks:
+            if nonlinearity_mismatch(fn, self._nl, theta, self._mu[k - 1], k):
+                raise RuntimeError(
+                    f"the nonlinearity {getattr(fn, '__name__', fn)!r} was recognised as {type(self._nl).__name__} on probe inputs "
+                    f"but differs from it at step {k} of this run: the device evaluated the wrong function.  Construct with "
+                    "recognise=False (or PSMF_RECOGNISE=0) so that the callable is host-stepped.")
 
     def _predict_hip(self, i, T, n_pred):
         if self._host_stepped():
@@ -757,6 +804,7 @@ class PSMFRecursive(PSMFIter):
         s = self._pull_state(T)
         self._theta[T] = s["theta"].reshape(np.asarray(self.theta0).shape)
         self._after_device_epoch(s, T)
+        self._verify_recognised_nonlinearity(self._theta[0], T, ks=[1])      # theta moves inside the loop: only step 1 has a known theta
 
 
 rPSMF_BASE = PSMFIter          # rebound by rpsmf.py once rPSMFIter exists
