@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define PSMF_ABI_VERSION 2
+#define PSMF_ABI_VERSION 3
 #define PSMF_RMAX 64 /* largest supported rank r */
 
 typedef enum {
@@ -89,6 +89,11 @@ typedef struct {
   int32_t dyn_terms;     /* PSMF_DYN_FOURIER: N                                                */
   int32_t nonuniform_R;  /* 1: R = rho * diag(rho_rows) with per-row values uploaded by psmf_set_row_noise
                             (psmf.py:140-153 takes any diagonal R); per-step engine, weighted Gram every step */
+  int32_t masked;        /* 1: every step has a 0/1 observation mask over the rows (psmf_upload_mask): the masked filter of
+                            ExperimentImpute/PSMF.py:59-84, rPSMF.py:75-135 -- e = m o (y - y_hat), rows with m_i = 0 not
+                            updated, Gram / innovation covariance over the observed rows only, eta and lambda with d (not the
+                            observed count), y_hat stored unmasked.  Per-step engine, one masked Gram pass per step; needs the
+                            full filter (coef_update, eta_full, pbar_predict = 1), uniform R, store_y_pred = 1 */
   double alpha, beta;    /* rPSMF scaling factors (rpsmf.py:45-51), 1.0 unless use_scaling     */
   double adam_lr, adam_lr_end, adam_lr_steps; /* lr (Constant) or lr_start/lr_end/steps
                             (ExponentialLearningRate, learning_rate.py:20-27; steps = 0 ->
@@ -134,6 +139,10 @@ int psmf_set_row_noise(psmf_handle h, const double* rho_rows, double rho_mean);
 int psmf_upload_series(psmf_handle h, const void* Y, int dtype, int64_t t0, int64_t nt,
                        int64_t T_total);
 
+/* masked = 1: M: nt x d_local uint8, time-major like Y, 1 = observed, for the steps t0+1 .. t0+nt (after psmf_upload_series, which
+ * sizes the buffer).  Where M = 0 the value of Y is never read.  replaces Mk = diag(M[:, t]) of ExperimentImpute/PSMF.py:62. */
+int psmf_upload_mask(psmf_handle h, const uint8_t* M, int64_t t0, int64_t nt);
+
 /* ---- the hot loop ---------------------------------------------------------------------- */
 /* for k in k_begin+1 .. k_end: inner(k, y_k)  entirely on the device
  * replaces PSMFIter.step / inner and its ten hooks (psmf.py:85-180), rPSMFIter overrides
@@ -166,6 +175,17 @@ int psmf_sq_error(psmf_handle h, int64_t t0, int64_t nt, double* out);
 /* the same for the roll-out window: sum over q < n_pred and the local rows of (C mu_pred_q - Y_true[q])^2, Y_true the held-out
  * observations y_{T+1} .. y_{T+n_pred} (n_pred x d_local float64, host): tracking.py:74-76 (`_E_pred`). */
 int psmf_predict_sq_error(psmf_handle h, int64_t T, int64_t n_pred, const double* Y_true, double* out);
+
+/* masked = 1, after psmf_run over the steps t0+1 .. t0+nt: the evaluation sums of ExperimentImpute over the held-out entries
+ * Mmiss (nt x d_local uint8, 1 = artificially removed) of this handle's rows, reduced on the device:
+ *   out4[0] = sum (y_hat - y)^2          RMSEM(Yrec, YorgInt, Mmiss)^2 * out4[3]            PSMF.py:88, common.py:79-84
+ *   out4[1] = sum (c_i . x_t - y)^2      RMSEM(C @ X, ...) with the present C, x_t = posterior mean of step t   PSMF.py:86-89
+ *   out4[2] = entries strictly inside y_hat -+ sig sqrt(N_t) (PSMF.py:83-84) resp. sig sqrt(s_t m_i + eta_t) (rPSMF.py:121-123)
+ *   out4[3] = number of held-out entries                                                     common.py:87-94
+ * (row-sharded filter: the caller adds the four sums over the shards).  y = the uploaded series (YorgInt). */
+int psmf_masked_metrics(psmf_handle h, const uint8_t* Mmiss, int64_t t0, int64_t nt, double sig, double* out4);
+/* masked = 1: (s_t, eta_t) of the steps t0+1 .. t0+nt -> out (nt x 2 float64): what the bands YrecL / YrecH are formed from. */
+int psmf_download_step_scalars(psmf_handle h, double* out, int64_t t0, int64_t nt);
 
 /* ---- multi-GPU (row shards, one process per GPU, RCCL over xGMI) ------------------------- */
 #define PSMF_UNIQUE_ID_BYTES 128
@@ -228,7 +248,10 @@ typedef struct {
   double lambda0;
 } psmf_impute_config;
 
-/* All arrays time-major (column t of the reference's d x n matrices is row t here):
+/* Any d and 1 <= r <= PSMF_RMAX.  Shapes whose replica state fits one workgroup's LDS (d <= 512, r <= 16) run one workgroup per
+ * replica, all replicas in one launch (psmf_impute_kernel3 / psmf_impute_kernel2); larger shapes run the replicas one after the
+ * other on the masked per-step engine of the large-d handle (method 0 / 1 only).  psmf_impute_kernel_id() tells which.
+ * All arrays time-major (column t of the reference's d x n matrices is row t here):
  *   YorgInt  n x d  float64  data with native missing values set to 0        (shared)
  *   M        batch x n x d  uint8   1 = observed                              (per replica)
  *   Mmiss    batch x n x d  uint8   1 = artificially removed (evaluation set)
@@ -238,13 +261,21 @@ typedef struct {
  *   Epred, Efull  batch x n_iter  (RMSE after each pass, PSMF.py:88-89)
  *   inside        batch           (coverage, common.py:87-94)
  *   Yrec, YrecL, YrecH  batch x n x d float64 or NULL
+ *   status        batch int32 or NULL: per-replica outcome, PSMF_OK or PSMF_ERR_NUMERIC (r x r system lost positive definiteness,
+ *                 or non-finite errors).  A failed replica gets NaN in Epred / Efull / inside, the others are unaffected and the
+ *                 call returns PSMF_OK -- the reference records NaN for a diverged repeat and carries on (rPSMF.py:236-243).
+ *                 With status = NULL a failed replica fails the call (PSMF_ERR_NUMERIC).
  * replaces ProbabilisticSequentialMatrixFactorizer / robust_PSMF (and, method 2 / 3, the baseline filters
  * stochasticGradientStateSpaceMF / temporalRegularizedMF that share their masked contractions) and the RMSEM /
  * compute_number_inside_bars calls made on their outputs. */
 int psmf_impute_run(const psmf_impute_config* cfg, const double* YorgInt, const uint8_t* M,
                     const uint8_t* Mmiss, double* C, double* X, const double* V,
                     const double* P, const double* Q, double rho, double* Epred, double* Efull,
-                    double* inside, double* Yrec, double* YrecL, double* YrecH, float* elapsed_ms);
+                    double* inside, double* Yrec, double* YrecL, double* YrecH, int32_t* status, float* elapsed_ms);
+/* Which column loop psmf_impute_run uses for cfg->d, cfg->r (with the present environment switches): 1 = round 1's loop,
+ * 2 = psmf_impute_kernel2, 300 + NG = psmf_impute_kernel3<NG> (d <= 80, r <= 14; NG = 4-row groups: 3, 5, 8, 12, 20),
+ * 4 = masked per-step engine of the large-d handle.  Negative = error.  (Diagnostics; the reference has one code path.) */
+int psmf_impute_kernel_id(const psmf_impute_config* cfg);
 
 #ifdef __cplusplus
 }

@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libpsmf_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 RMAX = 64
 F32, F64 = 0, 1
 DYN_RANDOM_WALK, DYN_COS_PHASE, DYN_SCALED_WALK, DYN_SINUSOID, DYN_FOURIER, DYN_HOST = 0, 1, 2, 3, 4, 5
@@ -29,7 +29,7 @@ class PsmfConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "abi_version", "d", "r", "row0", "d_local", "robust", "coef_update", "eta_full", "pbar_predict",
         "fixed_lambda", "dyn_kind", "n_theta", "storage", "store_y_pred", "recursive", "update_every",
-        "gram_refresh", "device", "use_graph", "n_workgroups", "engine", "dyn_flags", "dyn_terms", "nonuniform_R")] + [(n, C.c_double) for n in (
+        "gram_refresh", "device", "use_graph", "n_workgroups", "engine", "dyn_flags", "dyn_terms", "nonuniform_R", "masked")] + [(n, C.c_double) for n in (
         "alpha", "beta", "adam_lr", "adam_lr_end", "adam_lr_steps", "adam_b1", "adam_b2")]
 
 
@@ -76,7 +76,11 @@ SIGNATURES = {
     "psmf_filter_kernel_time": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_int]),
     "psmf_measure_copy_bandwidth": (C.c_int, [C.c_int, C.c_size_t, C.c_int, _dp]),
     "psmf_impute_run": (C.c_int, [C.POINTER(PsmfImputeConfig), _dp, _u8p, _u8p, _dp, _dp, _dp, _dp, _dp,
-                                  C.c_double, _dp, _dp, _dp, _dp, _dp, _dp, C.POINTER(C.c_float)]),
+                                  C.c_double, _dp, _dp, _dp, _dp, _dp, _dp, C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
+    "psmf_impute_kernel_id": (C.c_int, [C.POINTER(PsmfImputeConfig)]),
+    "psmf_upload_mask": (C.c_int, [C.c_void_p, _u8p, C.c_int64, C.c_int64]),
+    "psmf_masked_metrics": (C.c_int, [C.c_void_p, _u8p, C.c_int64, C.c_int64, C.c_double, _dp]),
+    "psmf_download_step_scalars": (C.c_int, [C.c_void_p, _dp, C.c_int64, C.c_int64]),
 }
 
 _lib = None
@@ -133,7 +137,7 @@ class DeviceFilter:
                  fixed_lambda=False, dyn_kind=DYN_RANDOM_WALK, storage="f32", store_y_pred=True,
                  recursive=False, update_every=1, gram_refresh=0, device=0, use_graph=True,
                  n_workgroups=0, engine="auto", alpha=1.0, beta=1.0, adam_lr=1e-3, adam_lr_end=0.0, adam_lr_steps=0.0,
-                 adam_b1=0.9, adam_b2=0.999, row0=0, d_local=None, dyn_flags=0, dyn_terms=0, nonuniform_R=False):
+                 adam_b1=0.9, adam_b2=0.999, row0=0, d_local=None, dyn_flags=0, dyn_terms=0, nonuniform_R=False, masked=False):
         self._lib = load_library()
         self._h = C.c_void_p()
         self.d, self.r = int(d), int(r)
@@ -146,7 +150,7 @@ class DeviceFilter:
             # f64 where the per-step engine runs (one rounding of C per timestep would breach the 1e-5 bar around
             # k = 300)
             blocked = (engine in ("auto", "block", 0, 2) and self.r <= 32 and self.dyn_kind != DYN_HOST and not nonuniform_R
-                       and os.environ.get("PSMF_ENGINE") != "1")
+                       and not masked and os.environ.get("PSMF_ENGINE") != "1")
             storage = "f32" if blocked else "f64"
         self.storage = F64 if storage in ("f64", F64, np.float64) else F32
         self.store_y_pred = bool(store_y_pred)
@@ -157,7 +161,7 @@ class DeviceFilter:
             n_theta=self.n_theta, storage=self.storage, store_y_pred=int(store_y_pred),
             recursive=int(recursive), update_every=int(update_every), gram_refresh=int(gram_refresh),
             device=int(device), use_graph=int(use_graph), n_workgroups=int(n_workgroups),
-            engine={"auto": 0, "step": 1, "block": 2}.get(engine, engine), dyn_flags=int(dyn_flags), dyn_terms=int(dyn_terms), nonuniform_R=int(bool(nonuniform_R)),
+            engine={"auto": 0, "step": 1, "block": 2}.get(engine, engine), dyn_flags=int(dyn_flags), dyn_terms=int(dyn_terms), nonuniform_R=int(bool(nonuniform_R)), masked=int(bool(masked)),
             alpha=float(alpha), beta=float(beta), adam_lr=float(adam_lr), adam_lr_end=float(adam_lr_end),
             adam_lr_steps=float(adam_lr_steps), adam_b1=float(adam_b1), adam_b2=float(adam_b2))
         rc = self._lib.psmf_create(C.byref(self._h), C.byref(cfg))
@@ -236,6 +240,29 @@ class DeviceFilter:
         T_total = t0 + nt if T_total is None else int(T_total)
         self._check(self._lib.psmf_upload_series(self._h, Y.ctypes.data_as(C.c_void_p), dt, t0, nt, T_total))
         self.T = max(self.T, T_total)
+
+    def upload_mask(self, M, t0=0):
+        """Observation mask of the steps t0+1 .. t0+nt (masked handles): (nt, d_local), nonzero = observed."""
+        M = np.ascontiguousarray(np.asarray(M) != 0, dtype=np.uint8)
+        if M.ndim != 2 or M.shape[1] != self.d_local:
+            raise ValueError(f"mask must be (T, {self.d_local}) time-major, got {M.shape}")
+        self._check(self._lib.psmf_upload_mask(self._h, M.ctypes.data_as(_u8p), int(t0), M.shape[0]))
+
+    def masked_metrics(self, Mmiss, sig, t0=0):
+        """(sum (y_hat - y)^2, sum (C x_t - y)^2, entries inside their band, count) over the held-out entries Mmiss (nt, d_local)
+        of this handle's rows, reduced on the device (ExperimentImpute/common.py:79-94)."""
+        Mm = np.ascontiguousarray(np.asarray(Mmiss) != 0, dtype=np.uint8)
+        if Mm.ndim != 2 or Mm.shape[1] != self.d_local:
+            raise ValueError(f"held-out mask must be (T, {self.d_local}) time-major, got {Mm.shape}")
+        out = np.empty(4)
+        self._check(self._lib.psmf_masked_metrics(self._h, Mm.ctypes.data_as(_u8p), int(t0), Mm.shape[0], float(sig), _ptr(out)))
+        return out
+
+    def step_scalars(self, t0, nt):
+        """(s_t, eta_t) of the steps t0+1 .. t0+nt of a masked handle -> (nt, 2)"""
+        out = np.empty((nt, 2))
+        self._check(self._lib.psmf_download_step_scalars(self._h, _ptr(out), int(t0), int(nt)))
+        return out
 
     def set_row_noise(self, rho_rows, rho_mean=None):
         """diag(R) of this handle's rows (nonuniform_R handles); rho_mean = sum(diag R) over ALL rows / d (default: these rows')"""

@@ -3,6 +3,7 @@
 // per-step launches replayed over the series.  No torch, no hipBLAS: plain HIP + RCCL.
 #include "../../include/psmf_hip.h"
 #include "psmf_kernels.hip"
+#include "psmf_masked.hip"
 #include <chrono>
 #include "psmf_block.hip"
 #include "psmf_blk3.hip"
@@ -16,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -64,6 +66,13 @@ struct psmf_filter {
   double* thbuf = nullptr;     // theta | gradsum | adam_m | adam_v, th_cap doubles each
   size_t th_cap = 0;
   double* rho_rows = nullptr;  // d_local per-row diag(R) (cfg.nonuniform_R)
+  // masked filter (cfg.masked, psmf_masked.hip)
+  uint8_t* mask = nullptr;     // T_cap x d_local observation mask (psmf_upload_mask)
+  uint8_t* mmiss = nullptr;    // staging of the held-out mask for psmf_masked_metrics (mmiss_cap bytes)
+  size_t mmiss_cap = 0;
+  double* mg = nullptr;        // r*r + 1: masked Gram and observed count of the current step, summed over workgroups (and ranks)
+  double* sc_hist = nullptr;   // T_cap x 2: (s_k, eta_k) of every step -- the bands are formed from them
+  bool have_mask = false;
   double* sched = nullptr;     // rho_k | q_k schedules, sched_n doubles each (psmf_set_schedules)
   int64_t sched_n = 0;
   double* mu_hist = nullptr;   // (T_cap + 1) x r
@@ -220,7 +229,13 @@ void launch_serial(psmf_filter* h, int first) {
 // one filter step on the stream (captured into the graph or launched eagerly)
 int enqueue_weighted_gram(psmf_filter* h);
 
+int enqueue_masked_gram(psmf_filter* h);
+
 int enqueue_step(psmf_filter* h) {
+  if (h->cfg.masked) {           // this step's masked Gram, observed count, eta, N, w / N (psmf_masked.hip), before the sweep rewrites C
+    const int rc = enqueue_masked_gram(h);
+    if (rc) return rc;
+  }
   if (h->sp.rho_rows && h->cfg.coef_update) {      // non-uniform diagonal R: this step's weighted Gram, before the sweep rewrites C
     const int rc = enqueue_weighted_gram(h);
     if (rc) return rc;
@@ -537,6 +552,22 @@ int enqueue_gram_into(psmf_filter* h, double* Gout, const DevState* wst, const d
   if (h->use_coll) { const int rc = all_reduce_sum(h, Gout, (size_t)r * r, h->stream); if (rc) return rc; }
   return PSMF_OK;
 }
+int enqueue_masked_gram(psmf_filter* h) {
+  const int r = h->cfg.r, rows = (h->cfg.d_local + kGramWG - 1) / kGramWG;
+  if (h->cfg.storage == PSMF_F64)
+    hipLaunchKernelGGL(psmf::psmf_mgram_partial<double>, dim3(kGramWG), dim3(psmf::WG), 0, h->stream, h->sp, (const uint8_t*)h->mask, rows, h->gpart);
+  else
+    hipLaunchKernelGGL(psmf::psmf_mgram_partial<float>, dim3(kGramWG), dim3(psmf::WG), 0, h->stream, h->sp, (const uint8_t*)h->mask, rows, h->gpart);
+  const int ne = r * r + 1;
+  hipLaunchKernelGGL(psmf::psmf_gram_reduce, dim3((ne + 127) / 128), dim3(128), 0, h->stream, (const double*)h->gpart, (int)kGramWG, ne, h->mg);
+  if (h->use_coll) {
+    const int rc = all_reduce_sum(h, h->mg, (size_t)ne, h->stream);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(psmf::psmf_masked_prep, dim3(1), dim3(psmf::WG), 0, h->stream, h->sp, (const double*)h->mg, h->sc_hist);
+  return PSMF_OK;
+}
+
 int enqueue_gram(psmf_filter* h) { return enqueue_gram_into(h, h->st->G, nullptr, nullptr); }
 int enqueue_weighted_gram(psmf_filter* h) { return enqueue_gram_into(h, h->st->GR, h->st, h->sp.rho_rows); }
 
@@ -684,6 +715,13 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
     return fail(nullptr, PSMF_ERR_ARG, "psmf_create: n_theta does not match dyn_kind / dyn_flags / dyn_terms (see psmf_dyn_kind)");
   if (cfg->dyn_kind == PSMF_DYN_HOST && cfg->recursive) return fail(nullptr, PSMF_ERR_ARG, "psmf_create: host-stepped dynamics keep theta (and its optimiser) on the host");
   if (cfg->recursive && cfg->update_every < 1) return fail(nullptr, PSMF_ERR_ARG, "psmf_create: update_every must be >= 1");
+  if (cfg->masked) {
+    if (cfg->dyn_kind != PSMF_DYN_RANDOM_WALK && cfg->dyn_kind != PSMF_DYN_COS_PHASE)
+      return fail(nullptr, PSMF_ERR_ARG, "psmf_create: masked = 1 runs on the per-step engine, which evaluates the random walk and cos-phase dynamics");
+    if (!cfg->coef_update || !cfg->eta_full || !cfg->pbar_predict || cfg->nonuniform_R || cfg->engine == 2 || !cfg->store_y_pred)
+      return fail(nullptr, PSMF_ERR_ARG, "psmf_create: masked = 1 needs the full filter (coef_update, eta_full, pbar_predict), a uniform diagonal R, "
+                                         "store_y_pred = 1 and the per-step engine");
+  }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1)
     return fail(nullptr, PSMF_ERR_NO_DEVICE, "psmf_create: no HIP device visible (the MI355X path has no CPU fallback)");
@@ -709,9 +747,10 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
   CREATE_TRY(hipMemset(h->st, 0, sizeof(DevState)));
   CREATE_TRY(hipMalloc(&h->C, (size_t)cfg->d_local * h->geo.rp * h->elem()));
   CREATE_TRY(hipMalloc((void**)&h->partials, (size_t)h->geo.n_sweep_wg * h->geo.ps * sizeof(double)));
-  CREATE_TRY(hipMalloc((void**)&h->gpart, (size_t)kGramWG * cfg->r * cfg->r * sizeof(double)));
+  CREATE_TRY(hipMalloc((void**)&h->gpart, (size_t)kGramWG * (cfg->r * cfg->r + 1) * sizeof(double)));
+  if (cfg->masked) CREATE_TRY(hipMalloc((void**)&h->mg, (size_t)(cfg->r * cfg->r + 2) * sizeof(double)));
   {
-    const bool can_block = cfg->r <= psmf::RM / 2 && cfg->dyn_kind != PSMF_DYN_HOST && !cfg->nonuniform_R;
+    const bool can_block = cfg->r <= psmf::RM / 2 && cfg->dyn_kind != PSMF_DYN_HOST && !cfg->nonuniform_R && !cfg->masked;
     if (cfg->engine == 2 && !can_block) { h->err = "psmf_create: the blocked engine needs r <= 32, device-evaluated dynamics and a uniform diagonal R"; return bail(PSMF_ERR_ARG); }
     if (cfg->engine < 0 || cfg->engine > 2) { h->err = "psmf_create: engine must be 0 (auto), 1 (per-step) or 2 (blocked)"; return bail(PSMF_ERR_ARG); }
     // auto: blocked whenever it applies -- it is exact and removes the per-step launches and row sweeps
@@ -842,7 +881,8 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
   sp.rho_sched = nullptr; sp.q_sched = nullptr;
   sp.rho_rows = nullptr; sp.rho_mean = 1.0;
   sp.recursive = cfg->recursive; sp.update_every = cfg->update_every > 0 ? cfg->update_every : 1;
-  sp.track_g = (cfg->eta_full || cfg->coef_update) ? 1 : 0;
+  sp.track_g = ((cfg->eta_full || cfg->coef_update) && !cfg->masked) ? 1 : 0;     // masked: G is this step's masked Gram, recomputed every step
+  sp.mask = nullptr;
   sp.external_reduce = 0;
   sp.use_ns = (getenv("PSMF_NS") && atoi(getenv("PSMF_NS")) == 0) ? 0 : 1;
   sp.ns_predict = getenv("PSMF_NS_PREDICT") ? atoi(getenv("PSMF_NS_PREDICT")) : 7;      // bits: 1 a / b (phase F), 2 core (wave 7), 4 applied
@@ -876,6 +916,10 @@ void psmf_destroy(psmf_handle h) {
   if (h->thbuf) hipFree(h->thbuf);
   if (h->sched) hipFree(h->sched);
   if (h->rho_rows) hipFree(h->rho_rows);
+  if (h->mask) hipFree(h->mask);
+  if (h->mmiss) hipFree(h->mmiss);
+  if (h->mg) hipFree(h->mg);
+  if (h->sc_hist) hipFree(h->sc_hist);
   if (h->Kpart) hipFree(h->Kpart);
   if (h->Kmat) hipFree(h->Kmat);
   if (h->Acoef) hipFree(h->Acoef);
@@ -1010,6 +1054,15 @@ int psmf_upload_series(psmf_handle h, const void* Y, int dtype, int64_t t0, int6
     if (h->mu_hist) HIP_TRY(h, hipFree(h->mu_hist));
     h->Y = h->YP = nullptr;
     h->mu_hist = nullptr;
+    if (h->cfg.masked) {
+      if (h->mask) HIP_TRY(h, hipFree(h->mask));
+      if (h->sc_hist) HIP_TRY(h, hipFree(h->sc_hist));
+      h->mask = nullptr; h->sc_hist = nullptr; h->have_mask = false;
+      HIP_TRY(h, hipMalloc((void**)&h->mask, (size_t)T_total * dl));
+      HIP_TRY(h, hipMalloc((void**)&h->sc_hist, (size_t)T_total * 2 * sizeof(double)));
+      HIP_TRY(h, hipMemset(h->sc_hist, 0, (size_t)T_total * 2 * sizeof(double)));
+      h->sp.mask = h->mask;
+    }
     HIP_TRY(h, hipMalloc(&h->Y, (size_t)T_total * dl * es));
     if (h->cfg.store_y_pred) HIP_TRY(h, hipMalloc(&h->YP, (size_t)T_total * dl * es));
     HIP_TRY(h, hipMalloc((void**)&h->mu_hist, (size_t)(T_total + 1) * h->cfg.r * sizeof(double)));
@@ -1055,6 +1108,7 @@ int psmf_run(psmf_handle h, int64_t k_begin, int64_t k_end) {
   if (h->cfg.dyn_kind == PSMF_DYN_HOST) return fail(h, PSMF_ERR_STATE, "psmf_run: host-stepped dynamics advance with psmf_step_host");
   if (h->sched && k_end >= h->sched_n) return fail(h, PSMF_ERR_ARG, "psmf_run: step range beyond the R / Q schedules");
   if (h->cfg.nonuniform_R && !h->sp.rho_rows) return fail(h, PSMF_ERR_STATE, "psmf_run: psmf_set_row_noise first (nonuniform_R = 1)");
+  if (h->cfg.masked && !h->have_mask) return fail(h, PSMF_ERR_STATE, "psmf_run: psmf_upload_mask first (masked = 1)");
   int rc = set_device(h);
   if (rc) return rc;
   if (h->need_prep || h->k_done != k_begin) {
@@ -1565,6 +1619,66 @@ int psmf_step_host(psmf_handle h, int64_t k, const double* mu_bar, const double*
   return PSMF_OK;
 }
 
+/* ---- masked filter on the large-d handle (psmf_masked.hip) ------------------------------------------------------------- */
+int psmf_upload_mask(psmf_handle h, const uint8_t* M, int64_t t0, int64_t nt) {
+  if (!h || !M || t0 < 0 || nt < 0) return fail(h, PSMF_ERR_ARG, "psmf_upload_mask: bad argument");
+  if (!h->cfg.masked) return fail(h, PSMF_ERR_STATE, "psmf_upload_mask: the handle was created with masked = 0");
+  if (!h->mask || t0 + nt > h->T_cap) return fail(h, PSMF_ERR_STATE, "psmf_upload_mask: upload the series first (it sizes the mask buffer)");
+  int rc = set_device(h);
+  if (rc) return rc;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, hipMemcpy(h->mask + (size_t)t0 * h->cfg.d_local, M, (size_t)nt * h->cfg.d_local, hipMemcpyHostToDevice));
+  h->have_mask = true;
+  return PSMF_OK;
+}
+
+int psmf_masked_metrics(psmf_handle h, const uint8_t* Mmiss, int64_t t0, int64_t nt, double sig, double* out4) {
+  if (!h || !Mmiss || !out4 || t0 < 0 || nt < 1) return fail(h, PSMF_ERR_ARG, "psmf_masked_metrics: bad argument");
+  if (!h->cfg.masked || !h->have_mask || !h->YP || t0 + nt > h->T_cap) return fail(h, PSMF_ERR_STATE, "psmf_masked_metrics: needs a masked handle that has run over these steps");
+  int rc = psmf_sync(h);
+  if (rc) return rc;
+  const size_t dl = h->cfg.d_local, nb = (size_t)nt * dl;
+  if (h->mmiss_cap < nb) {
+    if (h->mmiss) HIP_TRY(h, hipFree(h->mmiss));
+    h->mmiss = nullptr; h->mmiss_cap = 0;
+    HIP_TRY(h, hipMalloc((void**)&h->mmiss, nb));
+    h->mmiss_cap = nb;
+  }
+  HIP_TRY(h, hipMemcpy(h->mmiss, Mmiss, nb, hipMemcpyHostToDevice));
+  const int gx = (int)((dl + psmf::WG - 1) / psmf::WG);
+  int gy = (int)((2048 + gx - 1) / gx);                  // ~2 k workgroups in all
+  if (gy > nt) gy = (int)nt;
+  if (gy < 1) gy = 1;
+  const int chunk = (int)((nt + gy - 1) / gy);
+  gy = (int)((nt + chunk - 1) / chunk);
+  rc = ensure_scratch(h, (size_t)gx * gy * 4 * sizeof(double));
+  if (rc) return rc;
+  const size_t lds = (size_t)32 * h->cfg.r * sizeof(double);
+  if (h->cfg.storage == PSMF_F64)
+    hipLaunchKernelGGL(psmf::psmf_masked_metrics_k<double>, dim3(gx, gy), dim3(psmf::WG), lds, h->stream, h->sp, (const uint8_t*)h->mask,
+                       (const uint8_t*)h->mmiss, (const double*)h->sc_hist, (long long)t0, (int)nt, chunk, sig, h->cfg.robust, h->scratch);
+  else
+    hipLaunchKernelGGL(psmf::psmf_masked_metrics_k<float>, dim3(gx, gy), dim3(psmf::WG), lds, h->stream, h->sp, (const uint8_t*)h->mask,
+                       (const uint8_t*)h->mmiss, (const double*)h->sc_hist, (long long)t0, (int)nt, chunk, sig, h->cfg.robust, h->scratch);
+  HIP_TRY(h, hipGetLastError());
+  std::vector<double> part((size_t)gx * gy * 4);
+  HIP_TRY(h, hipMemcpyAsync(part.data(), h->scratch, part.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+  HIP_TRY(h, spin_stream(h->stream));
+  for (int q = 0; q < 4; ++q) out4[q] = 0.0;
+  for (size_t b = 0; b < (size_t)gx * gy; ++b)
+    for (int q = 0; q < 4; ++q) out4[q] += part[b * 4 + q];       // fixed order
+  return PSMF_OK;
+}
+
+int psmf_download_step_scalars(psmf_handle h, double* out, int64_t t0, int64_t nt) {
+  if (!h || !out || t0 < 0 || nt < 0) return fail(h, PSMF_ERR_ARG, "psmf_download_step_scalars: bad argument");
+  if (!h->cfg.masked || !h->sc_hist || t0 + nt > h->T_cap) return fail(h, PSMF_ERR_STATE, "psmf_download_step_scalars: needs a masked handle with an uploaded series");
+  int rc = psmf_sync(h);
+  if (rc) return rc;
+  HIP_TRY(h, hipMemcpy(out, h->sc_hist + 2 * (size_t)t0, (size_t)nt * 2 * sizeof(double), hipMemcpyDeviceToHost));
+  return PSMF_OK;
+}
+
 int psmf_measure_copy_bandwidth(int device, size_t bytes, int iters, double* gbps) {
   if (!gbps || iters < 1 || bytes < (size_t)1 << 20) return fail(nullptr, PSMF_ERR_ARG, "psmf_measure_copy_bandwidth: bad argument");
   psmf_handle h = nullptr;       // errors go to the create-error slot
@@ -1617,3 +1731,88 @@ int psmf_comm_init_host(psmf_handle h, int nranks, int rank, psmf_allreduce_fn f
 }  // extern "C"
 
 #include "psmf_impute.hip"
+
+// psmf_impute_run beyond one workgroup's LDS (d > 512 or r > 16): the replicas one after the other on the masked per-step engine
+// of the large-d handle (psmf_masked.hip), float64 storage.  ExperimentImpute/PSMF.py:59-95, rPSMF.py:75-148: the prior mean of
+// column 0 is X[:, n - 1] (the initial X on pass 0, the last posterior afterwards -- i.e. the running mean), C, V, P carry over the
+// passes, rPSMF restarts Q, rho, lambda at every pass; X[:, t] is the posterior mean of column t (the mean history).
+int impute_run_large(const psmf_impute_config* cfg, const double* YorgInt, const uint8_t* M, const uint8_t* Mmiss, double* C, double* X,
+                     const double* V, const double* P, const double* Q, double rho, double* Epred, double* Efull, double* inside,
+                     double* Yrec, double* YrecL, double* YrecH, int32_t* status, float* elapsed_ms) {
+  auto failc = [&](int code, const std::string& msg) { g_create_error = "psmf_impute_run: " + msg; return code; };
+  if (cfg->method > 1) return failc(PSMF_ERR_ARG, "MLE-SMF / TMF (method 2 / 3) run on the one-workgroup-per-replica engine only: d <= 512, r <= 16");
+  const int d = cfg->d, n = cfg->n, r = cfg->r, B = cfg->batch, robust = cfg->method == 1;
+  psmf_config pc;
+  memset(&pc, 0, sizeof(pc));
+  pc.abi_version = PSMF_ABI_VERSION; pc.d = d; pc.r = r; pc.row0 = 0; pc.d_local = d; pc.robust = robust;
+  pc.coef_update = 1; pc.eta_full = 1; pc.pbar_predict = 1; pc.dyn_kind = PSMF_DYN_RANDOM_WALK; pc.n_theta = 0;
+  pc.storage = PSMF_F64; pc.store_y_pred = 1; pc.update_every = 1; pc.device = cfg->device; pc.use_graph = 1; pc.engine = 1; pc.masked = 1;
+  pc.alpha = pc.beta = 1.0; pc.adam_lr = 1e-3; pc.adam_b1 = 0.9; pc.adam_b2 = 0.999;
+  psmf_handle h = nullptr;
+  int rc = psmf_create(&h, &pc);
+  if (rc) return rc;               // (g_create_error holds the message)
+  auto bail = [&](int code) { g_create_error = std::string("psmf_impute_run: ") + psmf_last_error(h); psmf_destroy(h); return code; };
+  rc = psmf_upload_series(h, YorgInt, PSMF_F64, 0, n, n);
+  if (rc) return bail(rc);
+  const size_t nd = (size_t)n * d;
+  const double qnan = std::numeric_limits<double>::quiet_NaN();
+  std::vector<double> yp, sc;
+  double total_ms = 0.0;
+  for (int b = 0; b < B; ++b) {
+    double* Cb = C + (size_t)b * d * r;
+    double* Xb = X + (size_t)b * n * r;
+    rc = psmf_upload_mask(h, M + (size_t)b * nd, 0, n);
+    if (rc) return bail(rc);
+    rc = psmf_set_state(h, Cb, V, P, Q, Xb + (size_t)(n - 1) * r, rho, robust ? cfg->lambda0 : 0.0, nullptr);
+    if (rc) return bail(rc);
+    bool bad = false;
+    double m4[4] = {0, 0, 0, 0};
+    const auto t_start = std::chrono::steady_clock::now();
+    for (int it = 0; it < cfg->n_iter && !bad; ++it) {
+      if (it > 0 && robust) {        // rPSMF.py:77-79: Q, R, lambda restart; V, P, C and the mean carry over
+        rc = psmf_set_state(h, nullptr, nullptr, nullptr, Q, nullptr, rho, cfg->lambda0, nullptr);
+        if (rc) return bail(rc);
+      }
+      rc = psmf_run(h, 0, n);
+      if (rc) return bail(rc);
+      rc = psmf_masked_metrics(h, Mmiss + (size_t)b * nd, 0, n, cfg->sig, m4);
+      if (rc == PSMF_ERR_NUMERIC) { bad = true; break; }
+      if (rc) return bail(rc);
+      Epred[(size_t)b * cfg->n_iter + it] = std::sqrt(m4[0] / m4[3]);
+      Efull[(size_t)b * cfg->n_iter + it] = std::sqrt(m4[1] / m4[3]);
+      if (!std::isfinite(m4[0]) || !std::isfinite(m4[1])) bad = true;
+    }
+    total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_start).count();
+    if (!bad) {
+      inside[b] = m4[2] / m4[3];
+      rc = psmf_get_state(h, Cb, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr);
+      if (!rc) rc = psmf_download_mu(h, Xb, 1, n);
+      if (!rc && cfg->want_bands) {
+        yp.resize(nd); sc.resize((size_t)2 * n);
+        rc = psmf_download_y_pred(h, yp.data(), PSMF_F64, 0, n);
+        if (!rc) rc = psmf_download_step_scalars(h, sc.data(), 0, n);
+        if (!rc) {
+          const uint8_t* Mb = M + (size_t)b * nd;
+          for (int t = 0; t < n; ++t)
+            for (int i = 0; i < d; ++i) {
+              const size_t at = (size_t)b * nd + (size_t)t * d + i;
+              const double yh = yp[(size_t)t * d + i];
+              const double band = cfg->sig * std::sqrt(robust ? (Mb[(size_t)t * d + i] ? sc[2 * t] : 0.0) + sc[2 * t + 1] : sc[2 * t] + sc[2 * t + 1]);
+              Yrec[at] = yh; YrecL[at] = yh - band; YrecH[at] = yh + band;
+            }
+        }
+      }
+      if (rc == PSMF_ERR_NUMERIC) bad = true;
+      else if (rc) return bail(rc);
+    }
+    if (status) status[b] = bad ? PSMF_ERR_NUMERIC : PSMF_OK;
+    if (bad) {
+      if (!status) return bail(PSMF_ERR_NUMERIC);
+      for (int it = 0; it < cfg->n_iter; ++it) Epred[(size_t)b * cfg->n_iter + it] = Efull[(size_t)b * cfg->n_iter + it] = qnan;
+      inside[b] = qnan;
+    }
+  }
+  if (elapsed_ms) *elapsed_ms = (float)total_ms;
+  psmf_destroy(h);
+  return PSMF_OK;
+}

@@ -74,6 +74,8 @@ struct StepParams {
   // rho_mean = sum(rho_rows over ALL shards) / d, so that tr(R) / d = st->rho * rho_mean.  nullptr / 1.0: uniform R = st->rho I
   const double* rho_rows;
   double rho_mean;
+  // masked filter (cfg.masked, psmf_masked.hip): T_cap x d_local observation mask, time-major like Y (1 = observed); nullptr = all observed
+  const uint8_t* mask;
   int external_reduce;  // 1: partial sums were reduced into st->red (multi-GPU)
   int use_ns;           // 1: Newton-Schulz refinement of the r x r inverses (f64 MFMA), sweep as fallback
   int ns_predict;       // 1: filter3 starts the iteration from the rank-2 downdated, kappa-rescaled previous inverse

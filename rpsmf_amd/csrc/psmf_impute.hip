@@ -817,25 +817,51 @@ inline size_t impute_lds_bytes(int d, int r) {
 #include "psmf_impute3.hip"
 
 #ifndef PSMF_IMPUTE_KERNEL_ONLY
+namespace {
+// Which column loop a shape gets (also what psmf_impute_kernel_id reports): 1 = round 1's loop (PSMF_IMPUTE_V1=1), 2 = psmf_impute_kernel2,
+// 300 + NG = psmf_impute_kernel3<NG> (d <= 80, r <= 14), 4 = the masked per-step engine of the large-d handle (any d, r <= PSMF_RMAX):
+// one workgroup per replica needs the replica's C, V, x in LDS (d <= 512, r <= 16).
+int impute_select(int d, int r, size_t* lds_out) {
+  using namespace psmf;
+  if (r > IR || d > 2 * WG) return 4;
+  const bool v1 = getenv("PSMF_IMPUTE_V1") && atoi(getenv("PSMF_IMPUTE_V1")) != 0;     // the previous column loop (LDS sweeps, ~15 barriers per column)
+  const bool v3 = !v1 && impute3_ok(d, r) && !(getenv("PSMF_IMPUTE_V3") && atoi(getenv("PSMF_IMPUTE_V3")) == 0);   // small shapes: every wave its own Gram
+  const size_t lds = v1 ? impute_lds_bytes(d, r) : (v3 ? impute3_lds_bytes(d, r) : impute2_lds_bytes(d, r));
+  if (lds > 160 * 1024) return 4;
+  if (lds_out) *lds_out = lds;
+  return v1 ? 1 : (v3 ? 300 + impute3_groups(d) : 2);
+}
+}  // namespace
+
+int impute_run_large(const psmf_impute_config* cfg, const double* YorgInt, const uint8_t* M, const uint8_t* Mmiss, double* C, double* X,
+                     const double* V, const double* P, const double* Q, double rho, double* Epred, double* Efull, double* inside,
+                     double* Yrec, double* YrecL, double* YrecH, int32_t* status, float* elapsed_ms);
+
+extern "C" int psmf_impute_kernel_id(const psmf_impute_config* cfg) {
+  if (!cfg || cfg->abi_version != PSMF_ABI_VERSION || cfg->d < 1 || cfg->r < 1 || cfg->r > PSMF_RMAX) return PSMF_ERR_ARG;
+  return impute_select(cfg->d, cfg->r, nullptr);
+}
+
 extern "C" int psmf_impute_run(const psmf_impute_config* cfg, const double* YorgInt, const uint8_t* M,
                                const uint8_t* Mmiss, double* C, double* X, const double* V, const double* P,
                                const double* Q, double rho, double* Epred, double* Efull, double* inside,
-                               double* Yrec, double* YrecL, double* YrecH, float* elapsed_ms) {
+                               double* Yrec, double* YrecL, double* YrecH, int32_t* status, float* elapsed_ms) {
   using namespace psmf;
   auto fail = [&](int code, const std::string& msg) { g_create_error = "psmf_impute_run: " + msg; return code; };
   if (!cfg || !YorgInt || !M || !Mmiss || !C || !X || !V || !P || !Q || !Epred || !Efull || !inside)
     return fail(PSMF_ERR_ARG, "null argument");
   if (cfg->abi_version != PSMF_ABI_VERSION) return fail(PSMF_ERR_ARG, "ABI version mismatch");
   const int d = cfg->d, n = cfg->n, r = cfg->r, B = cfg->batch;
-  if (r < 1 || r > IR) return fail(PSMF_ERR_ARG, "need 1 <= r <= 16");
-  if (d < 1 || d > 2 * WG) return fail(PSMF_ERR_ARG, "need 1 <= d <= 512 (one workgroup per replica)");
+  if (r < 1 || r > PSMF_RMAX) return fail(PSMF_ERR_ARG, "need 1 <= r <= PSMF_RMAX");
+  if (d < 1) return fail(PSMF_ERR_ARG, "need d >= 1");
   if (n < 2 || B < 1 || cfg->n_iter < 1) return fail(PSMF_ERR_ARG, "bad n / batch / n_iter");
   if (cfg->method < 0 || cfg->method > 3) return fail(PSMF_ERR_ARG, "method must be 0 (PSMF), 1 (rPSMF), 2 (MLE-SMF) or 3 (TMF)");
   if (cfg->want_bands && (!Yrec || !YrecL || !YrecH)) return fail(PSMF_ERR_ARG, "want_bands needs Yrec, YrecL, YrecH");
-  const bool v1 = getenv("PSMF_IMPUTE_V1") && atoi(getenv("PSMF_IMPUTE_V1")) != 0;     // the previous column loop (LDS sweeps, ~15 barriers per column)
-  const bool v3 = !v1 && impute3_ok(d, r) && !(getenv("PSMF_IMPUTE_V3") && atoi(getenv("PSMF_IMPUTE_V3")) == 0);   // small shapes: every wave its own Gram
-  const size_t lds = v1 ? impute_lds_bytes(d, r) : (v3 ? impute3_lds_bytes(d, r) : impute2_lds_bytes(d, r));
-  if (lds > 160 * 1024) return fail(PSMF_ERR_ARG, "d * r does not fit one workgroup's LDS");
+  size_t lds = 0;
+  const int sel = impute_select(d, r, &lds);
+  if (sel == 4)       // beyond one workgroup's LDS: the replicas one after the other on the masked per-step engine (psmf_masked.hip)
+    return impute_run_large(cfg, YorgInt, M, Mmiss, C, X, V, P, Q, rho, Epred, Efull, inside, Yrec, YrecL, YrecH, status, elapsed_ms);
+  const bool v1 = sel == 1, v3 = sel >= 300;
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(PSMF_ERR_NO_DEVICE, "no HIP device visible");
   if (cfg->device < 0 || cfg->device >= ndev) return fail(PSMF_ERR_ARG, "bad device ordinal");
@@ -916,8 +942,20 @@ extern "C" int psmf_impute_run(const psmf_impute_config* cfg, const double* Yorg
     I_TRY(hipMemcpy(YrecL, dYl, bnd * 8, hipMemcpyDeviceToHost));
     I_TRY(hipMemcpy(YrecH, dYh, bnd * 8, hipMemcpyDeviceToHost));
   }
-  for (int b = 0; b < B; ++b)
-    if (herr[b]) { rc = fail(PSMF_ERR_NUMERIC, "singular r x r system in replica " + std::to_string(b)); break; }
+  // Per-replica outcome (the reference records NaN for a diverged repeat and carries on, ExperimentImpute/rPSMF.py:236-243): a
+  // replica whose r x r system lost positive definiteness -- or whose errors are not finite -- gets status PSMF_ERR_NUMERIC and NaN
+  // results; the other replicas are untouched by it (one workgroup each).  Without a status array the call fails as a whole.
+  for (int b = 0; b < B; ++b) {
+    bool bad = herr[b] != 0;
+    for (int it = 0; it < cfg->n_iter && !bad; ++it)
+      bad = !std::isfinite(Epred[(size_t)b * cfg->n_iter + it]) || !std::isfinite(Efull[(size_t)b * cfg->n_iter + it]);
+    if (status) status[b] = bad ? PSMF_ERR_NUMERIC : PSMF_OK;
+    if (!bad) continue;
+    if (!status) { rc = fail(PSMF_ERR_NUMERIC, "singular r x r system in replica " + std::to_string(b)); break; }
+    const double qnan = std::numeric_limits<double>::quiet_NaN();
+    for (int it = 0; it < cfg->n_iter; ++it) Epred[(size_t)b * cfg->n_iter + it] = Efull[(size_t)b * cfg->n_iter + it] = qnan;
+    inside[b] = qnan;
+  }
 done:
   hipFree(dY); hipFree(dM); hipFree(dMm); hipFree(dC); hipFree(dX); hipFree(dV); hipFree(dP); hipFree(dQ);
   hipFree(dEp); hipFree(dEf); hipFree(dIn); hipFree(dErr); hipFree(dYr); hipFree(dYl); hipFree(dYh);

@@ -255,6 +255,8 @@ __global__ __launch_bounds__(NT) void psmf_sweep_solve(StepParams p) {
   const T* __restrict__ y = reinterpret_cast<const T*>(p.Y) + (size_t)t * p.d_local;
   T* __restrict__ yp = p.store_yp ? reinterpret_cast<T*>(p.YP) + (size_t)t * p.d_local : nullptr;
   T* __restrict__ C = reinterpret_cast<T*>(p.C);
+  // masked step (psmf_masked.hip): e_i = m_i (y_i - y_hat_i); rows with m_i = 0 keep their c_i, y_hat is stored unmasked
+  const uint8_t* __restrict__ msk = p.mask ? p.mask + (size_t)t * p.d_local : nullptr;
 
   // r-sized operands and all row arithmetic in float64; only the storage of C, y, y_hat is T
   double mub[VEC], wn[VEC];
@@ -296,6 +298,9 @@ __global__ __launch_bounds__(NT) void psmf_sweep_solve(StepParams p) {
     double kr[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) kr[u] = rrow ? rrow[min(base + u * RPP + g, row_end - 1)] : 0.0;
+    bool mo[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) mo[u] = msk ? msk[min(base + u * RPP + g, row_end - 1)] != 0 : true;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int row = base + u * RPP + g;
@@ -309,7 +314,7 @@ __global__ __launch_bounds__(NT) void psmf_sweep_solve(StepParams p) {
       }
 #pragma unroll
       for (int m = GS / 2; m >= 1; m >>= 1) dot += __shfl_xor(dot, m, 64);
-      const double e = ok ? (double)yv[u] - dot : 0.0;
+      const double e = (ok && mo[u]) ? (double)yv[u] - dot : 0.0;
       VT cn;
 #pragma unroll
       for (int v = 0; v < VEC; ++v) {

@@ -34,6 +34,15 @@ def _uniform_rho(R, d):
     return float(dg[0])
 
 
+def kernel_name(d, r):
+    """Which device code psmf_impute_run uses for a (d, r) shape (psmf_impute_kernel_id of include/psmf_hip.h)."""
+    cfg = _capi.PsmfImputeConfig(abi_version=_capi.ABI_VERSION, d=int(d), n=2, r=int(r), batch=1, method=0, n_iter=1)
+    code = _capi.load_library().psmf_impute_kernel_id(C.byref(cfg))
+    if code >= 300:
+        return f"psmf_impute_kernel3<{code - 300}>"
+    return {1: "psmf_impute_kernel", 2: "psmf_impute_kernel2", 4: "masked per-step engine"}.get(code, f"error {code}")
+
+
 def impute_batch(YorgInt, M, Mmiss, C0, X0, V, Q, R, P, sig, Iter, robust=False, lambda0=0.0, device=0,
                  want_bands=False, method=None):
     """Run `batch` replicas.  Reference layouts: YorgInt (d, n); M, Mmiss (batch, d, n);
@@ -69,11 +78,12 @@ def impute_batch(YorgInt, M, Mmiss, C0, X0, V, Q, R, P, sig, Iter, robust=False,
                                  n_iter=int(Iter), device=int(device), want_bands=int(want_bands),
                                  sig=float(sig), lambda0=float(lambda0))
     ms = C.c_float()
+    status = np.zeros(B, dtype=np.int32)
     dp = lambda a: None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
     up = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint8))
     rc = lib.psmf_impute_run(C.byref(cfg), dp(Yt), up(Mt), up(Mmt), dp(Cb), dp(Xb), dp(Vm), dp(Pm), dp(Qm),
                              _uniform_rho(R, d), dp(Epred), dp(Efull), dp(inside), dp(bands[0]), dp(bands[1]),
-                             dp(bands[2]), C.byref(ms))
+                             dp(bands[2]), status.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(ms))
     if rc != _capi.OK:
         msg = lib.psmf_last_error(None).decode()
         if rc == _capi.ERR_NUMERIC:
@@ -81,7 +91,10 @@ def impute_batch(YorgInt, M, Mmiss, C0, X0, V, Q, R, P, sig, Iter, robust=False,
         if rc == _capi.ERR_ARG:
             raise ValueError(msg)
         raise _capi.PsmfError(f"psmf_impute_run failed ({rc}): {msg}")
-    out = dict(Epred=Epred, Efull=Efull, inside=inside, C=Cb, X=np.transpose(Xb, (0, 2, 1)), elapsed_ms=ms.value)
+    # a replica whose r x r system broke down has NaN results and status != 0; the others are complete (the reference's
+    # repeats loop records NaN for such a repeat and carries on, ExperimentImpute/rPSMF.py:236-243)
+    out = dict(Epred=Epred, Efull=Efull, inside=inside, C=Cb, X=np.transpose(Xb, (0, 2, 1)), elapsed_ms=ms.value, status=status,
+               kernel=kernel_name(d, r))
     if want_bands:
         out.update(Yrec=np.transpose(bands[0], (0, 2, 1)), YrecL=np.transpose(bands[1], (0, 2, 1)),
                    YrecH=np.transpose(bands[2], (0, 2, 1)))
@@ -97,6 +110,10 @@ def _single(Y, C, X, d, n, r, M, Mmiss, V, Q, R, P, sig, Iter, YorgInt, Einit, r
         raise ValueError("the device path requires Y == YorgInt * M (as the experiment constructs it)")
     res = impute_batch(YorgInt, M, Mmiss, C, X, V, Q, R, P, sig, Iter, robust=robust, lambda0=lambda0, method=method)
     X[...] = res["X"][0]  # the reference updates the caller's X in place (PSMF.py:74)
+    if res["status"][0] != 0:
+        # the reference's functions return NaN errors when the recursion diverges (its main() then records NaN for the repeat,
+        # rPSMF.py:236-243): same here, with NaN coverage
+        res["inside"][0] = np.nan
     Epred = np.zeros((1, Iter + 1))
     Efull = np.zeros((1, Iter + 1))
     Epred[0, 0] = Efull[0, 0] = Einit

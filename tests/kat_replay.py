@@ -1,0 +1,45 @@
+"""Replay of the input draws behind the reference's stored known answers (ExperimentImpute/output/*.json).
+
+Every script of the experiment (PSMF.py:101-158, rPSMF.py:153-213, MLESMF.py:98-156, TMF.py:79-131) seeds the GLOBAL numpy
+RNG with 123 once and then, per repeat: prepare_missing (common.py:50-76), C ~ U(0,1)^{d x r}, X ~ U(0,1)^{r x n} -- the same
+sequence for all four methods (the JSONs' input hashes are identical across them).  Repeat k can only be drawn after repeats
+0 .. k-1; masks are kept as uint8 (100 repeats of the S&P 500 shape would be 1 GB as int64 / float64).
+"""
+
+import functools
+import json
+
+import numpy as np
+
+from conftest import load_golden
+from rpsmf_amd import impute_harness as H
+
+DATASETS = {"pm25": "impute_kat_pm25", "pm10": "impute_kat_pm10", "sp500": "impute_kat_sp500"}
+METHODS = ("PSMF", "rPSMF", "MLESMF", "TMF")
+# relative tolerance on error_predict / error_full against the stored answers (see tests/test_oracle_kat.py for the S&P 500 figure)
+TOL = {"pm25": 1e-9, "pm10": 1e-9, "sp500": 2e-8}
+
+
+@functools.lru_cache(maxsize=3)
+def fixture(ds):
+    return load_golden(DATASETS[ds])
+
+
+def params(g, method, pct):
+    return json.loads(str(g[f"{method}_{pct}_params"]))
+
+
+def draws(ds, pct, n_rep, r=10, want=None):
+    """The first `n_rep` repeats of (dataset, pct): list of dicts with M, Mmiss (uint8, d x n), C, X, hashes of Y, C, X.
+    `want`: the repeats to KEEP (the others are still drawn, to advance the RNG, but dropped)."""
+    g = fixture(ds)
+    Yorig = g["Yorig"]
+    np.random.seed(123)
+    out = []
+    for rep in range(n_rep):
+        pb = H.draw_problem(Yorig, pct, r)
+        if want is not None and rep not in want:
+            continue
+        out.append(dict(rep=rep, M=pb["M"].astype(np.uint8), Mmiss=pb["Mmiss"].astype(np.uint8), C=pb["C"], X=pb["X"], ratio=pb["ratio"],
+                        hY=H.matrix_hash(pb["Y"]), hC=H.matrix_hash(pb["C"]), hX=H.matrix_hash(pb["X"])))
+    return out

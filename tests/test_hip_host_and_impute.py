@@ -225,5 +225,5 @@ def test_impute_bands_and_state_vs_oracle_ragged(robust):
 
 def test_impute_argument_errors():
     with pytest.raises(ValueError):
-        impute.impute_batch(np.zeros((3, 10)), np.ones((3, 10)), np.ones((3, 10)), np.ones((3, 17)), np.ones((17, 10)),
-                            np.eye(17), np.eye(17), 1.0, np.eye(17), 2, 1)   # r > 16
+        impute.impute_batch(np.zeros((3, 10)), np.ones((3, 10)), np.ones((3, 10)), np.ones((3, 65)), np.ones((65, 10)),
+                            np.eye(65), np.eye(65), 1.0, np.eye(65), 2, 1)   # r > PSMF_RMAX (r = 17 .. 64: the masked per-step engine)
