@@ -75,6 +75,9 @@ def parse():
                     help="N > 1: strong = BASELINE config E as stated, the d rows sharded over the ranks (default); weak = every rank holds "
                          "--rows rows, d = N x rows (what more GPUs buy here: rows at the same timesteps/s, DESIGN section 6)")
     ap.add_argument("--pid-dir", default=None, help="write rank<r>.pid / rank<r>.timed marker files there (fault-injection tests)")
+    ap.add_argument("--parity-fixture", default=None,
+                    help="stored oracle answers of this workload (format of tests/golden/make_golden_fullsize.py) for the in-run parity of a "
+                         "sharded run; default: tests/golden/fullsize_E_{psmf,rpsmf}.npz when the workload is BASELINE config E")
     return ap.parse_args()
 
 
@@ -82,7 +85,11 @@ class Series:
     """Synthetic series of ExperimentSynthetic/data.py semantics, generated shard-by-shard in
     time chunks so that neither the host nor PCIe ever holds the whole (T, d) array."""
 
-    def __init__(self, d, r, T, seed, row0, d_local, robust):
+    def __init__(self, d, r, T, seed, row0, d_local, robust, global_noise=False):
+        # global_noise: a row shard draws the noise of the WHOLE width (the N = 1 stream) and keeps its columns, so that the
+        # series of a sharded run is bit for bit the series of the unsharded one (the stored full-horizon answers then apply to
+        # every N); otherwise a shard has a noise stream of its own (weak scaling: d grows with N)
+        self.d, self.row0, self.global_noise = d, row0, bool(global_noise) and d_local != d
         rng = np.random.default_rng(seed)
         C_true = rng.standard_normal((d, r))
         self.Ct = np.ascontiguousarray(C_true[row0:row0 + d_local].T)
@@ -93,17 +100,20 @@ class Series:
             x = np.cos(2.0 * np.pi * theta * t + x)
             self.X[t - 1] = x
         self.T, self.d_local, self.robust = T, d_local, robust
-        self.noise_seed = seed * 1000 + row0
+        self.noise_seed = seed * 1000 + (0 if self.global_noise else row0)
 
     def chunks(self, chunk=500):
         rng = np.random.default_rng(self.noise_seed)
         sd = np.sqrt(0.1)
         for a in range(0, self.T, chunk):
             b = min(self.T, a + chunk)
+            width = self.d if self.global_noise else self.d_local
             if self.robust:
-                eps = rng.standard_t(3.0, (b - a, self.d_local)).astype(np.float32)
+                eps = rng.standard_t(3.0, (b - a, width)).astype(np.float32)
             else:
-                eps = rng.standard_normal((b - a, self.d_local), dtype=np.float32)
+                eps = rng.standard_normal((b - a, width), dtype=np.float32)
+            if self.global_noise:
+                eps = np.ascontiguousarray(eps[:, self.row0:self.row0 + self.d_local])
             Y = (self.X[a:b] @ self.Ct).astype(np.float32)
             Y += np.float32(sd) * eps
             yield a, Y
@@ -329,6 +339,97 @@ def run_impute_config(seeds=50, n=295_719, d=19, r=10, n_par=3000, variants=(Fal
     return out
 
 
+def _digest(*arrays):
+    import hashlib
+
+    hsh = hashlib.blake2b(digest_size=16)
+    for a in arrays:
+        hsh.update(np.ascontiguousarray(a, dtype=np.float64).tobytes())
+    return hsh.hexdigest()
+
+
+def sharded_parity_vs_fixture(f, path, d, r, T, seed, robust, row0, d_local, world, dist, reset):
+    """In-run parity of a SHARDED run at a size the oracle cannot be re-run at (BASELINE config E: 0.1 s of CPU per timestep):
+    stored oracle answers of the same workload (tests/golden/make_golden_fullsize.py: r-sized state, eta, N and a fixed 64-column
+    sketch S^T C at checkpoints).  Every rank filters to the first two checkpoints; the replicated V, P, mu, eta, N must be
+    BIT-IDENTICAL across the ranks (digests gathered over the rendezvous) and within 1e-5 of the stored answers; the sketch is
+    summed over the ranks' row shards (S[row0 : row0 + d_local]^T C_local) and compared as a whole."""
+    import torch
+
+    g = np.load(path)
+    assert (int(g["d"]), int(g["r"]), int(g["T"]), int(g["seed"]), bool(g["robust"])) == (d, r, T, seed, robust), "fixture is of another workload"
+    S = np.random.default_rng(20240607).standard_normal((d, 64))[row0:row0 + d_local]        # make_golden_fullsize.sketch_matrix
+    cps = [int(k) for k in g["checkpoints"] if int(k) <= T][:2]
+    rel = lambda a, b_: float(np.max(np.abs(np.asarray(a) - np.asarray(b_))) / np.max(np.abs(b_)))
+    worst, identical, k_prev = {}, True, 0
+    reset()
+    for k in cps:
+        f.run(k_prev, k)
+        k_prev = k
+        sdev = f.get_state()
+        digests = [None] * world
+        dist.all_gather_object(digests, _digest(sdev["V"], sdev["P"], sdev["mu"], [sdev["eta"], sdev["N"], sdev["rho"], sdev["lam"]]))
+        identical = identical and len(set(digests)) == 1
+        sk = torch.from_numpy(np.ascontiguousarray(S.T @ sdev["C"]))
+        dist.all_reduce(sk, op=dist.ReduceOp.SUM)
+        p = f"k{k}_"
+        errs = dict(V=rel(sdev["V"], g[p + "V"]), P=rel(sdev["P"], g[p + "P"]), mu=rel(sdev["mu"], g[p + "mu"]), eta=rel(sdev["eta"], g[p + "eta"]),
+                    N=rel(sdev["N"], g[p + "N"]), StC=rel(sk.numpy(), g[p + "StC"]))
+        for name, e in errs.items():
+            worst[name] = max(worst.get(name, 0.0), e)
+    tm = torch.tensor([worst[n] for n in sorted(worst)], dtype=torch.float64)
+    dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+    out = dict(zip(sorted(worst), [float(v) for v in tm]))
+    out.update(checkpoints=cps, ranks=world, replicated_state_bit_identical=bool(identical), against=os.path.relpath(path, ROOT),
+               ok=bool(identical and max(float(v) for v in tm) < 1e-5))
+    return out
+
+
+def sharded_parity_vs_oracle(f, args, series, st0, d, r, T, seed, row0, d_local, world, dist, reset):
+    """Sharded parity at small sizes (rehearsals, tests): every rank runs the oracle on the WHOLE problem -- the series is the
+    concatenation of the shards' series -- and checks its own rows of C and the replicated V, mu, P; worst over the ranks."""
+    import torch
+
+    from oracle import psmf_oracle as O
+    from rpsmf_amd.sharding import shard_rows
+
+    n_cpu = min(args.cpu_steps, T)
+    gn = args.scaling == "strong"
+    parts = [Series(d, r, T, seed, *shard_rows(d, world, q), bool(args.robust), global_noise=gn) for q in range(world)]
+    Yfull = np.hstack([np.vstack([Yc for _, Yc in p_.chunks(chunk=n_cpu)][:1])[:n_cpu] for p_ in parts]).astype(np.float64)
+    st = O.State(C=st0["C"].copy(), V=st0["V"].copy(), mu=st0["mu"].copy(), P=st0["P"].copy(), Q=st0["Q"].copy(), rho=st0["rho"], lam=st0["lam"])
+    st, _, _ = O.run_epoch(st, Yfull, O.Mode(robust=bool(args.robust)), O.RandomWalkDyn(), want_grad=False)
+    reset()
+    f.run(0, n_cpu)
+    sdev = f.get_state()
+    rel = lambda a, b_: float(np.max(np.abs(a - b_)) / np.max(np.abs(b_)))
+    mine = np.array([rel(sdev["C"], st.C[row0:row0 + d_local]), rel(sdev["V"], st.V), rel(sdev["mu"], st.mu), rel(sdev["P"], st.P)])
+    tm = torch.from_numpy(mine)
+    dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+    digests = [None] * world
+    dist.all_gather_object(digests, _digest(sdev["V"], sdev["P"], sdev["mu"]))
+    return dict(steps=n_cpu, ranks=world, C=float(tm[0]), V=float(tm[1]), mu=float(tm[2]), P=float(tm[3]),
+                replicated_state_bit_identical=len(set(digests)) == 1)
+
+
+def exchange_info(world, args, per_rank, geo, r):
+    """config.exchange: None for a plain N = 1 run, else what carried the sum over the row shards and how many ranks it spanned."""
+    c0 = per_rank[0]["comm"]
+    if c0["transport"] is None:
+        return None
+    if geo["engine"] == "block":
+        msgs = {"first_block_gram_bytes": 64 * 64 * 8, "cross_gram_per_block_bytes": 128 * 64 * 8, "blocks_per_pass": -(-args.T // geo["block_steps"]),
+                "where": "bulk stream, one block ahead of its use (off the filter chain's critical path)"}
+    else:
+        msgs = {"per_timestep_bytes": (r + 1) * 8, "where": "between the row sweep and the serial stage of every timestep"}
+    return {"transport": "RCCL all-reduce (ncclDouble, sum)" if c0["transport"] == "rccl" else "host-mediated all-reduce over gloo (rehearsal transport)",
+            "rccl_ranks": c0["ranks"] if c0["transport"] == "rccl" else None,        # ncclCommCount of rank 0's communicator
+            "ranks": [p["comm"]["ranks"] for p in per_rank], "world_size": world,
+            "rank_devices": [{"rank": p["rank"], "hip_device": p["device"], "pci_bus_id": p["pci_bus_id"]} for p in per_rank],
+            "distinct_gpus": len({p["pci_bus_id"] for p in per_rank}), "messages": msgs,
+            "forced_single_rank": bool(os.environ.get("PSMF_FORCE_COLLECTIVE")) and world == 1}
+
+
 def load_pmc(name):
     p = os.path.join(ROOT, "profiles", name)
     return json.load(open(p)) if os.path.exists(p) else None
@@ -360,7 +461,7 @@ def main():
             fp.write(str(os.getpid()))
     row0, d_local = shard_rows(d, world, rank)
     seed = 35833 if args.robust else 35853  # Makefile:55,64 of the reference
-    series = Series(d, r, T, seed, row0, d_local, bool(args.robust))
+    series = Series(d, r, T, seed, row0, d_local, bool(args.robust), global_noise=(args.scaling == "strong"))
     st0 = init_state(d, r, seed)
 
     if args.one_device:
@@ -422,26 +523,14 @@ def main():
         reset()
         f.run(0, n_cpu)
         parity = parity_of(f, st_cpu, n_cpu)
-    elif world > 1 and args.cpu_steps > 0 and d * r <= 1_000_000:
-        # sharded parity (small problems: rehearsals, tests): every rank runs the oracle on the WHOLE problem -- the series is the
-        # concatenation of the shards' series -- and checks its own rows of C and the replicated V, mu, P; worst over the ranks
-        from oracle import psmf_oracle as O
-
-        n_cpu = min(args.cpu_steps, T)
-        parts = [Series(d, r, T, seed, *shard_rows(d, world, q), bool(args.robust)) for q in range(world)]
-        Yfull = np.hstack([np.vstack([Yc for _, Yc in p_.chunks(chunk=n_cpu)][:1])[:n_cpu] for p_ in parts]).astype(np.float64)
-        st = O.State(C=st0["C"].copy(), V=st0["V"].copy(), mu=st0["mu"].copy(), P=st0["P"].copy(), Q=st0["Q"].copy(), rho=st0["rho"], lam=st0["lam"])
-        st, _, _ = O.run_epoch(st, Yfull, O.Mode(robust=bool(args.robust)), O.RandomWalkDyn(), want_grad=False)
-        reset()
-        f.run(0, n_cpu)
-        sdev = f.get_state()
-        rel = lambda a, b_: float(np.max(np.abs(a - b_)) / np.max(np.abs(b_)))
-        mine = np.array([rel(sdev["C"], st.C[row0:row0 + d_local]), rel(sdev["V"], st.V), rel(sdev["mu"], st.mu), rel(sdev["P"], st.P)])
-        import torch
-
-        tm = torch.from_numpy(mine)
-        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
-        parity = dict(steps=n_cpu, ranks=world, C=float(tm[0]), V=float(tm[1]), mu=float(tm[2]), P=float(tm[3]))
+    elif world > 1 and args.cpu_steps > 0:
+        fixture = args.parity_fixture
+        if fixture is None and (d, r, T, args.scaling) == (100_000, 32, 10_000, "strong"):
+            fixture = os.path.join(ROOT, "tests", "golden", f"fullsize_E_{'rpsmf' if args.robust else 'psmf'}.npz")
+        if fixture is not None and os.path.exists(fixture):
+            parity = sharded_parity_vs_fixture(f, fixture, d, r, T, seed, bool(args.robust), row0, d_local, world, dist, reset)
+        elif d * r <= 1_000_000:
+            parity = sharded_parity_vs_oracle(f, args, series, st0, d, r, T, seed, row0, d_local, world, dist, reset)
 
     # ---- untimed pre-warm: the HIP runtime grows its signal / kernel-argument pools the first time a whole pass worth of
     # launches is queued ahead of the GPU (a one-off ~80 ms stall in the second pass, tools/probe_stall.py)
@@ -482,6 +571,16 @@ def main():
     chained = f.filter_kernel_time() if geo_engine_block(f) else (0, 0.0)   # HIP events around the chained filter launches of the timed region
     elapsed = max_over_ranks(elapsed)
     value = args.steps * T / elapsed
+    # ---- what the exchange really was: the communicator as RCCL reports it, which GPU every rank drives, and per rank the time
+    # between consecutive blocks of the chained filter launch (an all-reduce that landed on the critical path shows there)
+    cinfo = f.comm_info()
+    mine = dict(rank=rank, device=local_rank, pci_bus_id=_capi.device_pci_bus_id(local_rank), comm=cinfo,
+                gap_between_blocks_us=insitu["filter_gap_us_mean"] if insitu else None,
+                block_us_in_kernel=insitu["filter_us_mean"] if insitu and insitu["filter_launches"] > 0 else None)
+    per_rank = [mine]
+    if dist is not None:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
 
     # ---- roofline of the dominant kernel, HIP events on the library's stream (psmf_time_kernel)
     es = 4.0 if args.storage == "f32" else 8.0
@@ -508,7 +607,7 @@ def main():
         nb1 = min(B, 64)
         xg_bytes = es * d_local * (r + B + nb1)          # cross-Gram reads C, the current and the next series block
         ap_bytes = 2.0 * es * d_local * (r + B)          # apply reads C, Y_cur and writes C, Y_hat
-        pmc_name = next((n for n in ("r3_pmc_traffic_block_engine.json", "r2_pmc_traffic_block_engine.json", "r1_pmc_traffic_block_engine.json")
+        pmc_name = next((n for n in ("r4_pmc_traffic_block_engine.json", "r3_pmc_traffic_block_engine.json", "r2_pmc_traffic_block_engine.json", "r1_pmc_traffic_block_engine.json")
                          if os.path.exists(os.path.join(ROOT, "profiles", n))), None)
         pmc = load_pmc(pmc_name) if pmc_name else None
         real_hbm = None
@@ -517,7 +616,9 @@ def main():
             # rocprofv3 --pmc passes of this workload (counter collection serialises the kernels; the library then runs
             # one filter launch per block): bytes per block of B timesteps, scaled to the blocks one launch advances
             traffic = pmc["traffic_bytes_per_launch"] * (steps_per_launch / B)
-            traffic_source = f"profiles/{pmc_name} (rocprofv3 --pmc passes of this workload, committed; NOT measured in this run)"
+            traffic_source = (f"profiles/{pmc_name} (rocprofv3 --pmc passes of this workload, committed; NOT measured in this run; counter "
+                              "collection serialises kernels, so those passes ran the per-block schedule -- one filter launch per block, event "
+                              "hand-off -- not the chained launch timed here: same kernels and bytes per block, different launch structure)")
             if "all_kernels_bytes_per_block" in pmc:
                 real_hbm = pmc["all_kernels_bytes_per_block"] * (T / B) / (elapsed / args.steps) / 1e9
         steps_timed = max(1, (insitu["ns_steps"] + insitu["sweep_steps"])) if insitu else 1
@@ -528,6 +629,8 @@ def main():
                  "block_us_in_kernel": t_block_insitu,
                  "one_block_us_hip_events_standalone": t_filter,
                  "gap_between_blocks_us": insitu["filter_gap_us_mean"] if insitu else None,
+                 "gap_between_blocks_us_per_rank": [p["gap_between_blocks_us"] for p in per_rank],
+                 "block_us_in_kernel_per_rank": [p["block_us_in_kernel"] for p in per_rank],
                  "real_hbm_GBps": real_hbm,
                  "traffic_source": traffic_source,
                  # the blocked formulation's own minimum per block of B timesteps: cross-Gram reads C, Y_cur, Y_next; apply reads
@@ -578,8 +681,11 @@ def main():
                                    f"T={T} synthetic Gaussian series, rows sharded over {world} GPU(s)"
                                    + (f" ({args.d} rows per GPU: weak scaling, d = N x {args.d})" if args.scaling == "weak" else ""),
                        "d": d, "d_per_gpu": d_local, "r": r, "T": T, "timesteps_per_pass": T, "store_y_pred": not args.no_y_pred,
-                       "exchange": ("RCCL all-reduce on the bulk stream, 1-rank communicator (PSMF_FORCE_COLLECTIVE)" if os.environ.get("PSMF_FORCE_COLLECTIVE") else None) if world == 1 else ("RCCL all-reduce on the bulk stream" if args.comm == "rccl" else "host-mediated all-reduce over gloo (rehearsal transport)"),
+                       "exchange": exchange_info(world, args, per_rank, geo, r),
                        "us_per_timestep": 1e6 * elapsed / (args.steps * T), "engine": geo["engine"], "geometry": geo},
+            # BASELINE config E as literally stated -- ONE pass of T timesteps from the initial state -- next to `value`, which is
+            # the steady state of carried-state passes (epochs 2, 3, ... of PSMFIter.run)
+            "value_config_E_literal": T / cold_elapsed,
             "cold_pass_steps_per_s": T / cold_elapsed,
             "cold_pass_runs_steps_per_s": [T / c for c in cold_runs],
             "roofline": dict({"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -200,6 +200,13 @@ int psmf_comm_init(psmf_handle h, int nranks, int rank, const void* unique_id);
 typedef int (*psmf_allreduce_fn)(void* ctx, double* buf, int64_t count);
 int psmf_comm_init_host(psmf_handle h, int nranks, int rank, psmf_allreduce_fn fn, void* ctx);
 
+/* What the handle's communicator is: out4[0] = 0 none, 1 RCCL, 2 host-mediated; out4[1] = number of ranks, out4[2] = this rank,
+ * out4[3] = HIP device -- for an RCCL communicator as RCCL itself reports them (ncclCommCount, ncclCommUserRank, ncclCommCuDevice),
+ * so that a benchmark line can state how many ranks the exchange really spanned.  (New; the reference is single-process.) */
+int psmf_comm_info(psmf_handle h, int32_t* out4);
+/* PCI bus id ("0000:c1:00.0") of HIP device `device` into buf (len >= 16): which physical GPU a rank drives. */
+int psmf_device_pci_bus_id(int device, char* buf, int len);
+
 /* ---- measurement ------------------------------------------------------------------------ */
 /* psmf_run bracketed by HIP events on the handle's stream; *ms = elapsed milliseconds. */
 int psmf_run_timed(psmf_handle h, int64_t k_begin, int64_t k_end, float* ms);
@@ -215,7 +222,8 @@ int psmf_geometry(psmf_handle h, int32_t* out7);
 /* Which kernel advances the r x r / coefficient-space state with the handle's present configuration (mode flags, dynamics, the Q
  * last uploaded, schedules, switches): 0 = per-step engine (psmf_sweep_solve + psmf_serial), 1 = psmf_blk_filter (general blocked
  * kernel), 2 = psmf_blk_filter2, 3 = psmf_blk_filter3, 4 = psmf_blk_filter3s, 5 = psmf_blk_filter4, 6 = psmf_blk_filter4s, 7 = psmf_blk_filter5,
- * 8 = psmf_blk_filter6 / psmf_blk_filter6d (every configuration at r <= 16 but the simplified hooks).
+ * 8 = psmf_blk_filter6 (every configuration at r <= 16 but the simplified hooks), 9 = psmf_blk_filter6d (its instantiation with the two
+ * inversions side by side: random walk, Q = q I).  The same function decides what is launched (select_filter_kernel, psmf_capi.hip).
  * (New: diagnostics for tests and bench.py -- the reference has one code path, pypsmf/psmf/psmf.py:90-102.) */
 int psmf_filter_kernel(psmf_handle h);
 /* diagnostics of the blocked engine's r x r inversions since the last reset: out[0] = timesteps inverted by

@@ -78,6 +78,8 @@ SIGNATURES = {
     "psmf_impute_run": (C.c_int, [C.POINTER(PsmfImputeConfig), _dp, _u8p, _u8p, _dp, _dp, _dp, _dp, _dp,
                                   C.c_double, _dp, _dp, _dp, _dp, _dp, _dp, C.POINTER(C.c_int32), C.POINTER(C.c_float)]),
     "psmf_impute_kernel_id": (C.c_int, [C.POINTER(PsmfImputeConfig)]),
+    "psmf_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "psmf_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "psmf_upload_mask": (C.c_int, [C.c_void_p, _u8p, C.c_int64, C.c_int64]),
     "psmf_masked_metrics": (C.c_int, [C.c_void_p, _u8p, C.c_int64, C.c_int64, C.c_double, _dp]),
     "psmf_download_step_scalars": (C.c_int, [C.c_void_p, _dp, C.c_int64, C.c_int64]),
@@ -330,7 +332,7 @@ class DeviceFilter:
         g = (C.c_int32 * 7)()
         self._check(self._lib.psmf_geometry(self._h, g))
         kern = {0: "psmf_sweep_solve", 1: "psmf_blk_filter", 2: "psmf_blk_filter2", 3: "psmf_blk_filter3", 4: "psmf_blk_filter3s",
-                5: "psmf_blk_filter4", 6: "psmf_blk_filter4s", 7: "psmf_blk_filter5", 8: "psmf_blk_filter6"}.get(self._lib.psmf_filter_kernel(self._h), "?")
+                5: "psmf_blk_filter4", 6: "psmf_blk_filter4s", 7: "psmf_blk_filter5", 8: "psmf_blk_filter6", 9: "psmf_blk_filter6d"}.get(self._lib.psmf_filter_kernel(self._h), "?")
         return dict(n_sweep_wg=g[0], rows_per_wg=g[1], row_stride=g[2], lanes_per_row=g[3], graph_chunk=g[4],
                     engine={1: "step", 2: "block"}.get(g[5], g[5]), block_steps=g[6], filter_kernel=kern)
 
@@ -384,6 +386,13 @@ class DeviceFilter:
         buf = C.create_string_buffer(bytes(unique_id), UNIQUE_ID_BYTES)
         self._check(self._lib.psmf_comm_init(self._h, int(nranks), int(rank), buf))
 
+    def comm_info(self):
+        """What the exchanges of this handle run on: transport ("rccl" / "host" / None), ranks, rank and device as the
+        communicator itself reports them (RCCL: ncclCommCount / ncclCommUserRank / ncclCommCuDevice)."""
+        v = (C.c_int32 * 4)()
+        self._check(self._lib.psmf_comm_info(self._h, v))
+        return dict(transport={0: None, 1: "rccl", 2: "host"}[v[0]], ranks=int(v[1]), rank=int(v[2]), device=int(v[3]))
+
     def comm_init_host(self, nranks, rank, allreduce):
         """Host-mediated communicator: `allreduce(vec) -> vec` (numpy float64, same length) is called wherever the sharded
         engine needs its sum over the ranks; it must return the same bits on every rank."""
@@ -410,6 +419,14 @@ def measure_copy_bandwidth(device=0, nbytes=1 << 30, iters=20):
     if rc != OK:
         raise PsmfError("psmf_measure_copy_bandwidth failed: " + lib.psmf_last_error(None).decode())
     return v.value
+
+
+def device_pci_bus_id(device=0):
+    buf = C.create_string_buffer(32)
+    rc = load_library().psmf_device_pci_bus_id(int(device), buf, 32)
+    if rc != OK:
+        raise PsmfError("psmf_device_pci_bus_id failed: " + load_library().psmf_last_error(None).decode())
+    return buf.value.decode()
 
 
 def device_count():

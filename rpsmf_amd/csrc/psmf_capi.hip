@@ -342,41 +342,51 @@ bool blk_simpl_ok(const psmf_filter* h) {
          !h->sp.q_sched;
 }
 
+// The ONE place that decides which kernel advances the coefficient-space state of a block: launch_blk_filter switches on it
+// and psmf_filter_kernel reports it (tests and bench.py quote that name as evidence of what ran).  Values = the codes of
+// psmf_filter_kernel in include/psmf_hip.h.
+enum FilterKernel { FK_STEP = 0, FK_GENERAL = 1, FK_FILTER2 = 2, FK_FILTER3 = 3, FK_FILTER3S = 4, FK_FILTER4 = 5, FK_FILTER4S = 6,
+                    FK_FILTER5 = 7, FK_FILTER6 = 8, FK_FILTER6D = 9 };
+
+FilterKernel select_filter_kernel(const psmf_filter* h) {
+  if (h->engine != 2) return FK_STEP;
+  if (blk_simpl_ok(h)) return FK_FILTER5;
+  const bool dual3 = blk_dual_ok(h) && blk_use_filter3(h);
+  if (!dual3 && blk_seq_ok(h)) return h->cfg.r > 16 ? FK_FILTER4 : FK_FILTER4S;
+  if (blk_small_dual(h)) return FK_FILTER6D;      // random walk, Q = q I at r <= 16: filter6 with the two inversions side by side
+  if (dual3) return h->cfg.r > 16 ? FK_FILTER3 : FK_FILTER3S;
+  if (blk_dual_ok(h)) return FK_FILTER2;
+  return blk_small_ok(h) ? FK_FILTER6 : FK_GENERAL;
+}
+
 void launch_blk_filter(psmf_filter* h, const psmf::BlockParams& b, hipStream_t stream = nullptr) {
   if (!stream) stream = h->stream;
-  if (blk_simpl_ok(h)) {
-    hipLaunchKernelGGL(psmf::psmf_blk_filter5, dim3(1), dim3(psmf::F3_NT), psmf::blk_filter3_lds_bytes(), stream, b);
-    return;
-  }
-  if (!(blk_dual_ok(h) && blk_use_filter3(h)) && blk_seq_ok(h)) {
-    if (h->cfg.r > 16) hipLaunchKernelGGL(psmf::psmf_blk_filter4, dim3(1), dim3(psmf::F3_NT), psmf::blk_filter3_lds_bytes(), stream, b);
-    else hipLaunchKernelGGL(psmf::psmf_blk_filter4s, dim3(1), dim3(psmf::F3_NT), psmf::blk_filter3_lds_bytes(), stream, b);
-    return;
-  }
-  if (blk_small_dual(h)) {        // random walk, Q = q I at r <= 16: filter6 with the two inversions side by side
-    psmf::BlockParams b2 = b;
-    b2.dual6 = 1;
-    hipLaunchKernelGGL(psmf::psmf_blk_filter6d, dim3(1), dim3(psmf::WG), psmf::blk_filter_lds_bytes(), stream, b2);
-    return;
-  }
-  if (blk_dual_ok(h) && blk_use_filter3(h)) {
-    if (h->cfg.r > 16) hipLaunchKernelGGL(psmf::psmf_blk_filter3, dim3(1), dim3(psmf::F3_NT), psmf::blk_filter3_lds_bytes(), stream, b);
-    else hipLaunchKernelGGL(psmf::psmf_blk_filter3s, dim3(1), dim3(psmf::F3_NT), psmf::blk_filter3_lds_bytes(), stream, b);
-    return;
-  }
-  if (blk_dual_ok(h)) {
-    const size_t lds2 = psmf::blk_filter2_lds_bytes();
-    switch (h->geo.rpad) {
-      case 8: hipLaunchKernelGGL(psmf::psmf_blk_filter2<8>, dim3(1), dim3(2 * psmf::WG), lds2, stream, b); break;
-      case 16: hipLaunchKernelGGL(psmf::psmf_blk_filter2<16>, dim3(1), dim3(2 * psmf::WG), lds2, stream, b); break;
-      default: hipLaunchKernelGGL(psmf::psmf_blk_filter2<32>, dim3(1), dim3(2 * psmf::WG), lds2, stream, b); break;
+  const size_t lds3 = psmf::blk_filter3_lds_bytes(), lds = psmf::blk_filter_lds_bytes();
+  switch (select_filter_kernel(h)) {
+    case FK_FILTER5: hipLaunchKernelGGL(psmf::psmf_blk_filter5, dim3(1), dim3(psmf::F3_NT), lds3, stream, b); return;
+    case FK_FILTER4: hipLaunchKernelGGL(psmf::psmf_blk_filter4, dim3(1), dim3(psmf::F3_NT), lds3, stream, b); return;
+    case FK_FILTER4S: hipLaunchKernelGGL(psmf::psmf_blk_filter4s, dim3(1), dim3(psmf::F3_NT), lds3, stream, b); return;
+    case FK_FILTER6D: {
+      psmf::BlockParams b2 = b;
+      b2.dual6 = 1;
+      hipLaunchKernelGGL(psmf::psmf_blk_filter6d, dim3(1), dim3(psmf::WG), lds, stream, b2);
+      return;
     }
-    return;
-  }
-  const size_t lds = psmf::blk_filter_lds_bytes();
-  if (blk_small_ok(h)) {
-    hipLaunchKernelGGL(psmf::psmf_blk_filter6, dim3(1), dim3(psmf::WG), lds, stream, b);
-    return;
+    case FK_FILTER3: hipLaunchKernelGGL(psmf::psmf_blk_filter3, dim3(1), dim3(psmf::F3_NT), lds3, stream, b); return;
+    case FK_FILTER3S: hipLaunchKernelGGL(psmf::psmf_blk_filter3s, dim3(1), dim3(psmf::F3_NT), lds3, stream, b); return;
+    case FK_FILTER2: {
+      const size_t lds2 = psmf::blk_filter2_lds_bytes();
+      switch (h->geo.rpad) {
+        case 8: hipLaunchKernelGGL(psmf::psmf_blk_filter2<8>, dim3(1), dim3(2 * psmf::WG), lds2, stream, b); break;
+        case 16: hipLaunchKernelGGL(psmf::psmf_blk_filter2<16>, dim3(1), dim3(2 * psmf::WG), lds2, stream, b); break;
+        default: hipLaunchKernelGGL(psmf::psmf_blk_filter2<32>, dim3(1), dim3(2 * psmf::WG), lds2, stream, b); break;
+      }
+      return;
+    }
+    case FK_FILTER6: hipLaunchKernelGGL(psmf::psmf_blk_filter6, dim3(1), dim3(psmf::WG), lds, stream, b); return;
+    case FK_GENERAL:
+    case FK_STEP:
+      break;
   }
   switch (h->geo.rpad) {
     case 8: hipLaunchKernelGGL(psmf::psmf_blk_filter<8>, dim3(1), dim3(psmf::WG), lds, stream, b); break;
@@ -1325,13 +1335,7 @@ int psmf_debug_read(psmf_handle h, double* out, int n) {
 
 int psmf_filter_kernel(psmf_handle h) {
   if (!h) return PSMF_ERR_ARG;
-  if (h->engine != 2) return 0;
-  if (blk_simpl_ok(h)) return 7;
-  if (blk_small_dual(h)) return 8;
-  if (blk_dual_ok(h) && blk_use_filter3(h)) return h->cfg.r > 16 ? 3 : 4;
-  if (blk_seq_ok(h)) return h->cfg.r > 16 ? 5 : 6;
-  if (blk_dual_ok(h)) return 2;
-  return blk_small_ok(h) ? 8 : 1;
+  return (int)select_filter_kernel(h);
 }
 
 int psmf_counters(psmf_handle h, int64_t* out8, int reset) {
@@ -1616,6 +1620,26 @@ int psmf_step_host(psmf_handle h, int64_t k, const double* mu_bar, const double*
   if (gf_out) HIP_TRY(h, hipMemcpy(gf_out, h->st->gf, r * sizeof(double), hipMemcpyDeviceToHost));
   if (P_out) HIP_TRY(h, hipMemcpy(P_out, h->st->P, (size_t)r * r * sizeof(double), hipMemcpyDeviceToHost));
   if (Q_out) HIP_TRY(h, hipMemcpy(Q_out, h->st->Q, (size_t)r * r * sizeof(double), hipMemcpyDeviceToHost));
+  return PSMF_OK;
+}
+
+int psmf_comm_info(psmf_handle h, int32_t* out4) {
+  if (!h || !out4) return PSMF_ERR_ARG;
+  out4[0] = h->host_fn ? 2 : (h->comm ? 1 : 0);
+  out4[1] = h->nranks; out4[2] = h->rank; out4[3] = h->cfg.device;
+  if (h->comm) {          // what RCCL itself says about the communicator the exchanges run on
+    int n = -1, rk = -1, dev = -1;
+    NCCL_TRY(h, ncclCommCount(h->comm, &n));
+    NCCL_TRY(h, ncclCommUserRank(h->comm, &rk));
+    NCCL_TRY(h, ncclCommCuDevice(h->comm, &dev));
+    out4[1] = n; out4[2] = rk; out4[3] = dev;
+  }
+  return PSMF_OK;
+}
+
+int psmf_device_pci_bus_id(int device, char* buf, int len) {
+  if (!buf || len < 16) return fail(nullptr, PSMF_ERR_ARG, "psmf_device_pci_bus_id: buffer of at least 16 bytes");
+  if (hipDeviceGetPCIBusId(buf, len, device) != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, PSMF_ERR_HIP, "hipDeviceGetPCIBusId failed"); }
   return PSMF_OK;
 }
 

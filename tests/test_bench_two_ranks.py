@@ -34,6 +34,44 @@ def test_bench_two_ranks_one_gpu(engine, d, r):
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0 and out["config"]["engine"] == engine
     par = out["parity_vs_cpu_oracle"]
     assert par["ranks"] == 2 and max(par["C"], par["V"], par["mu"], par["P"]) < 1e-5, par
+    assert par["replicated_state_bit_identical"] is True
+    # the line says what carried the exchange, how many ranks it spanned and which GPU each rank drove
+    ex = out["config"]["exchange"]
+    assert ex["transport"].startswith("host-mediated") and ex["rccl_ranks"] is None and ex["world_size"] == 2 and ex["ranks"] == [2, 2]
+    assert [p["rank"] for p in ex["rank_devices"]] == [0, 1] and ex["distinct_gpus"] == 1          # --one-device: both ranks on GPU 0
+    assert all(len(p["pci_bus_id"]) >= 7 for p in ex["rank_devices"])
+    if engine == "block":
+        assert ex["messages"]["cross_gram_per_block_bytes"] == 128 * 64 * 8
+        gaps = out["roofline"]["gap_between_blocks_us_per_rank"]
+        assert len(gaps) == 2 and all(g is not None and g >= 0.0 for g in gaps)
+    else:
+        assert ex["messages"]["per_timestep_bytes"] == (r + 1) * 8
+
+
+def test_bench_two_ranks_parity_against_stored_answers(tmp_path):
+    """The in-run parity of a sharded run at BASELINE size cannot re-run the oracle (0.1 s per timestep): bench.py compares with
+    STORED oracle answers of the unsharded workload (tests/golden/fullsize_E_*.npz at d = 100 000; format of
+    tests/golden/make_golden_fullsize.py) -- replicated state bit-identical across ranks, the sketch S^T C summed over the
+    shards.  Rehearsed here with a small fixture made on the spot by the same generator and handed over with --parity-fixture."""
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from golden.make_golden_fullsize import generate
+
+    d, r, T = 8000, 32, 400
+    fx = generate(False, d=d, r=r, T=T, epochs=1, checkpoints=(100, 300), log=lambda *a, **k: None)
+    path = str(tmp_path / "fixture.npz")
+    np.savez_compressed(path, **fx)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rows", str(d),
+           "--latent-rank", str(r), "--timesteps", str(T), "--cpu-steps", "150", "--no-extras", "--comm", "gloo", "--one-device",
+           "--parity-fixture", path]
+    pr = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=dict(os.environ, OMP_NUM_THREADS="4"), cwd=ROOT)
+    assert pr.returncode == 0, pr.stdout[-2000:] + pr.stderr[-3000:]
+    out = json.loads([ln for ln in pr.stdout.splitlines() if ln.startswith("{")][0])
+    par = out["parity_vs_cpu_oracle"]
+    assert par["checkpoints"] == [100, 300] and par["ranks"] == 2 and par["replicated_state_bit_identical"] is True and par["ok"] is True, par
+    assert max(par[k] for k in ("V", "P", "mu", "eta", "N", "StC")) < 1e-5, par
 
 
 def _free_port():
@@ -71,6 +109,9 @@ def test_forced_collective_single_rank_bench_costs_nothing():
         assert pr.returncode == 0, pr.stdout[-2000:] + pr.stderr[-3000:]
         out = json.loads([ln for ln in pr.stdout.splitlines() if ln.startswith("{")][0])
         assert (out["config"]["exchange"] is not None) == forced
+        if forced:          # the communicator as RCCL itself reports it (ncclCommCount)
+            assert out["config"]["exchange"]["rccl_ranks"] == 1 and out["config"]["exchange"]["forced_single_rank"] is True
+        assert out["value_config_E_literal"] == out["cold_pass_steps_per_s"]
         vals[forced] = max(vals.get(forced, 0.0), out["value"])
     assert vals[True] > 0.97 * vals[False], vals
     print("timesteps/s plain vs forced collective:", vals)

@@ -332,7 +332,7 @@ def test_filter6_fourier_and_random_walk_at_size(robust):
         f = c.DeviceFilter(d, r, robust=robust, storage="f32", dyn_kind=nl.device_kind, dyn_flags=nl.device_flags, dyn_terms=nl.device_terms)
         f.upload_series(Y)
         f.set_state(C0, V0, P0, Q, mu0, rho=1.0, lambda0=1.8, theta=theta0 if nl.n_params else None)
-        assert f.geometry()["filter_kernel"] == "psmf_blk_filter6"
+        assert f.geometry()["filter_kernel"] == ("psmf_blk_filter6" if nl.n_params else "psmf_blk_filter6d")
         if nl.n_params:
             f.zero_gradsum()
         f.run(0, T)

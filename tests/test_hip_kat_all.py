@@ -4,7 +4,7 @@
 
 Host: the RNG replay of the input draws (tests/kat_replay.py; hashes asserted against the JSONs' own).  Device: psmf_impute_run
 through rpsmf_amd.impute.impute_batch.  Asserted per repeat: error_predict, error_full (relative) and inside_sig (absolute) to
-1e-9 (S&P 500: 2e-8, tests/kat_replay.py; MLE-SMF: against the reference FUNCTION's outputs on repeats 0 and 1 -- its stored JSONs are
+1e-9 (S&P 500: 1e-6 / 1e-5, tests/kat_replay.py; MLE-SMF: against the reference FUNCTION's outputs on repeats 0 and 1 -- its stored JSONs are
 not what its own source computes, see make_golden.py -- with the JSONs as a 2 % sanity bound), and the kernel that ran -- d = 27: psmf_impute_kernel3<8>, d = 75: psmf_impute_kernel3<20> (rows beyond 64 on wave 1),
 d = 505: psmf_impute_kernel2.  Reference: ExperimentImpute/PSMF.py:138-207, rPSMF.py:190-260, MLESMF.py:135-200, TMF.py:112-160,
 common.py:50-111.
@@ -68,4 +68,4 @@ def test_all_stored_known_answers(ds, pct):
                 assert abs(res["inside"][rep] - ref[rep, 2]) < 1e-9
             assert e1 < 2e-2 and e2 < 2e-2 and e3 < 1e-2, (ds, pct, method, e1, e2, e3)
             continue
-        assert e1 < K.TOL[ds] and e2 < K.TOL[ds] and e3 < 1e-9, (ds, pct, method, e1, e2, e3)
+        assert e1 < K.TOL[ds] and e2 < K.TOL[ds] and e3 < K.TOL_INSIDE[ds], (ds, pct, method, e1, e2, e3)

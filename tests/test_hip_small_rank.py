@@ -161,7 +161,7 @@ def test_small_rank_random_walk_inversions_side_by_side(r, robust):
     mu0 = 0.2 * rng.standard_normal(r)
     st = O.State(C=C0, V=V0, mu=mu0, P=P0, Q=Q, rho=1.0, lam=1.8)
     st, Yp, _ = O.run_epoch(st, Y, O.Mode(robust=robust), O.RandomWalkDyn(), want_grad=False)
-    s, yp = _device(c, nl, d, r, Y, C0, V0, P0, Q, mu0, np.zeros(0), T, robust, FULL)
+    s, yp = _device(c, nl, d, r, Y, C0, V0, P0, Q, mu0, np.zeros(0), T, robust, FULL, want="psmf_blk_filter6d")
     tol = 1e-7 if robust else 1e-9
     for k in ("C", "V", "mu", "P"):
         assert relerr(s[k], getattr(st, k)) < tol, k

@@ -150,10 +150,9 @@ def test_stored_results_all_datasets_methods(ds, method):
                 assert relerr(ep, g[key + "error_predict"][rep]) < 2e-2 and relerr(ef, g[key + "error_full"][rep]) < 2e-2
                 assert abs(ib - g[key + "inside_sig"][rep]) < 1e-2
                 continue
-            # S&P 500 (prices up to 2 049, d = 505): the r x r restatement and the reference's d x d algebra, both float64, part by
-            # up to 1.5e-9 over the 2 518 steps (conditioning of the recursion, not a difference of formula); LondonAir: 1e-13
+            # (tolerances per data set: tests/kat_replay.py -- the S&P 500 recursion is badly conditioned on some draws)
             tol = K.TOL[ds]
             assert relerr(ep, g[key + "error_predict"][rep]) < tol, (ds, method, pct, rep)
             assert relerr(ef, g[key + "error_full"][rep]) < tol, (ds, method, pct, rep)
             if ib is not None:
-                assert abs(ib - g[key + "inside_sig"][rep]) < 1e-9
+                assert abs(ib - g[key + "inside_sig"][rep]) < K.TOL_INSIDE[ds]
