@@ -562,14 +562,24 @@ int enqueue_gram_into(psmf_filter* h, double* Gout, const DevState* wst, const d
   if (h->use_coll) { const int rc = all_reduce_sum(h, Gout, (size_t)r * r, h->stream); if (rc) return rc; }
   return PSMF_OK;
 }
+constexpr int kMGramWG = 256;      // workgroups of the masked Gram (one partial each); r > 48 runs 4 waves per workgroup, else 8
+
+template <typename T>
+void launch_mgram(psmf_filter* h) {
+  const int nt = (h->cfg.r + 15) / 16;
+  const uint8_t* mk = h->mask;
+  switch (nt) {
+    case 1: hipLaunchKernelGGL((psmf::psmf_mgram_mfma<T, 1, 8>), dim3(kMGramWG), dim3(512), 0, h->stream, h->sp, mk, h->gpart); break;
+    case 2: hipLaunchKernelGGL((psmf::psmf_mgram_mfma<T, 2, 8>), dim3(kMGramWG), dim3(512), 0, h->stream, h->sp, mk, h->gpart); break;
+    case 3: hipLaunchKernelGGL((psmf::psmf_mgram_mfma<T, 3, 8>), dim3(kMGramWG), dim3(512), 0, h->stream, h->sp, mk, h->gpart); break;
+    default: hipLaunchKernelGGL((psmf::psmf_mgram_mfma<T, 4, 4>), dim3(kMGramWG), dim3(256), 0, h->stream, h->sp, mk, h->gpart); break;
+  }
+}
+
 int enqueue_masked_gram(psmf_filter* h) {
-  const int r = h->cfg.r, rows = (h->cfg.d_local + kGramWG - 1) / kGramWG;
-  if (h->cfg.storage == PSMF_F64)
-    hipLaunchKernelGGL(psmf::psmf_mgram_partial<double>, dim3(kGramWG), dim3(psmf::WG), 0, h->stream, h->sp, (const uint8_t*)h->mask, rows, h->gpart);
-  else
-    hipLaunchKernelGGL(psmf::psmf_mgram_partial<float>, dim3(kGramWG), dim3(psmf::WG), 0, h->stream, h->sp, (const uint8_t*)h->mask, rows, h->gpart);
-  const int ne = r * r + 1;
-  hipLaunchKernelGGL(psmf::psmf_gram_reduce, dim3((ne + 127) / 128), dim3(128), 0, h->stream, (const double*)h->gpart, (int)kGramWG, ne, h->mg);
+  const int r = h->cfg.r, ne = r * r + 1;
+  if (h->cfg.storage == PSMF_F64) launch_mgram<double>(h); else launch_mgram<float>(h);
+  hipLaunchKernelGGL(psmf::psmf_mgram_reduce, dim3((ne + 63) / 64), dim3(512), 0, h->stream, (const double*)h->gpart, (int)kMGramWG, ne, h->mg);
   if (h->use_coll) {
     const int rc = all_reduce_sum(h, h->mg, (size_t)ne, h->stream);
     if (rc) return rc;
@@ -757,7 +767,7 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
   CREATE_TRY(hipMemset(h->st, 0, sizeof(DevState)));
   CREATE_TRY(hipMalloc(&h->C, (size_t)cfg->d_local * h->geo.rp * h->elem()));
   CREATE_TRY(hipMalloc((void**)&h->partials, (size_t)h->geo.n_sweep_wg * h->geo.ps * sizeof(double)));
-  CREATE_TRY(hipMalloc((void**)&h->gpart, (size_t)kGramWG * (cfg->r * cfg->r + 1) * sizeof(double)));
+  CREATE_TRY(hipMalloc((void**)&h->gpart, (size_t)(cfg->masked ? 256 : kGramWG) * (cfg->r * cfg->r + 1) * sizeof(double)));
   if (cfg->masked) CREATE_TRY(hipMalloc((void**)&h->mg, (size_t)(cfg->r * cfg->r + 2) * sizeof(double)));
   {
     const bool can_block = cfg->r <= psmf::RM / 2 && cfg->dyn_kind != PSMF_DYN_HOST && !cfg->nonuniform_R && !cfg->masked;

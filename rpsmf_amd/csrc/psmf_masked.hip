@@ -3,76 +3,146 @@
 //
 //   e_i   = m_i (y_i - c_i . mu_bar)             rows with m_i = 0 are neither used nor updated; y_hat is stored unmasked
 //   G_m   = sum_i m_i c_i c_i^T                  the mask changes with every step, so neither the algebraically tracked Gram
-//                                                nor time-blocking apply: one masked Gram pass per step (psmf_mgram_partial)
+//                                                nor time-blocking apply: one masked Gram pass per step (psmf_mgram_mfma)
 //   eta   = (rho n_obs + <G_m, P_bar>) / d       divided by d, NOT by the observed count (PSMF.py:77)
 //   kappa_i = m_i / (rho + s)                    =>  P+ = (P_bar^-1 + kappa G_m)^-1,  b = kappa h,  q = kappa ee  (uniform rho)
 //   lambda <- lambda + d                         (d again, rPSMF.py:135)
 //   bands : PSMF  y_hat -+ sig sqrt(N)  (PSMF.py:83-84);  rPSMF  y_hat_i -+ sig sqrt(s m_i + eta)  (rPSMF.py:112,121-123)
 //
-// A step is: psmf_mgram_partial -> psmf_gram_reduce (-> all-reduce of r^2 + 1 doubles) -> psmf_masked_prep (eta, N, w / N, kappa and
+// A step is: psmf_mgram_mfma -> psmf_mgram_reduce (-> all-reduce of r^2 + 1 doubles) -> psmf_masked_prep (eta, N, w / N, kappa and
 // the step's (s, eta) into the history the bands are formed from) -> psmf_sweep_solve with the mask (-> all-reduce of r + 1 doubles)
 // -> psmf_serial.  The metrics of a pass (RMSE of the predictions and of C X over the held-out entries, coverage of the bands:
 // ExperimentImpute/common.py:79-94) are reduced on the device by psmf_masked_metrics_k; nothing d x n travels.
 #pragma once
 #include "psmf_kernels.hip"
+#include "psmf_blk3.hip"      // f64x4, readlane_f64
 
 namespace psmf {
 
-// Masked Gram of this workgroup's rows for the step st->k: gpart[wg][0 .. r*r) = sum m_i c_i c_i^T, gpart[wg][r*r] = sum m_i.
-template <typename T>
-__global__ __launch_bounds__(WG) void psmf_mgram_partial(StepParams p, const uint8_t* __restrict__ mask, int rows_per_wg,
-                                                         double* __restrict__ gpart) {
-  constexpr int TR = 32;   // rows per LDS tile
-  __shared__ double tile[TR][RM + 1];
-  __shared__ double mrow[TR];
-  __shared__ double s4[4];
-  const int tid = threadIdx.x, r = p.r, rp = p.rp, d_local = p.d_local;
+// Masked Gram of the step st->k on the float64 matrix cores: gpart[wg][0 .. r*r) = sum m_i c_i c_i^T over the workgroup's rows,
+// gpart[wg][r*r] = sum m_i.  One WAVE per slab of 16 rows (wave-private LDS image, float64, rows with m_i = 0 stored as zeros, so
+// that one image serves both operands: m^2 = m); the next slab is already in registers while the current one is multiplied
+// (16 row loads in flight per lane); per slab and 16 x 16 output tile four v_mfma_f64_16x16x4_f64 (K = 4 rows each), upper
+// triangle of tiles only.  NT = column tiles (r <= 16 NT), NW = waves per workgroup.  The waves' accumulators are summed in a
+// fixed order through LDS: one partial per workgroup, reduced in fixed order by psmf_mgram_reduce -> deterministic.
+// LDS row stride S == 16 (mod 32) doubles: the two rows a half-wave reads sit 32 banks apart (conflict-free ds_read_b64).
+__host__ __device__ constexpr int mgram_stride(int nt) { return nt == 1 ? 16 : (nt <= 3 ? 48 : 80); }
+
+template <typename T, int NT, int NW>
+__global__ __launch_bounds__(NW * 64) void psmf_mgram_mfma(StepParams p, const uint8_t* __restrict__ mask, double* __restrict__ gpart) {
+  constexpr int S = mgram_stride(NT);
+  constexpr int NTT = NT * (NT + 1) / 2;
+  __shared__ double sZ[NW * 16 * S > NT * NT * 256 ? NW * 16 * S : NT * NT * 256];
+  __shared__ double sCnt[NW];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lk = lane >> 4;
+  const int r = p.r, rp = p.rp, dl = p.d_local;
   const T* __restrict__ C = reinterpret_cast<const T*>(p.C);
-  const uint8_t* __restrict__ mk = mask + (size_t)(p.st->k - p.series_t0) * d_local;
-  constexpr int MU = (RM * RM) / WG;   // 16
-  double acc[MU];
-  int qa[MU], qb[MU];
+  const uint8_t* __restrict__ mk = mask + (size_t)(p.st->k - p.series_t0) * dl;
+  double* slab = sZ + w * 16 * S;
+  for (int idx = lane; idx < 16 * S; idx += 64) slab[idx] = 0.0;        // columns rp .. 16 NT stay zero
+  f64x4 acc[NTT];
 #pragma unroll
-  for (int u = 0; u < MU; ++u) {
-    const int q = tid + u * WG;
-    acc[u] = 0.0;
-    qa[u] = q < r * r ? q / r : -1;
-    qb[u] = q < r * r ? q - (q / r) * r : 0;
-  }
+  for (int t = 0; t < NTT; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
   double cnt = 0.0;
-  const int row_begin = blockIdx.x * rows_per_wg;
-  const int row_end = min(row_begin + rows_per_wg, d_local);
-  for (int base = row_begin; base < row_end; base += TR) {
-    __syncthreads();
-    if (tid < TR) {
-      const int row = base + tid;
-      const double m = (row < row_end && mk[row]) ? 1.0 : 0.0;
-      mrow[tid] = m;
-      cnt += m;
-    }
-    __syncthreads();
-    for (int idx = tid; idx < TR * r; idx += WG) {
-      const int rr = idx / r, c = idx - rr * r;
-      const int row = base + rr;
-      tile[rr][c] = (row < row_end && mrow[rr] != 0.0) ? (double)C[(size_t)row * rp + c] : 0.0;   // m^2 = m: one masked copy serves both factors
-    }
-    __syncthreads();
+  const int nslab = (dl + 15) / 16, stride = gridDim.x * NW;
+  const int cl = lane < rp ? lane : 0;
+  const bool con = lane < rp;
+  int sl = blockIdx.x * NW + w;
+  T v[16];
+  uint8_t m[16];
+  if (sl < nslab) {
 #pragma unroll
-    for (int u = 0; u < MU; ++u) {
-      if (qa[u] >= 0) {
-        double a = acc[u];
-        for (int rr = 0; rr < TR; ++rr) a += tile[rr][qa[u]] * tile[rr][qb[u]];
-        acc[u] = a;
+    for (int rr = 0; rr < 16; ++rr) {
+      const int row = min(sl * 16 + rr, dl - 1);
+      v[rr] = C[(size_t)row * rp + cl];
+      m[rr] = mk[row];
+    }
+  }
+  for (; sl < nslab; sl += stride) {
+    const int row0 = sl * 16;
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+      const bool on = (row0 + rr < dl) && m[rr] != 0;
+      if (con) slab[rr * S + lane] = on ? (double)v[rr] : 0.0;
+      cnt += on ? 1.0 : 0.0;
+    }
+    const int nx = sl + stride;
+    if (nx < nslab) {                       // the next slab's loads fly during this slab's products
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) {
+        const int row = min(nx * 16 + rr, dl - 1);
+        v[rr] = C[(size_t)row * rp + cl];
+        m[rr] = mk[row];
       }
     }
-  }
-  const size_t stride = (size_t)r * r + 1;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the wave's own LDS stores (global loads stay in flight)
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
-  for (int u = 0; u < MU; ++u)
-    if (qa[u] >= 0) gpart[(size_t)blockIdx.x * stride + tid + u * WG] = acc[u];
-  cnt = wave_sum(cnt);                         // only wave 0 holds counts (tid < TR)
-  if (tid == 0) gpart[(size_t)blockIdx.x * stride + (size_t)r * r] = cnt;
-  (void)s4;
+    for (int q = 0; q < 4; ++q) {
+      double a[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) a[t] = slab[(4 * q + lk) * S + 16 * t + lr];
+      int tt = 0;
+#pragma unroll
+      for (int ta = 0; ta < NT; ++ta)
+#pragma unroll
+        for (int tb = ta; tb < NT; ++tb, ++tt) acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ta], a[tb], acc[tt], 0, 0, 0);
+    }
+    __builtin_amdgcn_wave_barrier();        // all lanes have read the image before it is overwritten
+  }
+  // ---- sum of the waves' tiles in wave order (fixed), then the workgroup's partial: both triangles
+  __syncthreads();
+  double* buf = sZ;                           // [tile ta * NT + tb][q][lane]
+  for (int ww = 0; ww < NW; ++ww) {
+    if (w == ww) {
+      int tt = 0;
+#pragma unroll
+      for (int ta = 0; ta < NT; ++ta)
+#pragma unroll
+        for (int tb = ta; tb < NT; ++tb, ++tt)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            double* o = buf + ((ta * NT + tb) * 4 + q) * 64 + lane;
+            *o = (ww == 0 ? 0.0 : *o) + acc[tt][q];
+          }
+    }
+    __syncthreads();
+  }
+  cnt = readlane_f64(cnt, 0);                 // every lane of a wave counted the same rows
+  if (lane == 0) sCnt[w] = cnt;
+  __syncthreads();
+  const size_t gs = (size_t)r * r + 1;
+  double* out = gpart + (size_t)blockIdx.x * gs;
+  for (int idx = tid; idx < r * r; idx += NW * 64) {
+    int i = idx / r, j = idx - i * r;
+    if ((i >> 4) > (j >> 4)) { const int t_ = i; i = j; j = t_; }      // lower tiles: the transposed entry of the upper one
+    const int ii = i & 15, jj = j & 15;
+    out[idx] = buf[(((i >> 4) * NT + (j >> 4)) * 4 + (ii >> 2)) * 64 + (ii & 3) * 16 + jj];
+  }
+  if (tid == 0) {
+    double c = 0.0;
+    for (int ww = 0; ww < NW; ++ww) c += sCnt[ww];
+    out[(size_t)r * r] = c;
+  }
+}
+
+// gpart (n_part rows of ne doubles) -> out[ne], every entry summed in the fixed order of the partials: 512 threads = 64 entries x 8
+// segments of the partial rows (all loads of a thread independent), then the 8 segment sums in order.
+__global__ __launch_bounds__(512) void psmf_mgram_reduce(const double* __restrict__ gpart, int n_part, int ne, double* __restrict__ out) {
+  __shared__ double s8[8][64];
+  const int e = blockIdx.x * 64 + (threadIdx.x & 63), sg = threadIdx.x >> 6;
+  const int per = (n_part + 7) / 8, a0 = sg * per, a1 = min(a0 + per, n_part);
+  double a = 0.0;
+  if (e < ne)
+    for (int w = a0; w < a1; ++w) a += gpart[(size_t)w * ne + e];
+  s8[sg][threadIdx.x & 63] = a;
+  __syncthreads();
+  if (sg == 0 && e < ne) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += s8[q][threadIdx.x];
+    out[e] = t;
+  }
 }
 
 // One workgroup: mg[0 .. r*r) = G_m, mg[r*r] = n_obs (already summed over workgroups and ranks) -> st->G, eta, N, w / N, kappa of

@@ -38,7 +38,20 @@ def golden():
 
 
 def relerr(a, b):
+    """The norm every stated tolerance of this suite is in: max |a - b| / max |b| (error relative to the LARGEST entry of the
+    reference array).  Small entries may be off by more in relative terms: see relerr_elementwise."""
     a = np.asarray(a, dtype=float)
     b = np.asarray(b, dtype=float)
     den = max(float(np.max(np.abs(b))), 1e-300)
     return float(np.max(np.abs(a - b))) / den
+
+
+def relerr_elementwise(a, b, floor=1e-3):
+    """max_ij |a_ij - b_ij| / |b_ij| over the entries with |b_ij| >= floor * max |b| (entries nearer to zero have no meaningful
+    relative error), and the share of the entries that covers.  Reported beside `relerr` at the full sizes."""
+    a = np.asarray(a, dtype=float).reshape(-1)
+    b = np.asarray(b, dtype=float).reshape(-1)
+    big = np.abs(b) >= floor * max(float(np.max(np.abs(b))), 1e-300)
+    if not big.any():
+        return 0.0, 0.0
+    return float(np.max(np.abs(a[big] - b[big]) / np.abs(b[big]))), float(big.mean())
