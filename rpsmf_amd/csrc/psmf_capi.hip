@@ -627,10 +627,10 @@ void compute_geometry(const psmf_config& c, Geometry& g) {
   g.nv = (c.r + g.vec - 1) / g.vec;
   g.rp = g.nv * g.vec;
   g.gs = next_pow2(g.nv);
-  g.nt = sweep_threads();
+  g.nt = c.r > 32 ? 256 : sweep_threads();      // r > 32: the solve block (16 matrix elements per thread) needs a 256-thread kernel's register budget
   g.rpp = g.nt / g.gs;
   g.rpad = next_pow2(c.r < 8 ? 8 : c.r);
-  const size_t solve_lds = c.coef_update ? (size_t)(4 * psmf::RM + 2) * 8 : 0;
+  const size_t solve_lds = c.coef_update ? (size_t)(8 * psmf::RM + 2) * 8 : 0;       // two pivot-row buffers (inversions side by side) + flag
   const size_t red_lds = (size_t)(g.nt / 64) * (g.gs * g.vec + 1) * 8;
   g.sweep_lds = ((solve_lds > red_lds ? solve_lds : red_lds) + 15) & ~(size_t)15;
   int target = c.n_workgroups > 0 ? c.n_workgroups : (g.nt == 512 ? 256 : 512);
@@ -640,6 +640,19 @@ void compute_geometry(const psmf_config& c, Geometry& g) {
   g.rows_per_wg = rows;
   g.n_sweep_wg = (c.d_local + rows - 1) / rows;
   g.ps = c.nonuniform_R ? 2 * (c.r + 1) : c.r + 1;      // partial row: h, ee (+ the weighted b, q)
+}
+
+// StepParams.solve_dual: can the per-step solve block run its two inversions side by side?  (random walk, Q = q I as last uploaded,
+// full filter, uniform R, r <= 32 on the 512-thread sweep, no Q_k schedule: q of the next step is q -- or omega q -- of this one)
+void update_solve_dual(psmf_filter* h) {
+  static const bool off = Switches::off("PSMF_STEP_DUAL");
+  const psmf_config& c = h->cfg;
+  const int v = (!off && h->engine == 1 && h->q_iso && c.dyn_kind == PSMF_DYN_RANDOM_WALK && c.coef_update && c.pbar_predict && !c.nonuniform_R &&
+                 c.r <= 32 && h->geo.nt == 512 && !h->sp.q_sched) ? 1 : 0;
+  if (v != h->sp.solve_dual) {
+    h->sp.solve_dual = v;
+    destroy_graph(h);        // the captured launches carry the old parameter block
+  }
 }
 
 int set_device(psmf_handle h) {
@@ -990,6 +1003,7 @@ int psmf_set_state(psmf_handle h, const double* C, const double* V, const double
       for (int c = 0; c < r; ++c)
         if (Q[i * r + c] != (i == c ? Q[0] : 0.0)) { iso = false; break; }
     h->q_iso = iso;
+    update_solve_dual(h);
   }
   if (mu) HIP_TRY(h, hipMemcpy(h->st->mu, mu, r * sizeof(double), hipMemcpyHostToDevice));
   if (theta && h->cfg.n_theta > 0)
@@ -1592,6 +1606,7 @@ int psmf_set_schedules(psmf_handle h, const double* rho_k, const double* q_k, in
     if (rho_k) h->sp.rho_sched = h->sched;
     if (q_k) h->sp.q_sched = h->sched + n + 1;
   }
+  update_solve_dual(h);
   destroy_graph(h);      // the graph's kernel nodes carry StepParams by value
   { const int zero = 0; HIP_TRY(h, hipMemcpy(&h->st->ns_valid, &zero, sizeof(int), hipMemcpyHostToDevice)); }   // another filter kernel may run next: no carried register dump
   h->need_prep = true;

@@ -35,7 +35,8 @@ struct DevState {
   double s_done, eta_done, N_done;  // s, eta, N of the last finished step
   long long k;            // number of finished steps = 0-based series index of the current step
   int err;                // != 0: numeric failure (singular system) at step err
-  int ns_valid;           // != 0: Lbar / XpX / XpY describe the current state; 3: so does the f3_* dump (cleared by every host state upload)
+  int ns_valid;           // != 0: Lbar / XpX / XpY describe the current state; 3: so does the f3_* dump (cleared by every host state upload);
+                          // 7: per-step engine with the inversions side by side (StepParams.solve_dual): Lbar = Pbar^-1 of the NEXT step, XpY = W
   // filter3 (psmf_blk3.hip): the r x r state between the blocks of a run, exactly as the waves hold it in registers
   // ([register][lane]: coalesced 512-byte rows), valid while ns_valid == 3.  The row-major V / P / G / Lbar / XpX / XpY
   // above are written by the LAST block of a run only (BlockParams.last).
@@ -76,6 +77,11 @@ struct StepParams {
   double rho_mean;
   // masked filter (cfg.masked, psmf_masked.hip): T_cap x d_local observation mask, time-major like Y (1 = observed); nullptr = all observed
   const uint8_t* mask;
+  // per-step engine, random walk with Q = q I (r <= 32, 512-thread sweep): the two r x r inversions of a step side by side on the two
+  // halves of the solve block -- P+ = M^-1, M = Lbar + kappa G, and W = (M / beta + I / q)^-1, from which the serial stage forms
+  // Lbar' = Pbar'^-1 = (I / q - W / q^2) / omega for the next step (the Woodbury form of filter3): ONE sweep on
+  // the path of a step instead of two.  DevState.Lbar / XpY carry Lbar / W while ns_valid == 7.
+  int solve_dual;
   int external_reduce;  // 1: partial sums were reduced into st->red (multi-GPU)
   int use_ns;           // 1: Newton-Schulz refinement of the r x r inverses (f64 MFMA), sweep as fallback
   int ns_predict;       // 1: filter3 starts the iteration from the rank-2 downdated, kappa-rescaled previous inverse

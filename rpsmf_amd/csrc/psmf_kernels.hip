@@ -41,7 +41,7 @@ template <> struct VecOf<double> { typedef double __attribute__((ext_vector_type
 
 // start of a run: step counter.  The numeric-error flag is NOT cleared here: runs may be queued back to back without a
 // sync in between, and a failure in an earlier one must still be reported by the next psmf_sync (cleared by psmf_set_state).
-__global__ void psmf_prepare_k(DevState* st, long long k) { st->k = k; }
+__global__ void psmf_prepare_k(DevState* st, long long k) { st->k = k; if (st->ns_valid == 7) st->ns_valid = 0; }   // (7: the per-step engine's carried Lbar -- a new run re-derives it)
 // end of a run: the numeric-error flag to mapped host memory (system-scope store)
 __global__ void psmf_publish_err_k(const DevState* st, int* host_flag) { __hip_atomic_store(host_flag, st->err, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 
@@ -218,8 +218,78 @@ __device__ __forceinline__ void solve_block_t(const StepParams& p, double* sm) {
   if (tid == 0 && *errflag && st->err == 0) st->err = (int)(st->k + 1);
 }
 
+// The same solve with the two inversions side by side (StepParams.solve_dual): 512 threads, half X (threads 0..255) sweeps
+// M = Lbar + kappa G -> P+, half Y sweeps M / beta + I / q -> W, in lockstep (shared barriers, a pivot-row buffer each).  Lbar =
+// Pbar^-1 comes from the previous step's W (serial stage); the first step of a run has none: half X then does the sequential
+// solve and a third sweep for W, half Y retires.  sm: 8 RM doubles of row buffers + the error flag.
+template <int RPAD>
+__device__ __forceinline__ void solve_block_dual_t(const StepParams& p, double* sm) {
+  constexpr int RG = WG / RPAD;
+  constexpr int M = (RPAD * RPAD) / WG > 0 ? (RPAD * RPAD) / WG : 1;
+  DevState* st = p.st;
+  const int r = p.r, tid = threadIdx.x, half = tid >> 8, t = tid & (WG - 1), c = t % RPAD, rg = t / RPAD;
+  const int r2 = r + (r & 1);
+  double* rowbuf = sm + half * 4 * RM;
+  int* errflag = reinterpret_cast<int*>(sm + 8 * RM);
+  const bool carried = st->ns_valid == 7;             // uniform
+  if (!carried && half == 1) return;                  // (barriers count the live waves)
+  if (tid == 0) *errflag = 0;
+  const double kappa = st->kappa, iq = 1.0 / st->Q[0], ib = p.robust ? 1.0 / p.beta : 1.0;
+  double A[M], Gk[M];
+  bool in[M], pad[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const int i = rg + m * RG;
+    in[m] = (i < r && c < r);
+    pad[m] = (i == c && i >= r && i < r2);
+    Gk[m] = in[m] ? kappa * st->G[i * r + c] : 0.0;
+  }
+  if (carried) {
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const int i = rg + m * RG;
+      const double mv = in[m] ? 0.5 * (st->Lbar[i * r + c] + st->Lbar[c * r + i]) + Gk[m] : 0.0;
+      A[m] = in[m] ? (half == 0 ? mv : mv * ib + (i == c ? iq : 0.0)) : (pad[m] ? 1.0 : 0.0);
+    }
+    sweep_all<RPAD>(A, r2, c, rg, rowbuf, errflag);
+    double* dst = half == 0 ? st->Pplus : st->XpY;
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+      if (in[m]) dst[(rg + m * RG) * r + c] = -A[m];
+  } else {
+    double Mv[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const int i = rg + m * RG;
+      A[m] = in[m] ? 0.5 * (st->Pbar[i * r + c] + st->Pbar[c * r + i]) : (pad[m] ? 1.0 : 0.0);
+    }
+    sweep_all<RPAD>(A, r2, c, rg, rowbuf, errflag);        // A = -Pbar^-1
+#pragma unroll
+    for (int m = 0; m < M; ++m) { Mv[m] = in[m] ? Gk[m] - A[m] : (pad[m] ? 1.0 : 0.0); A[m] = Mv[m]; }
+    sweep_all<RPAD>(A, r2, c, rg, rowbuf, errflag);        // A = -P+
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const int i = rg + m * RG;
+      if (in[m]) st->Pplus[i * r + c] = -A[m];
+      A[m] = in[m] ? Mv[m] * ib + (i == c ? iq : 0.0) : (pad[m] ? 1.0 : 0.0);
+    }
+    sweep_all<RPAD>(A, r2, c, rg, rowbuf, errflag);        // A = -W
+#pragma unroll
+    for (int m = 0; m < M; ++m)
+      if (in[m]) st->XpY[(rg + m * RG) * r + c] = -A[m];
+  }
+  if (t == 0 && *errflag && st->err == 0) st->err = (int)(st->k + 1);
+}
+
 __device__ __forceinline__ void solve_block(const StepParams& p, double* sm) {
   const int r = p.r;
+  if (p.solve_dual) {          // (host: r <= 32, 512 threads)
+    if (r <= 8) solve_block_dual_t<8>(p, sm);
+    else if (r <= 16) solve_block_dual_t<16>(p, sm);
+    else solve_block_dual_t<32>(p, sm);
+    return;
+  }
+  if (blockDim.x > WG && threadIdx.x >= WG) return;   // the sequential solve uses 4 waves; surplus waves retire (barriers count live waves)
   if (r <= 8) solve_block_t<8>(p, sm);
   else if (r <= 16) solve_block_t<16>(p, sm);
   else if (r <= 32) solve_block_t<32>(p, sm);
@@ -243,7 +313,8 @@ __global__ __launch_bounds__(NT) void psmf_sweep_solve(StepParams p) {
   // block 0 runs the r x r solve (dispatched first: it is the longest block)
   const int has_solve = p.coef_update;
   if (has_solve && blockIdx.x == 0) {
-    if (NT > WG && threadIdx.x >= WG) return;   // the solve uses 4 waves; surplus waves retire (barriers count live waves)
+    // (raising the solve waves' issue priority on the CU they share with a row-sweep workgroup was measured neutral: the block
+    //  is a chain of LDS exchanges and barriers, not short of issue slots)
     solve_block(p, sm);
     return;
   }
@@ -393,8 +464,10 @@ __global__ __launch_bounds__(NT) void psmf_sweep_solve(StepParams p) {
 // barrier (the stage is latency-bound: what matters is the number of dependent round trips).
 // ------------------------------------------------------------------------------------------
 constexpr int SWG = 1024;
-// r > 16: the worker threads keep 4 matrices x (4..16) elements in registers -- 8 waves (256 VGPRs each) instead of 16 (128: spills)
-__host__ __device__ constexpr int serial_threads(int rpad) { return rpad >= 32 ? 512 : SWG; }
+// r > 16: the worker threads keep 4 matrices x (4..16) elements in registers -- 8 waves (256 VGPRs each) instead of 16 (128: spills);
+// r > 32 (RPAD = 64: 16 elements of each matrix per thread): the 4 worker waves alone, a whole SIMD's register file each (with
+// 512 threads the stage spilled 196 registers to scratch and took 33 us per timestep, profiles/r4_step_engine.txt)
+__host__ __device__ constexpr int serial_threads(int rpad) { return rpad >= 64 ? WG : (rpad >= 32 ? 512 : SWG); }
 
 template <int RPAD>
 __device__ __forceinline__ void col_reduce(double partial, double* s_red, double* s_out) {
@@ -466,6 +539,16 @@ __device__ __forceinline__ void serial_body(const StepParams& p, const int first
     Qv[m] = val[m] ? lq : 0.0;
     Pv[m] = val[m] ? 0.5 * (lp + lt) : 0.0;
   }
+  // inversions side by side (solve_dual): W of this step -> Lbar of the next (written with the r x r updates below)
+  const bool dual = p.solve_dual && !first;
+  double Wv[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const int idx = val[m] ? ii[m] * r + j : 0, idt = val[m] ? j * r + ii[m] : 0;
+    const double lw = st->XpY[idx], lwt = st->XpY[idt];
+    Wv[m] = (dual && val[m]) ? 0.5 * (lw + lwt) : 0.0;
+  }
+  const double q_old = st->Q[0];
   double rho = st->rho, lam = st->lam;
   const double N0 = st->N, kappa0 = st->kappa, s0 = st->s, eta0 = st->eta;
   const long long k0 = st->k;       // read once (thread 0 rewrites it below)
@@ -597,6 +680,10 @@ __device__ __forceinline__ void serial_body(const StepParams& p, const int first
           st->G[idx] = Gv[m];
         }
         if (qscale != 1.0) { Qv[m] *= qscale; st->Q[idx] = Qv[m]; }
+        if (dual) {      // Pbar'^-1 = (I / q - W / q^2) / omega  (Pbar' = omega (beta P+ + q I); non-robust: omega = beta = 1)
+          const double iq = 1.0 / q_old;
+          st->Lbar[idx] = ((ii[m] == j ? iq : 0.0) - Wv[m] * iq * iq) / omega;
+        }
       }
     }
     knext = k0 + 1;
@@ -624,7 +711,7 @@ __device__ __forceinline__ void serial_body(const StepParams& p, const int first
     }
     if (tid == 0) {
       st->k = knext;
-      st->ns_valid = 0;
+      st->ns_valid = dual ? 7 : 0;
       st->rho = rho;
       st->lam = lam;
       st->phi = phi;

@@ -133,8 +133,14 @@ __global__ __launch_bounds__(512) void psmf_mgram_reduce(const double* __restric
   const int e = blockIdx.x * 64 + (threadIdx.x & 63), sg = threadIdx.x >> 6;
   const int per = (n_part + 7) / 8, a0 = sg * per, a1 = min(a0 + per, n_part);
   double a = 0.0;
-  if (e < ne)
-    for (int w = a0; w < a1; ++w) a += gpart[(size_t)w * ne + e];
+  const int ec = min(e, ne - 1);
+  for (int w0 = a0; w0 < a1; w0 += 8) {        // 8 independent loads in flight (clamped index, masked value), summed in order
+    double v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = gpart[(size_t)min(w0 + q, a1 - 1) * ne + ec];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) a += (w0 + q < a1) ? v[q] : 0.0;
+  }
   s8[sg][threadIdx.x & 63] = a;
   __syncthreads();
   if (sg == 0 && e < ne) {
