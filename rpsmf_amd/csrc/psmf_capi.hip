@@ -630,7 +630,7 @@ void compute_geometry(const psmf_config& c, Geometry& g) {
   g.nt = c.r > 32 ? 256 : sweep_threads();      // r > 32: the solve block (16 matrix elements per thread) needs a 256-thread kernel's register budget
   g.rpp = g.nt / g.gs;
   g.rpad = next_pow2(c.r < 8 ? 8 : c.r);
-  const size_t solve_lds = c.coef_update ? (size_t)(8 * psmf::RM + 2) * 8 : 0;       // two pivot-row buffers (inversions side by side) + flag
+  const size_t solve_lds = c.coef_update ? (size_t)(4 * psmf::RM + 2) * 8 : 0;
   const size_t red_lds = (size_t)(g.nt / 64) * (g.gs * g.vec + 1) * 8;
   g.sweep_lds = ((solve_lds > red_lds ? solve_lds : red_lds) + 15) & ~(size_t)15;
   int target = c.n_workgroups > 0 ? c.n_workgroups : (g.nt == 512 ? 256 : 512);
@@ -648,7 +648,7 @@ void update_solve_dual(psmf_filter* h) {
   static const bool off = Switches::off("PSMF_STEP_DUAL");
   const psmf_config& c = h->cfg;
   const int v = (!off && h->engine == 1 && h->q_iso && c.dyn_kind == PSMF_DYN_RANDOM_WALK && c.coef_update && c.pbar_predict && !c.nonuniform_R &&
-                 c.r <= 32 && h->geo.nt == 512 && !h->sp.q_sched) ? 1 : 0;
+                 c.r <= 32 && !h->sp.solve_lds && !h->sp.q_sched) ? 1 : 0;
   if (v != h->sp.solve_dual) {
     h->sp.solve_dual = v;
     destroy_graph(h);        // the captured launches carry the old parameter block
@@ -916,6 +916,7 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
   sp.recursive = cfg->recursive; sp.update_every = cfg->update_every > 0 ? cfg->update_every : 1;
   sp.track_g = ((cfg->eta_full || cfg->coef_update) && !cfg->masked) ? 1 : 0;     // masked: G is this step's masked Gram, recomputed every step
   sp.mask = nullptr;
+  sp.solve_lds = Switches::off("PSMF_STEP_WAVE_SOLVE") ? 1 : 0;
   sp.external_reduce = 0;
   sp.use_ns = (getenv("PSMF_NS") && atoi(getenv("PSMF_NS")) == 0) ? 0 : 1;
   sp.ns_predict = getenv("PSMF_NS_PREDICT") ? atoi(getenv("PSMF_NS_PREDICT")) : 7;      // bits: 1 a / b (phase F), 2 core (wave 7), 4 applied

@@ -77,11 +77,12 @@ struct StepParams {
   double rho_mean;
   // masked filter (cfg.masked, psmf_masked.hip): T_cap x d_local observation mask, time-major like Y (1 = observed); nullptr = all observed
   const uint8_t* mask;
-  // per-step engine, random walk with Q = q I (r <= 32, 512-thread sweep): the two r x r inversions of a step side by side on the two
-  // halves of the solve block -- P+ = M^-1, M = Lbar + kappa G, and W = (M / beta + I / q)^-1, from which the serial stage forms
+  // per-step engine, random walk with Q = q I (r <= 32): the two r x r inversions of a step side by side on two waves
+  // of the solve block -- P+ = M^-1, M = Lbar + kappa G, and W = (M / beta + I / q)^-1, from which the serial stage forms
   // Lbar' = Pbar'^-1 = (I / q - W / q^2) / omega for the next step (the Woodbury form of filter3): ONE sweep on
   // the path of a step instead of two.  DevState.Lbar / XpY carry Lbar / W while ns_valid == 7.
   int solve_dual;
+  int solve_lds;        // 1: the LDS-and-barrier sweeps of round 1 for every r (PSMF_STEP_WAVE_SOLVE=0); default: wave-local sweeps for r <= 32
   int external_reduce;  // 1: partial sums were reduced into st->red (multi-GPU)
   int use_ns;           // 1: Newton-Schulz refinement of the r x r inverses (f64 MFMA), sweep as fallback
   int ns_predict;       // 1: filter3 starts the iteration from the rank-2 downdated, kappa-rescaled previous inverse

@@ -218,78 +218,17 @@ __device__ __forceinline__ void solve_block_t(const StepParams& p, double* sm) {
   if (tid == 0 && *errflag && st->err == 0) st->err = (int)(st->k + 1);
 }
 
-// The same solve with the two inversions side by side (StepParams.solve_dual): 512 threads, half X (threads 0..255) sweeps
-// M = Lbar + kappa G -> P+, half Y sweeps M / beta + I / q -> W, in lockstep (shared barriers, a pivot-row buffer each).  Lbar =
-// Pbar^-1 comes from the previous step's W (serial stage); the first step of a run has none: half X then does the sequential
-// solve and a third sweep for W, half Y retires.  sm: 8 RM doubles of row buffers + the error flag.
-template <int RPAD>
-__device__ __forceinline__ void solve_block_dual_t(const StepParams& p, double* sm) {
-  constexpr int RG = WG / RPAD;
-  constexpr int M = (RPAD * RPAD) / WG > 0 ? (RPAD * RPAD) / WG : 1;
-  DevState* st = p.st;
-  const int r = p.r, tid = threadIdx.x, half = tid >> 8, t = tid & (WG - 1), c = t % RPAD, rg = t / RPAD;
-  const int r2 = r + (r & 1);
-  double* rowbuf = sm + half * 4 * RM;
-  int* errflag = reinterpret_cast<int*>(sm + 8 * RM);
-  const bool carried = st->ns_valid == 7;             // uniform
-  if (!carried && half == 1) return;                  // (barriers count the live waves)
-  if (tid == 0) *errflag = 0;
-  const double kappa = st->kappa, iq = 1.0 / st->Q[0], ib = p.robust ? 1.0 / p.beta : 1.0;
-  double A[M], Gk[M];
-  bool in[M], pad[M];
-#pragma unroll
-  for (int m = 0; m < M; ++m) {
-    const int i = rg + m * RG;
-    in[m] = (i < r && c < r);
-    pad[m] = (i == c && i >= r && i < r2);
-    Gk[m] = in[m] ? kappa * st->G[i * r + c] : 0.0;
-  }
-  if (carried) {
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-      const int i = rg + m * RG;
-      const double mv = in[m] ? 0.5 * (st->Lbar[i * r + c] + st->Lbar[c * r + i]) + Gk[m] : 0.0;
-      A[m] = in[m] ? (half == 0 ? mv : mv * ib + (i == c ? iq : 0.0)) : (pad[m] ? 1.0 : 0.0);
-    }
-    sweep_all<RPAD>(A, r2, c, rg, rowbuf, errflag);
-    double* dst = half == 0 ? st->Pplus : st->XpY;
-#pragma unroll
-    for (int m = 0; m < M; ++m)
-      if (in[m]) dst[(rg + m * RG) * r + c] = -A[m];
-  } else {
-    double Mv[M];
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-      const int i = rg + m * RG;
-      A[m] = in[m] ? 0.5 * (st->Pbar[i * r + c] + st->Pbar[c * r + i]) : (pad[m] ? 1.0 : 0.0);
-    }
-    sweep_all<RPAD>(A, r2, c, rg, rowbuf, errflag);        // A = -Pbar^-1
-#pragma unroll
-    for (int m = 0; m < M; ++m) { Mv[m] = in[m] ? Gk[m] - A[m] : (pad[m] ? 1.0 : 0.0); A[m] = Mv[m]; }
-    sweep_all<RPAD>(A, r2, c, rg, rowbuf, errflag);        // A = -P+
-#pragma unroll
-    for (int m = 0; m < M; ++m) {
-      const int i = rg + m * RG;
-      if (in[m]) st->Pplus[i * r + c] = -A[m];
-      A[m] = in[m] ? Mv[m] * ib + (i == c ? iq : 0.0) : (pad[m] ? 1.0 : 0.0);
-    }
-    sweep_all<RPAD>(A, r2, c, rg, rowbuf, errflag);        // A = -W
-#pragma unroll
-    for (int m = 0; m < M; ++m)
-      if (in[m]) st->XpY[(rg + m * RG) * r + c] = -A[m];
-  }
-  if (t == 0 && *errflag && st->err == 0) st->err = (int)(st->k + 1);
-}
+// r <= 32: wave-local sweeps on the matrix cores, no LDS, no barrier -- and, for the random walk with Q = q I, the two inversions
+// side by side on two waves (psmf_wave16.hip: solve_block_wave, defined after the helpers it needs; same translation unit)
+__device__ void solve_block_wave(const StepParams& p);
 
 __device__ __forceinline__ void solve_block(const StepParams& p, double* sm) {
   const int r = p.r;
-  if (p.solve_dual) {          // (host: r <= 32, 512 threads)
-    if (r <= 8) solve_block_dual_t<8>(p, sm);
-    else if (r <= 16) solve_block_dual_t<16>(p, sm);
-    else solve_block_dual_t<32>(p, sm);
+  if (r <= 32 && !p.solve_lds) {
+    solve_block_wave(p);
     return;
   }
-  if (blockDim.x > WG && threadIdx.x >= WG) return;   // the sequential solve uses 4 waves; surplus waves retire (barriers count live waves)
+  if (blockDim.x > WG && threadIdx.x >= WG) return;   // the LDS sweep uses 4 waves; surplus waves retire (barriers count live waves)
   if (r <= 8) solve_block_t<8>(p, sm);
   else if (r <= 16) solve_block_t<16>(p, sm);
   else if (r <= 32) solve_block_t<32>(p, sm);
