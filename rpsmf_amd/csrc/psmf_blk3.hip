@@ -53,9 +53,7 @@ __device__ __forceinline__ double row_sum_f64_dpp(double v) {
   return v;
 }
 
-__device__ __forceinline__ double readlane_f64(double v, const int lane) {
-  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
-}
+// (readlane_f64: psmf_ns.hip)
 
 // sum over the 64 lanes, float64, fixed order; result uniform
 __device__ __forceinline__ double wave_sum_f64_dpp(double v) {

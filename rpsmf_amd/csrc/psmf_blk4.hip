@@ -44,13 +44,57 @@ struct F4Lds {
     else last_ = w_ * w_ < L.nrm[10];             /* one more iteration is the last: no check needed */     \
   } while (0)
 
-// The direct symmetric sweep of ONE 32 x 32 image (in place, A <- A^-1) by the four VECTOR waves -- one per SIMD, so that a pivot
-// round costs what it costs in the one-group kernels (filter3's fallback sweeps two images on all eight waves: two waves per
-// SIMD share the arithmetic of every round, and here only one matrix is inverted at a time), and waves with few live registers:
-// inlined into the inversion programs (~200 live registers each) the sweep's temporaries would be spilled inside its pivot loop.
-// Waves 0-3 keep the barrier count.  Called by all 512 threads at the same point; the image was published before the barrier
-// that precedes it.
+// The direct symmetric sweep of ONE 32 x 32 image (in place, A <- A^-1).  Round 4: by ONE vector wave (wave 4), wave-local on the
+// matrix cores (wave_sweep_tiles, psmf_ns.hip: the image as 2 x 2 tiles of 16 x 16 in its registers, no LDS exchange, no barrier
+// inside) -- where P ~ q both inversions of every step end up here, and a pivot round of the LDS-and-barrier sweep that the four
+// vector waves ran before cost 1 150 cycles against ~450.  (PSMF_F4_WAVE_SWEEP=0 at build time: that sweep, kept for A/B runs.)
+// Called by all 512 threads at the same point; the image was published before the barrier that precedes it.
+#ifndef PSMF_F4_WAVE_SWEEP
+#define PSMF_F4_WAVE_SWEEP 1
+#endif
 __device__ __forceinline__ void f4_sweep_image(const F3Lds& L, double* im, const int r2, const int tid) {
+#if PSMF_F4_WAVE_SWEEP
+  if ((tid >> 6) == 4) {
+    const int lane = tid & 63, lk = lane >> 4, lr = lane & 15;
+    bool bad = false;
+    if (r2 <= 16) {
+      double A[1][1][4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = lk + 4 * q;
+        A[0][0][q] = (i < r2 && lr < r2) ? im[i * F3_S + lr] : (i == lr ? 1.0 : 0.0);
+      }
+      wave_sweep_tiles<1>(A, r2, lk, lr, bad);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int i = lk + 4 * q;
+        if (i < r2 && lr < r2) im[i * F3_S + lr] = -A[0][0][q];
+      }
+    } else {
+      double A[2][2][4];
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int i = 16 * ti + lk + 4 * q, c = 16 * tj + lr;
+            A[ti][tj][q] = (i < r2 && c < r2) ? im[i * F3_S + c] : (i == c ? 1.0 : 0.0);
+          }
+      wave_sweep_tiles<2>(A, r2, lk, lr, bad);
+#pragma unroll
+      for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int i = 16 * ti + lk + 4 * q, c = 16 * tj + lr;
+            if (i < r2 && c < r2) im[i * F3_S + c] = -A[ti][tj][q];
+          }
+    }
+    if (__any((int)bad) && lane == 0) *L.errflag = 1;
+  }
+#else
   if (tid >= WG) {
     const int lt = tid - WG, c32 = lt & 31, rg = lt >> 5;
     double A1[4];
@@ -66,6 +110,7 @@ __device__ __forceinline__ void f4_sweep_image(const F3Lds& L, double* im, const
     __syncthreads();                                   // sweep_all: one barrier before the pivot loop, one per 2 x 2 pivot
     for (int kk = 0; kk < r2; kk += 2) __syncthreads();
   }
+#endif
   __syncthreads();
 }
 

@@ -76,66 +76,7 @@ __device__ __forceinline__ void wave_sweep16m(double (&A)[4], const int r2, cons
   }
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// The same symmetric sweep for matrices up to 32 x 32 held by ONE wave as NT x NT tiles of 16 x 16 in the MFMA output layout
-// (tile (ti, tj), lane l: column 16 tj + (l & 15), rows 16 ti + (l >> 4) + 4 q):  A <- -A^-1 of the leading r2 x r2 block (r2 even;
-// identity padding beyond r), 2 x 2 SPD block pivots, no LDS, no barrier.  A round pivots on rows k, k + 1 of tile row tp = k >> 4:
-// they sit in register kq = (k & 15) >> 2 of the lanes lk = k & 3, (k + 1) & 3 of the tiles (tp, 0 .. NT) -- which is where the A
-// operand of the update of tile ROW ti wants the pivot columns' entries 16 ti .. 16 ti + 15 (by symmetry the pivot rows' entries in
-// tile (tp, ti)); the B operand of tile COLUMN tj is -Ki [u; w]^T over the columns of tile tj (+Ki at the pivot columns, whose C
-// input is zeroed), formed from u_j, w_j that one v_permlane16_swap pair brings into both rows.  NT^2 independent MFMAs per round
-// (pipelined), then the pivot rows are overwritten in place.  Used where the LDS-and-barrier sweep of psmf_kernels.hip (one
-// publish / barrier / read exchange per round, ~700 cycles alone and ~1400 on a CU shared with a streaming workgroup) sat on a
-// step's critical path: the solve block of the per-step engine (r <= 32).
-// ------------------------------------------------------------------------------------------------------------
-template <int NT>
-__device__ __forceinline__ void wave_sweep_tiles(double (&A)[NT][NT][4], const int r2, const int lk, const int lr, bool& bad) {
-#pragma unroll
-  for (int k = 0; k < 16 * NT; k += 2) {
-    if (k < r2) {                                  // uniform
-      const int tp = k >> 4, kl = k & 15, kq = kl >> 2, b0 = (kl & 3) << 4, b1 = b0 + 16;
-      const double rkd = A[tp][tp][kq];
-      const double ka = readlane_f64(rkd, b0 | kl), kb = readlane_f64(rkd, b0 | (kl + 1)), ke = readlane_f64(rkd, b1 | (kl + 1));
-      const double det = ka * ke - kb * kb;
-      bad |= !(ka > 0.0) | !(det > 0.0);
-      const double x0 = __builtin_amdgcn_rcp(det);
-      const double e1 = fma(-det, x0, 1.0);
-      const double dinv = fma(x0 * e1, 1.0 + e1, x0);       // 1 / det: v_rcp_f64 and one cubic step
-      const double kp = ke * dinv, kq2 = -kb * dinv, ks = ka * dinv;       // Ki = [[kp, kq2], [kq2, ks]]
-      const bool in_piv = (lk >> 1) == ((kl >> 1) & 1);     // the lanes that hold the two pivot rows
-      const bool is_u = (lk & 1) == 0;                      // ... row k (else row k + 1)
-      const double cu = is_u ? kp : kq2, cw = is_u ? kq2 : ks;
-      double aop[NT], bop[NT], sv[NT];
-      bool piv[NT];
-#pragma unroll
-      for (int tj = 0; tj < NT; ++tj) {
-        const double rk = A[tp][tj][kq];
-        const unsigned lo = __double2loint(rk), hi = __double2hiint(rk);
-        const auto l2 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-        const auto h2 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-        const double uj = __hiloint2double(h2[0], l2[0]), wj = __hiloint2double(h2[1], l2[1]);
-        const bool c0 = (tj == tp) && (lr == kl), c1 = (tj == tp) && (lr == kl + 1);
-        piv[tj] = c0 | c1;
-        const double u1 = c0 ? 1.0 : (c1 ? 0.0 : uj), w1 = c0 ? 0.0 : (c1 ? 1.0 : wj);
-        sv[tj] = cu * u1 + cw * w1;                         // t1_j / t2_j; at the pivot columns the entries of Ki
-        aop[tj] = in_piv ? rk : 0.0;
-        bop[tj] = in_piv ? (piv[tj] ? sv[tj] : -sv[tj]) : 0.0;
-      }
-#pragma unroll
-      for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-        for (int tj = 0; tj < NT; ++tj) {
-          const double keep = piv[tj] ? 0.0 : 1.0;
-          f64x4 acc = {keep * A[ti][tj][0], keep * A[ti][tj][1], keep * A[ti][tj][2], keep * A[ti][tj][3]};
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[ti], bop[tj], acc, 0, 0, 0);
-#pragma unroll
-          for (int q = 0; q < 4; ++q) A[ti][tj][q] = acc[q];
-        }
-#pragma unroll
-      for (int tj = 0; tj < NT; ++tj) A[tp][tj][kq] = in_piv ? (piv[tj] ? -sv[tj] : sv[tj]) : A[tp][tj][kq];   // pivot rows: t1, t2; pivot block: -Ki
-    }
-  }
-}
+// (wave_sweep_tiles<NT>, the same sweep for NT x NT tiles in one wave's registers, lives in psmf_ns.hip: the block filters use it too)
 
 // ------------------------------------------------------------------------------------------------------------
 // Solve block of the per-step engine for r <= 32 (declared in psmf_kernels.hip, which psmf_sweep_solve's block 0 calls): the two
