@@ -93,7 +93,10 @@ typedef struct {
                             ExperimentImpute/PSMF.py:59-84, rPSMF.py:75-135 -- e = m o (y - y_hat), rows with m_i = 0 not
                             updated, Gram / innovation covariance over the observed rows only, eta and lambda with d (not the
                             observed count), y_hat stored unmasked.  Per-step engine, one masked Gram pass per step; needs the
-                            full filter (coef_update, eta_full, pbar_predict = 1), uniform R, store_y_pred = 1 */
+                            full filter (coef_update, eta_full, pbar_predict = 1), uniform R, store_y_pred = 1.
+                            2 / 3: the baseline filters that share these contractions -- 2 = MLE-SMF (MLESMF.py:57-88: weights m_i / rho,
+                            C += gam / eta (m o e) x_p^T, bands -+ sig sqrt(eta)), 3 = TMF (TMF.py:47-66: Pbar = I / nu with Q = I / nu and
+                            P = 0 from the caller, kappa = 1, C += gam (m o e) x_p^T); gam from psmf_set_step_size */
   double alpha, beta;    /* rPSMF scaling factors (rpsmf.py:45-51), 1.0 unless use_scaling     */
   double adam_lr, adam_lr_end, adam_lr_steps; /* lr (Constant) or lr_start/lr_end/steps
                             (ExponentialLearningRate, learning_rate.py:20-27; steps = 0 ->
@@ -176,7 +179,10 @@ int psmf_sq_error(psmf_handle h, int64_t t0, int64_t nt, double* out);
  * observations y_{T+1} .. y_{T+n_pred} (n_pred x d_local float64, host): tracking.py:74-76 (`_E_pred`). */
 int psmf_predict_sq_error(psmf_handle h, int64_t T, int64_t n_pred, const double* Y_true, double* out);
 
-/* masked = 1, after psmf_run over the steps t0+1 .. t0+nt: the evaluation sums of ExperimentImpute over the held-out entries
+/* masked = 2 / 3: the step size gam of the stochastic-gradient update of C for the runs that follow (the experiments use
+ * 1e-6 / (pass + 1)^0.7, MLESMF.py:59-60, TMF.py:46-48). */
+int psmf_set_step_size(psmf_handle h, double gam);
+/* masked != 0, after psmf_run over the steps t0+1 .. t0+nt: the evaluation sums of ExperimentImpute over the held-out entries
  * Mmiss (nt x d_local uint8, 1 = artificially removed) of this handle's rows, reduced on the device:
  *   out4[0] = sum (y_hat - y)^2          RMSEM(Yrec, YorgInt, Mmiss)^2 * out4[3]            PSMF.py:88, common.py:79-84
  *   out4[1] = sum (c_i . x_t - y)^2      RMSEM(C @ X, ...) with the present C, x_t = posterior mean of step t   PSMF.py:86-89
@@ -258,7 +264,7 @@ typedef struct {
 
 /* Any d and 1 <= r <= PSMF_RMAX.  Shapes whose replica state fits one workgroup's LDS (d <= 512, r <= 16) run one workgroup per
  * replica, all replicas in one launch (psmf_impute_kernel3 / psmf_impute_kernel2); larger shapes run the replicas one after the
- * other on the masked per-step engine of the large-d handle (method 0 / 1 only).  psmf_impute_kernel_id() tells which.
+ * other on the masked per-step engine of the large-d handle (all four methods).  psmf_impute_kernel_id() tells which.
  * All arrays time-major (column t of the reference's d x n matrices is row t here):
  *   YorgInt  n x d  float64  data with native missing values set to 0        (shared)
  *   M        batch x n x d  uint8   1 = observed                              (per replica)

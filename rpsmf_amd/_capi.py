@@ -81,6 +81,7 @@ SIGNATURES = {
     "psmf_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "psmf_device_pci_bus_id": (C.c_int, [C.c_int, C.c_char_p, C.c_int]),
     "psmf_upload_mask": (C.c_int, [C.c_void_p, _u8p, C.c_int64, C.c_int64]),
+    "psmf_set_step_size": (C.c_int, [C.c_void_p, C.c_double]),
     "psmf_masked_metrics": (C.c_int, [C.c_void_p, _u8p, C.c_int64, C.c_int64, C.c_double, _dp]),
     "psmf_download_step_scalars": (C.c_int, [C.c_void_p, _dp, C.c_int64, C.c_int64]),
 }
@@ -163,7 +164,7 @@ class DeviceFilter:
             n_theta=self.n_theta, storage=self.storage, store_y_pred=int(store_y_pred),
             recursive=int(recursive), update_every=int(update_every), gram_refresh=int(gram_refresh),
             device=int(device), use_graph=int(use_graph), n_workgroups=int(n_workgroups),
-            engine={"auto": 0, "step": 1, "block": 2}.get(engine, engine), dyn_flags=int(dyn_flags), dyn_terms=int(dyn_terms), nonuniform_R=int(bool(nonuniform_R)), masked=int(bool(masked)),
+            engine={"auto": 0, "step": 1, "block": 2}.get(engine, engine), dyn_flags=int(dyn_flags), dyn_terms=int(dyn_terms), nonuniform_R=int(bool(nonuniform_R)), masked=int(masked),
             alpha=float(alpha), beta=float(beta), adam_lr=float(adam_lr), adam_lr_end=float(adam_lr_end),
             adam_lr_steps=float(adam_lr_steps), adam_b1=float(adam_b1), adam_b2=float(adam_b2))
         rc = self._lib.psmf_create(C.byref(self._h), C.byref(cfg))
@@ -249,6 +250,10 @@ class DeviceFilter:
         if M.ndim != 2 or M.shape[1] != self.d_local:
             raise ValueError(f"mask must be (T, {self.d_local}) time-major, got {M.shape}")
         self._check(self._lib.psmf_upload_mask(self._h, M.ctypes.data_as(_u8p), int(t0), M.shape[0]))
+
+    def set_step_size(self, gam):
+        """masked = 2 / 3 (MLE-SMF / TMF): step size of the gradient update of C for the runs that follow."""
+        self._check(self._lib.psmf_set_step_size(self._h, float(gam)))
 
     def masked_metrics(self, Mmiss, sig, t0=0):
         """(sum (y_hat - y)^2, sum (C x_t - y)^2, entries inside their band, count) over the held-out entries Mmiss (nt, d_local)

@@ -647,7 +647,7 @@ void compute_geometry(const psmf_config& c, Geometry& g) {
 void update_solve_dual(psmf_filter* h) {
   static const bool off = Switches::off("PSMF_STEP_DUAL");
   const psmf_config& c = h->cfg;
-  const int v = (!off && h->engine == 1 && h->q_iso && c.dyn_kind == PSMF_DYN_RANDOM_WALK && c.coef_update && c.pbar_predict && !c.nonuniform_R &&
+  const int v = (!off && h->engine == 1 && h->q_iso && c.masked < 2 && c.dyn_kind == PSMF_DYN_RANDOM_WALK && c.coef_update && c.pbar_predict && !c.nonuniform_R &&
                  c.r <= 32 && !h->sp.solve_lds && !h->sp.q_sched) ? 1 : 0;
   if (v != h->sp.solve_dual) {
     h->sp.solve_dual = v;
@@ -748,6 +748,9 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
     return fail(nullptr, PSMF_ERR_ARG, "psmf_create: n_theta does not match dyn_kind / dyn_flags / dyn_terms (see psmf_dyn_kind)");
   if (cfg->dyn_kind == PSMF_DYN_HOST && cfg->recursive) return fail(nullptr, PSMF_ERR_ARG, "psmf_create: host-stepped dynamics keep theta (and its optimiser) on the host");
   if (cfg->recursive && cfg->update_every < 1) return fail(nullptr, PSMF_ERR_ARG, "psmf_create: update_every must be >= 1");
+  if (cfg->masked < 0 || cfg->masked > 3) return fail(nullptr, PSMF_ERR_ARG, "psmf_create: masked must be 0 .. 3");
+  if (cfg->masked >= 2 && (cfg->robust || cfg->dyn_kind != PSMF_DYN_RANDOM_WALK))
+    return fail(nullptr, PSMF_ERR_ARG, "psmf_create: masked = 2 (MLE-SMF) / 3 (TMF) are random-walk, non-robust filters");
   if (cfg->masked) {
     if (cfg->dyn_kind != PSMF_DYN_RANDOM_WALK && cfg->dyn_kind != PSMF_DYN_COS_PHASE)
       return fail(nullptr, PSMF_ERR_ARG, "psmf_create: masked = 1 runs on the per-step engine, which evaluates the random walk and cos-phase dynamics");
@@ -916,6 +919,7 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
   sp.recursive = cfg->recursive; sp.update_every = cfg->update_every > 0 ? cfg->update_every : 1;
   sp.track_g = ((cfg->eta_full || cfg->coef_update) && !cfg->masked) ? 1 : 0;     // masked: G is this step's masked Gram, recomputed every step
   sp.mask = nullptr;
+  sp.masked_method = cfg->masked >= 2 ? cfg->masked : 0;
   sp.solve_lds = Switches::off("PSMF_STEP_WAVE_SOLVE") ? 1 : 0;
   sp.external_reduce = 0;
   sp.use_ns = (getenv("PSMF_NS") && atoi(getenv("PSMF_NS")) == 0) ? 0 : 1;
@@ -1682,6 +1686,15 @@ int psmf_upload_mask(psmf_handle h, const uint8_t* M, int64_t t0, int64_t nt) {
   return PSMF_OK;
 }
 
+int psmf_set_step_size(psmf_handle h, double gam) {
+  if (!h || !(gam >= 0.0)) return fail(h, PSMF_ERR_ARG, "psmf_set_step_size: bad argument");
+  int rc = set_device(h);
+  if (rc) return rc;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  HIP_TRY(h, hipMemcpy(&h->st->sgd_gamma, &gam, sizeof(double), hipMemcpyHostToDevice));
+  return PSMF_OK;
+}
+
 int psmf_masked_metrics(psmf_handle h, const uint8_t* Mmiss, int64_t t0, int64_t nt, double sig, double* out4) {
   if (!h || !Mmiss || !out4 || t0 < 0 || nt < 1) return fail(h, PSMF_ERR_ARG, "psmf_masked_metrics: bad argument");
   if (!h->cfg.masked || !h->have_mask || !h->YP || t0 + nt > h->T_cap) return fail(h, PSMF_ERR_STATE, "psmf_masked_metrics: needs a masked handle that has run over these steps");
@@ -1790,13 +1803,13 @@ int impute_run_large(const psmf_impute_config* cfg, const double* YorgInt, const
                      const double* V, const double* P, const double* Q, double rho, double* Epred, double* Efull, double* inside,
                      double* Yrec, double* YrecL, double* YrecH, int32_t* status, float* elapsed_ms) {
   auto failc = [&](int code, const std::string& msg) { g_create_error = "psmf_impute_run: " + msg; return code; };
-  if (cfg->method > 1) return failc(PSMF_ERR_ARG, "MLE-SMF / TMF (method 2 / 3) run on the one-workgroup-per-replica engine only: d <= 512, r <= 16");
-  const int d = cfg->d, n = cfg->n, r = cfg->r, B = cfg->batch, robust = cfg->method == 1;
+  (void)failc;
+  const int d = cfg->d, n = cfg->n, r = cfg->r, B = cfg->batch, robust = cfg->method == 1, meth = cfg->method;
   psmf_config pc;
   memset(&pc, 0, sizeof(pc));
   pc.abi_version = PSMF_ABI_VERSION; pc.d = d; pc.r = r; pc.row0 = 0; pc.d_local = d; pc.robust = robust;
   pc.coef_update = 1; pc.eta_full = 1; pc.pbar_predict = 1; pc.dyn_kind = PSMF_DYN_RANDOM_WALK; pc.n_theta = 0;
-  pc.storage = PSMF_F64; pc.store_y_pred = 1; pc.update_every = 1; pc.device = cfg->device; pc.use_graph = 1; pc.engine = 1; pc.masked = 1;
+  pc.storage = PSMF_F64; pc.store_y_pred = 1; pc.update_every = 1; pc.device = cfg->device; pc.use_graph = 1; pc.engine = 1; pc.masked = meth >= 2 ? meth : 1;
   pc.alpha = pc.beta = 1.0; pc.adam_lr = 1e-3; pc.adam_b1 = 0.9; pc.adam_b2 = 0.999;
   psmf_handle h = nullptr;
   int rc = psmf_create(&h, &pc);
@@ -1813,7 +1826,13 @@ int impute_run_large(const psmf_impute_config* cfg, const double* YorgInt, const
     double* Xb = X + (size_t)b * n * r;
     rc = psmf_upload_mask(h, M + (size_t)b * nd, 0, n);
     if (rc) return bail(rc);
-    rc = psmf_set_state(h, Cb, V, P, Q, Xb + (size_t)(n - 1) * r, rho, robust ? cfg->lambda0 : 0.0, nullptr);
+    if (meth == 3) {       // TMF (TMF.py:47,60): Pbar = I / nu at every step, nu = 2 -- as Q with P = 0 (the serial stage keeps P at 0); V unused
+      std::vector<double> Inu((size_t)r * r, 0.0), Zr((size_t)r * r, 0.0), Iv((size_t)r * r, 0.0);
+      for (int i = 0; i < r; ++i) { Inu[(size_t)i * r + i] = 0.5; Iv[(size_t)i * r + i] = 1.0; }
+      rc = psmf_set_state(h, Cb, Iv.data(), Zr.data(), Inu.data(), Xb + (size_t)(n - 1) * r, 1.0, 0.0, nullptr);
+    } else {
+      rc = psmf_set_state(h, Cb, V, P, Q, Xb + (size_t)(n - 1) * r, rho, robust ? cfg->lambda0 : 0.0, nullptr);
+    }
     if (rc) return bail(rc);
     bool bad = false;
     double m4[4] = {0, 0, 0, 0};
@@ -1823,9 +1842,13 @@ int impute_run_large(const psmf_impute_config* cfg, const double* YorgInt, const
         rc = psmf_set_state(h, nullptr, nullptr, nullptr, Q, nullptr, rho, cfg->lambda0, nullptr);
         if (rc) return bail(rc);
       }
+      if (meth >= 2) {       // gam = 1e-6 / (pass + 1)^0.7  (MLESMF.py:59-60, TMF.py:46-48)
+        rc = psmf_set_step_size(h, 1e-6 / std::pow((double)(it + 1), 0.7));
+        if (rc) return bail(rc);
+      }
       rc = psmf_run(h, 0, n);
       if (rc) return bail(rc);
-      rc = psmf_masked_metrics(h, Mmiss + (size_t)b * nd, 0, n, cfg->sig, m4);
+      rc = psmf_masked_metrics(h, Mmiss + (size_t)b * nd, 0, n, meth == 3 ? 0.0 : cfg->sig, m4);
       if (rc == PSMF_ERR_NUMERIC) { bad = true; break; }
       if (rc) return bail(rc);
       Epred[(size_t)b * cfg->n_iter + it] = std::sqrt(m4[0] / m4[3]);
@@ -1847,7 +1870,7 @@ int impute_run_large(const psmf_impute_config* cfg, const double* YorgInt, const
             for (int i = 0; i < d; ++i) {
               const size_t at = (size_t)b * nd + (size_t)t * d + i;
               const double yh = yp[(size_t)t * d + i];
-              const double band = cfg->sig * std::sqrt(robust ? (Mb[(size_t)t * d + i] ? sc[2 * t] : 0.0) + sc[2 * t + 1] : sc[2 * t] + sc[2 * t + 1]);
+              const double band = meth == 3 ? 0.0 : cfg->sig * std::sqrt(robust ? (Mb[(size_t)t * d + i] ? sc[2 * t] : 0.0) + sc[2 * t + 1] : sc[2 * t] + sc[2 * t + 1]);
               Yrec[at] = yh; YrecL[at] = yh - band; YrecH[at] = yh + band;
             }
         }

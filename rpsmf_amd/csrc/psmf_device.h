@@ -33,6 +33,7 @@ struct DevState {
   double s, eta, N, kappa;  // scalars of the current step
   double phi, omega, ee;  // scalars of the last finished step
   double s_done, eta_done, N_done;  // s, eta, N of the last finished step
+  double sgd_gamma;       // masked_method 2 / 3: the pass's step size gam = 1e-6 / (pass + 1)^0.7 (MLESMF.py:59-60, TMF.py:46-48), set by the host
   long long k;            // number of finished steps = 0-based series index of the current step
   int err;                // != 0: numeric failure (singular system) at step err
   int ns_valid;           // != 0: Lbar / XpX / XpY describe the current state; 3: so does the f3_* dump (cleared by every host state upload);
@@ -82,6 +83,10 @@ struct StepParams {
   // Lbar' = Pbar'^-1 = (I / q - W / q^2) / omega for the next step (the Woodbury form of filter3): ONE sweep on
   // the path of a step instead of two.  DevState.Lbar / XpY carry Lbar / W while ns_valid == 7.
   int solve_dual;
+  // masked handle: which filter of ExperimentImpute the masked steps are.  0: PSMF / rPSMF (PSMF.py:59-84, rPSMF.py:75-135).
+  // 2: MLE-SMF (MLESMF.py:57-88): weights m_i / rho (no s), C += gam / eta (m o e) x_p^T, V unused, bands -+ sig sqrt(eta).
+  // 3: TMF (TMF.py:47-66): x = x_p + (nu I + G_m)^-1 C^T e, i.e. the same solve with Pbar = I / nu, kappa = 1; C += gam (m o e) x_p^T.
+  int masked_method;
   int solve_lds;        // 1: the LDS-and-barrier sweeps of round 1 for every r (PSMF_STEP_WAVE_SOLVE=0); default: wave-local sweeps for r <= 32
   int external_reduce;  // 1: partial sums were reduced into st->red (multi-GPU)
   int use_ns;           // 1: Newton-Schulz refinement of the r x r inverses (f64 MFMA), sweep as fallback

@@ -419,8 +419,25 @@ __device__ __forceinline__ void wave_sweep16(double (&A)[4], const int r2, const
 // (wave 0: the r x r work; wave 1: W beside it, Gram share; waves 2, 3: Gram share, rank-1 updates; wave 3: w = V x).  With the
 // wave index as a run-time value every wave carried the union of the roles through the loop (the same change took 7 % off the
 // blocked engine's filter kernel and 30 % off the simplified-hooks kernel).
+// The column loops of psmf_impute_kernel2 / psmf_impute_kernel3 are FOUR programs, one per wave (impute2_wave<WV>, impute3_wave<WV, NG>),
+// that meet at workgroup barriers placed inside role-dependent code: correct only while every program executes the same NUMBER of
+// barriers on every path (n_iter, robust, q_iso, method, row-group branches) -- an edit that adds or drops one in a single role would
+// deadlock or, worse, pair up the wrong phases silently.  Every barrier of those programs goes through these two wrappers, which count;
+// at the end the four counts are compared and a mismatch is reported as a numeric failure of the replica (flag value 9) -- one scalar
+// add per barrier.  tests/test_hip_impute_small.py runs every role / method / shape combination through it.
+__device__ __forceinline__ void imp_barrier_lds(int& n) { ++n; solve_barrier<true>(); }
+__device__ __forceinline__ void imp_barrier_full(int& n) { ++n; __syncthreads(); }
+__device__ __forceinline__ void imp_barrier_check(const int n, int* errflag) {
+  __shared__ int s_nbar[4];
+  if ((threadIdx.x & 63) == 0) s_nbar[threadIdx.x >> 6] = n;
+  __syncthreads();
+  if (threadIdx.x == 0 && (s_nbar[0] != s_nbar[1] || s_nbar[0] != s_nbar[2] || s_nbar[0] != s_nbar[3])) *errflag = 9;
+  __syncthreads();
+}
+
 template <int WV>
 __device__ __forceinline__ void impute2_wave(const ImputeParams& p) {
+  int nbar = 0;          // barriers this wave has executed (imp_barrier_check at the end)
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* sm = reinterpret_cast<double*>(smem_raw);
   const int d = p.d, n = p.n, r = p.r, tid = threadIdx.x, rep = blockIdx.x;
@@ -485,7 +502,7 @@ __device__ __forceinline__ void impute2_wave(const ImputeParams& p) {
   bool bad = false;
   unsigned long long nmiss_l = 0;
   int cur = 0;
-  __syncthreads();
+  imp_barrier_full(nbar);
   IMP_T0();
   for (int it = 0; it < p.n_iter; ++it) {
     const double gam = 1e-6 / pow((double)(it + 1), 0.7);     // MLESMF.py:59-60, TMF.py:46-48
@@ -512,7 +529,7 @@ __device__ __forceinline__ void impute2_wave(const ImputeParams& p) {
         iqv = 1.0 / qv;
         if (lane == 0) { ssc[4] = 1.0; ssc[5] = iqv; ssc[6] = iqv; }
       }
-      __syncthreads();
+      imp_barrier_full(nbar);
     }
     double sse_pred = 0.0;
     unsigned long long inside_l = 0;
@@ -578,7 +595,7 @@ __device__ __forceinline__ void impute2_wave(const ImputeParams& p) {
         sw[lane] = a0 + a1;
       }
       IMP_T(0);
-      solve_barrier<true>();                                          // ---- barrier 1
+      imp_barrier_lds(nbar);                                          // ---- barrier 1
       IMP_T(1);
       // ---- P2: augmented masked Gram on the matrix cores, wave w: 4-row groups w, w + 4, ... ----
       double G[4], Bq[4], PP[4], kappa = 0.0, N = 0.0, eta = 0.0, s = 0.0, ee = 0.0, phi = 1.0, msum = 0.0, ild = 0.0;
@@ -622,7 +639,7 @@ __device__ __forceinline__ void impute2_wave(const ImputeParams& p) {
         }
       }
       IMP_T(2);
-      solve_barrier<true>();                                          // ---- barrier 2
+      imp_barrier_lds(nbar);                                          // ---- barrier 2
       IMP_T(3);
       // ---- P3a (wave 0; wave 1 too when it inverts beside it): G, b, Lbar, <G, P + Q>, eta, N, phi ----
       if (wv == 0 || (par && wv == 1)) {
@@ -654,7 +671,7 @@ __device__ __forceinline__ void impute2_wave(const ImputeParams& p) {
         if (lane == 0) { ssc[1] = eta; ssc[2] = N; ssc[3] = phi; }
       }
       IMP_T(4);
-      solve_barrier<true>();                                          // ---- barrier 3
+      imp_barrier_lds(nbar);                                          // ---- barrier 3
       IMP_T(5);
       if (par && wv == 1) {
         // ---- P3b, wave 1: W_t = (M_t + I / q_t)^-1 for the next column's Lbar, beside wave 0's inversion of M_t ----
@@ -764,17 +781,17 @@ __device__ __forceinline__ void impute2_wave(const ImputeParams& p) {
       }
       cur ^= 1;
       IMP_T(6);
-      solve_barrier<true>();                                          // ---- barrier 4
+      imp_barrier_lds(nbar);                                          // ---- barrier 4
       IMP_T(7);
     }
     // ---- end of pass: RMSE of the one-step predictions, RMSE of C @ X, coverage ----
-    __syncthreads();                 // (drains the X stores of wave 0)
+    imp_barrier_full(nbar);                 // (drains the X stores of wave 0)
     double nm_d = (double)nmiss_l;
     const double sse_full = held_out_sse(sC, IR, Xg, Yorg, Mm, d, n, r, tid);
     double v0 = wave_sum(sse_pred), v1 = wave_sum(sse_full), v2 = wave_sum(nm_d), v3 = wave_sum((double)inside_l);
-    __syncthreads();
+    imp_barrier_full(nbar);
     if (lane == 0) { sred[wv * 4 + 0] = v0; sred[wv * 4 + 1] = v1; sred[wv * 4 + 2] = v2; sred[wv * 4 + 3] = v3; }
-    __syncthreads();
+    imp_barrier_full(nbar);
     if (tid == 0) {
       const double tp = (sred[0] + sred[4]) + (sred[8] + sred[12]);
       const double tf = (sred[1] + sred[5]) + (sred[9] + sred[13]);
@@ -784,11 +801,12 @@ __device__ __forceinline__ void impute2_wave(const ImputeParams& p) {
       p.Efull[(size_t)rep * p.n_iter + it] = sqrt(tf / tn);
       if (it == p.n_iter - 1) p.inside[rep] = ti / tn;
     }
-    __syncthreads();
+    imp_barrier_full(nbar);
   }
   for (int idx = tid; idx < d * r; idx += WG) { const int i = idx / r, l = idx - i * r; Cg[idx] = sC[i * IR + l]; }
   if (wv < 2 && bad) *errflag = 1;           // (benign race: every writer stores 1)
-  __syncthreads();
+  imp_barrier_full(nbar);
+  imp_barrier_check(nbar, errflag);
   if (tid == 0) p.err[rep] = *errflag;
   IMP_TOUT();
 }
@@ -945,6 +963,8 @@ extern "C" int psmf_impute_run(const psmf_impute_config* cfg, const double* Yorg
   // Per-replica outcome (the reference records NaN for a diverged repeat and carries on, ExperimentImpute/rPSMF.py:236-243): a
   // replica whose r x r system lost positive definiteness -- or whose errors are not finite -- gets status PSMF_ERR_NUMERIC and NaN
   // results; the other replicas are untouched by it (one workgroup each).  Without a status array the call fails as a whole.
+  for (int b = 0; b < B; ++b)
+    if (herr[b] == 9) { rc = fail(PSMF_ERR_HIP, "internal error: the wave programs of the column loop executed different numbers of barriers (imp_barrier_check)"); goto done; }
   for (int b = 0; b < B; ++b) {
     bool bad = herr[b] != 0;
     for (int it = 0; it < cfg->n_iter && !bad; ++it)

@@ -47,6 +47,7 @@ inline size_t impute3_lds_bytes(int d, int r) {
 
 template <int WV, int NG>
 __device__ __forceinline__ void impute3_wave(const ImputeParams& p) {
+  int nbar = 0;          // barriers this wave has executed (imp_barrier_check, psmf_impute.hip)
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* sm = reinterpret_cast<double*>(smem_raw);
   const int d = p.d, n = p.n, r = p.r, tid = threadIdx.x, rep = blockIdx.x;
@@ -128,7 +129,7 @@ __device__ __forceinline__ void impute3_wave(const ImputeParams& p) {
   const int rowi = WIDE ? (WV == 1 ? 64 + lane : lane) : (lane & 31);       // this lane's row
   const int row = min(rowi, d - 1), half = WIDE ? 0 : lane >> 5;
   const bool rown = ROWS && rowi < d && (WIDE || lane < 32);
-  __syncthreads();
+  imp_barrier_full(nbar);
   IMP_T0();
   for (int it = 0; it < p.n_iter; ++it) {
     const double gam = 1e-6 / pow((double)(it + 1), 0.7);     // MLESMF.py:59-60, TMF.py:46-48
@@ -166,7 +167,7 @@ __device__ __forceinline__ void impute3_wave(const ImputeParams& p) {
         if (lane == 0) { ssc[8] = rho; ssc[9] = lam; ssc[16 + 8] = rho; ssc[16 + 9] = lam; }
       }
     }
-    __syncthreads();
+    imp_barrier_full(nbar);
     double sse_pred = 0.0;
     unsigned long long inside_l = 0;
     nmiss_l = 0;
@@ -234,7 +235,7 @@ __device__ __forceinline__ void impute3_wave(const ImputeParams& p) {
         if (lane == 0) ssc[cur * 16] = sv;
       }
       IMP_T(0);
-      solve_barrier<true>();                                          // ---- barrier 1
+      imp_barrier_lds(nbar);                                          // ---- barrier 1
       IMP_T(1);
       if (ROWS) {          // next column's inputs: issued here, off the path to barrier 1, a whole column before their use
         const size_t cbase = (size_t)min(t + 1, n - 1) * d;      // (the last column is simply loaded twice)
@@ -397,18 +398,18 @@ __device__ __forceinline__ void impute3_wave(const ImputeParams& p) {
       }
       cur ^= 1;
       IMP_T(5);
-      solve_barrier<true>();                                          // ---- barrier 2
+      imp_barrier_lds(nbar);                                          // ---- barrier 2
       IMP_T(6);
     }
     if (WV == 1 && lane < r) Xg[(size_t)(n - 1) * r + lane] = sx[cur * IR + lane];
     // ---- end of pass: RMSE of the one-step predictions, RMSE of C @ X, coverage ----
-    __syncthreads();                 // (drains the X stores)
+    imp_barrier_full(nbar);                 // (drains the X stores)
     double nm_d = (double)nmiss_l;
     const double sse_full = held_out_sse(sC + cur * (D4 * IR), IR, Xg, Yorg, Mm, d, n, r, tid);
     double v0 = wave_sum(sse_pred), v1 = wave_sum(sse_full), v2 = wave_sum(nm_d), v3 = wave_sum((double)inside_l);
-    __syncthreads();
+    imp_barrier_full(nbar);
     if (lane == 0) { sred[WV * 4 + 0] = v0; sred[WV * 4 + 1] = v1; sred[WV * 4 + 2] = v2; sred[WV * 4 + 3] = v3; }
-    __syncthreads();
+    imp_barrier_full(nbar);
     if (tid == 0) {
       const double tp = (sred[0] + sred[4]) + (sred[8] + sred[12]);
       const double tf = (sred[1] + sred[5]) + (sred[9] + sred[13]);
@@ -418,11 +419,12 @@ __device__ __forceinline__ void impute3_wave(const ImputeParams& p) {
       p.Efull[(size_t)rep * p.n_iter + it] = sqrt(tf / tn);
       if (it == p.n_iter - 1) p.inside[rep] = ti / tn;
     }
-    __syncthreads();
+    imp_barrier_full(nbar);
   }
   for (int idx = tid; idx < d * r; idx += WG) { const int i = idx / r, l = idx - i * r; Cg[idx] = sC[cur * (D4 * IR) + i * IR + l]; }
   if (WV < 2 && bad) *errflag = 1;           // (benign race: every writer stores 1)
-  __syncthreads();
+  imp_barrier_full(nbar);
+  imp_barrier_check(nbar, errflag);
   if (tid == 0) p.err[rep] = *errflag;
   IMP_TOUT();
 }

@@ -612,6 +612,7 @@ __device__ __forceinline__ void serial_body(const StepParams& p, const int first
         const double wi = s_w[ii[m]], hi = s_he[ii[m]], hj = s_he[j];
         Vv[m] = vscale * (Vv[m] - wi * wj * invN);
         Pv[m] *= pscale;
+        if (p.masked_method == 3) Pv[m] = 0.0;          // TMF: Pbar of every step is Q = I / nu (TMF.py:47,60), nothing is carried
         st->V[idx] = Vv[m];
         st->P[idx] = Pv[m];
         if (p.track_g) {

@@ -8,6 +8,9 @@
 //   kappa_i = m_i / (rho + s)                    =>  P+ = (P_bar^-1 + kappa G_m)^-1,  b = kappa h,  q = kappa ee  (uniform rho)
 //   lambda <- lambda + d                         (d again, rPSMF.py:135)
 //   bands : PSMF  y_hat -+ sig sqrt(N)  (PSMF.py:83-84);  rPSMF  y_hat_i -+ sig sqrt(s m_i + eta)  (rPSMF.py:112,121-123)
+// and, sharing these contractions (StepParams.masked_method), the two baseline filters of the imputation tables: MLE-SMF (weights
+// m_i / rho, C += gam / eta (m o e) x_p^T, bands -+ sig sqrt(eta): MLESMF.py:57-88) and TMF (Pbar = I / nu, kappa = 1, C += gam (m o e) x_p^T:
+// TMF.py:47-66).
 //
 // A step is: psmf_mgram_mfma -> psmf_mgram_reduce (-> all-reduce of r^2 + 1 doubles) -> psmf_masked_prep (eta, N, w / N, kappa and
 // the step's (s, eta) into the history the bands are formed from) -> psmf_sweep_solve with the mask (-> all-reduce of r + 1 doubles)
@@ -168,14 +171,16 @@ __global__ __launch_bounds__(WG) void psmf_masked_prep(StepParams p, const doubl
   if ((tid & 63) == 0) s4[tid >> 6] = gp;
   __syncthreads();
   const double tr = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-  const double s = st->s, rho = st->rho;
+  const int meth = p.masked_method;
+  const double s = meth ? 0.0 : st->s, rho = st->rho;
   const double eta = (rho * mg[r * r] + tr) / (double)p.d;
   const double N = s + eta;
-  if (tid < r) st->wN[tid] = st->w[tid] * fast_rcp(N);
+  // the direction of the rank-1 update of C: PSMF  w / N (w = V mu_bar);  MLE-SMF  (gam / eta) mu_bar;  TMF  gam mu_bar
+  if (tid < r) st->wN[tid] = meth == 0 ? st->w[tid] * fast_rcp(N) : st->mu_bar[tid] * (meth == 2 ? st->sgd_gamma * fast_rcp(eta) : st->sgd_gamma);
   if (tid == 0) {
     st->eta = eta;
     st->N = N;
-    st->kappa = fast_rcp(rho + s);
+    st->kappa = meth == 3 ? 1.0 : fast_rcp(rho + s);
     if (sc_hist) {
       const long long t = st->k - p.series_t0;
       sc_hist[2 * t] = s;

@@ -21,12 +21,13 @@ from rpsmf_amd.sharding import shard_rows
 pytestmark = [pytest.mark.gpu, pytest.mark.timeout(600)]
 
 
-def _problem(d, n, r, seed, miss=0.4):
+def _problem(d, n, r, seed, miss=0.4, empty_column=True):
     rng = np.random.default_rng(seed)
     Yorig = np.cumsum(0.3 * rng.standard_normal((d, n)), axis=1) + 3.0 * rng.random((d, 1))
     M = (rng.random((d, n)) > miss).astype(int)
     M[3] = 0                 # a row that is never observed
-    M[:, 5] = 0              # a column with no observation at all
+    if empty_column:
+        M[:, 5] = 0          # a column with no observation at all (MLE-SMF divides by eta = 0 there, in the reference too)
     Mmiss = ((1 - M) * (rng.random((d, n)) > 0.1)).astype(float)
     return Yorig, M, Mmiss, rng.random((d, r)), rng.random((r, n))
 
@@ -61,8 +62,30 @@ def test_drop_in_functions_beyond_the_small_engine():
             dp, df, rt, di = impute.ProbabilisticSequentialMatrixFactorizer(Yorig * M, C0.copy(), Xd, d, n, r, M, Mmiss, 10, V, Q, R, P, 2, 2, Yorig, 0.25)
         assert dp.shape == (1, 3) and dp[0, 0] == 0.25 and relerr(dp, ep) < 1e-9 and relerr(df, ef) < 1e-9 and abs(di - ib) < 1e-12
         assert relerr(Xd, Xo) < 1e-9
-    with pytest.raises(ValueError, match="MLE-SMF"):
-        impute.impute_batch(Yorig, M, Mmiss, C0, X0, V, Q, 10.0, P, 2, 1, method="mle_smf")
+
+
+def test_baseline_filters_beyond_the_small_engine():
+    """MLE-SMF (MLESMF.py:40-92) and TMF (TMF.py:30-73) at d = 600 / r = 12 and d = 40 / r = 20 on the masked per-step engine
+    (cfg.masked = 2 / 3), through the drop-in functions, against the oracle's restatements (pinned to the reference functions'
+    outputs by tests/golden/impute_baselines.npz)."""
+    from oracle.impute_oracle import mle_smf_filter, tmf_filter
+
+    for d, n, r in ((600, 60, 12), (40, 90, 20)):
+        Yorig, M, Mmiss, C0, X0 = _problem(d, n, r, 21 + d, empty_column=False)
+        Q, P, R = 0.1 * np.eye(r), np.eye(r), 10 * np.eye(d)
+        Xo, Xd = X0.copy(), X0.copy()
+        ep, ef, ib, st = mle_smf_filter(Yorig * M, C0, Xo, M, Mmiss, Q, 10.0, P, 2, 2, Yorig, 0.3, return_state=True)
+        dp, df, rt, di = impute.stochasticGradientStateSpaceMF(Yorig * M, C0.copy(), Xd, d, n, r, M, Mmiss, 10, Q, R, P, 2, 2, Yorig, 0.3)
+        assert relerr(dp, ep) < 1e-9 and relerr(df, ef) < 1e-9 and abs(di - ib) < 1e-12 and relerr(Xd, Xo) < 1e-9
+        res = impute.impute_batch(Yorig, M, Mmiss, C0, X0, np.eye(r), Q, 10.0, P, 2, 2, method="mle_smf", want_bands=True)
+        assert res["kernel"] == "masked per-step engine"
+        assert relerr(res["C"][0], st["C"]) < 1e-9 and relerr(res["YrecL"][0], st["YrecL"]) < 1e-9 and relerr(res["YrecH"][0], st["YrecH"]) < 1e-9
+        Xo, Xd = X0.copy(), X0.copy()
+        ep, ef, st = tmf_filter(Yorig * M, C0, Xo, M, Mmiss, 2, Yorig, 0.3, return_state=True)
+        dp, df, rt = impute.temporalRegularizedMF(Yorig * M, C0.copy(), Xd, d, n, r, M, Mmiss, 10, R, 2, Yorig, 0.3)
+        assert relerr(dp, ep) < 1e-9 and relerr(df, ef) < 1e-9 and relerr(Xd, Xo) < 1e-9
+        res = impute.impute_batch(Yorig, M, Mmiss, C0, X0, np.eye(r), np.eye(r), 1.0, np.eye(r), 0.0, 2, method="tmf")
+        assert relerr(res["C"][0], st["C"]) < 1e-9 and res["inside"][0] == 0.0
 
 
 @pytest.mark.parametrize("robust", [False, True], ids=["PSMF", "rPSMF"])

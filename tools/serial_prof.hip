@@ -14,7 +14,10 @@ int main() {
   double one = 1.0; hipMemcpy(&st->rho, &one, 8, hipMemcpyHostToDevice); hipMemcpy(&st->N, &one, 8, hipMemcpyHostToDevice); hipMemcpy(&st->kappa, &one, 8, hipMemcpyHostToDevice);
   double* part; hipMalloc((void**)&part, (4096 + 64) * 8 + (size_t)nwg * ps * 8 + 65536); hipMemset(part, 0, (4096 + 64) * 8 + (size_t)nwg * ps * 8 + 65536);
   StepParams p{}; p.st = st; p.partials = part; p.r = r; p.d = 100000; p.d_local = 100000; p.n_sweep_wg = nwg; p.ps = ps;
-  p.coef_update = 1; p.eta_full = 1; p.pbar_predict = 1; p.track_g = 1; p.alpha = p.beta = 1.0;
+  p.coef_update = 1; p.eta_full = 1; p.pbar_predict = 1; p.track_g = 1; p.alpha = p.beta = 1.0; p.rho_mean = 1.0;
+  // the stage loads theta / gradsum / Adam moments unconditionally (RM entries each, masked afterwards): they must point at memory
+  double* th; hipMalloc((void**)&th, 4 * RM * 8); hipMemset(th, 0, 4 * RM * 8);
+  p.theta = th; p.gradsum = th + RM; p.adam_m = th + 2 * RM; p.adam_v = th + 3 * RM; p.rp = 32; p.nv = 8; p.rows_per_wg = 224;
   for (int it = 0; it < 3; ++it) { psmf_serial<32><<<1, serial_threads(32)>>>(p, 0); hipDeviceSynchronize(); }
   unsigned long long h[16]; hipMemcpy(h, reinterpret_cast<unsigned long long*>(part) + 4096, 16 * 8, hipMemcpyDeviceToHost);
   const char* nm[8] = {"issue loads", "partials->LDS reduce (+wait for loads)", "P+h col-reduce, mu", "gradient/robust scalars", "elementwise V,P,G + stores", "prep: mu_bar, Pbar, partials", "col-reduce V mu_bar", "s, <G,Pbar>, N, stores"};
