@@ -229,13 +229,9 @@ void launch_serial(psmf_filter* h, int first) {
 // one filter step on the stream (captured into the graph or launched eagerly)
 int enqueue_weighted_gram(psmf_filter* h);
 
-int enqueue_masked_gram(psmf_filter* h);
+int enqueue_serial_mgram(psmf_filter* h, int first);
 
 int enqueue_step(psmf_filter* h) {
-  if (h->cfg.masked) {           // this step's masked Gram, observed count, eta, N, w / N (psmf_masked.hip), before the sweep rewrites C
-    const int rc = enqueue_masked_gram(h);
-    if (rc) return rc;
-  }
   if (h->sp.rho_rows && h->cfg.coef_update) {      // non-uniform diagonal R: this step's weighted Gram, before the sweep rewrites C
     const int rc = enqueue_weighted_gram(h);
     if (rc) return rc;
@@ -246,6 +242,7 @@ int enqueue_step(psmf_filter* h) {
     const int rc = all_reduce_sum(h, h->st->red, h->geo.ps, h->stream);
     if (rc) return rc;
   }
+  if (h->cfg.masked) return enqueue_serial_mgram(h, 0);      // serial stage of this step beside the masked Gram of the next (psmf_masked.hip)
   launch_serial(h, 0);
   return PSMF_OK;
 }
@@ -562,29 +559,39 @@ int enqueue_gram_into(psmf_filter* h, double* Gout, const DevState* wst, const d
   if (h->use_coll) { const int rc = all_reduce_sum(h, Gout, (size_t)r * r, h->stream); if (rc) return rc; }
   return PSMF_OK;
 }
-constexpr int kMGramWG = 256;      // workgroups of the masked Gram (one partial each); r > 48 runs 4 waves per workgroup, else 8
+constexpr int kMGramWG = 256;      // workgroups of the masked Gram (one partial each)
 
+// psmf_serial_mgram: block 0 = the serial stage, blocks 1 .. kMGramWG = the masked Gram of the next step (psmf_masked.hip)
 template <typename T>
-void launch_mgram(psmf_filter* h) {
-  const int nt = (h->cfg.r + 15) / 16;
-  const uint8_t* mk = h->mask;
-  switch (nt) {
-    case 1: hipLaunchKernelGGL((psmf::psmf_mgram_mfma<T, 1, 8>), dim3(kMGramWG), dim3(512), 0, h->stream, h->sp, mk, h->gpart); break;
-    case 2: hipLaunchKernelGGL((psmf::psmf_mgram_mfma<T, 2, 8>), dim3(kMGramWG), dim3(512), 0, h->stream, h->sp, mk, h->gpart); break;
-    case 3: hipLaunchKernelGGL((psmf::psmf_mgram_mfma<T, 3, 8>), dim3(kMGramWG), dim3(512), 0, h->stream, h->sp, mk, h->gpart); break;
-    default: hipLaunchKernelGGL((psmf::psmf_mgram_mfma<T, 4, 4>), dim3(kMGramWG), dim3(256), 0, h->stream, h->sp, mk, h->gpart); break;
-  }
+int launch_serial_mgram_t(psmf_filter* h, int first) {
+  const int r = h->cfg.r, rpad = h->geo.rpad;
+  const dim3 grid(1 + kMGramWG);
+#define PSMF_SM_LAUNCH(RPAD_, NT_, NW_)                                                                                     \
+  do {                                                                                                                      \
+    const size_t lds_ = (size_t)psmf::mgram_lds_doubles(NT_, NW_) * sizeof(double);                                         \
+    static bool attr_[2] = {false, false};                                                                                  \
+    if (!attr_[sizeof(T) == 8]) {                                                                                           \
+      HIP_TRY(h, hipFuncSetAttribute((const void*)psmf::psmf_serial_mgram<RPAD_, T, NT_, NW_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_)); \
+      attr_[sizeof(T) == 8] = true;                                                                                         \
+    }                                                                                                                       \
+    hipLaunchKernelGGL((psmf::psmf_serial_mgram<RPAD_, T, NT_, NW_>), grid, dim3(NW_ * 64), lds_, h->stream, h->sp, first, h->gpart); \
+  } while (0)
+  if (rpad == 8) PSMF_SM_LAUNCH(8, 1, 16);
+  else if (rpad == 16) PSMF_SM_LAUNCH(16, 1, 16);
+  else if (rpad == 32) PSMF_SM_LAUNCH(32, 2, 8);
+  else if (r <= 48) PSMF_SM_LAUNCH(64, 3, 4);
+  else PSMF_SM_LAUNCH(64, 4, 4);
+#undef PSMF_SM_LAUNCH
+  return PSMF_OK;
 }
 
-int enqueue_masked_gram(psmf_filter* h) {
-  const int r = h->cfg.r, ne = r * r + 1;
-  if (h->cfg.storage == PSMF_F64) launch_mgram<double>(h); else launch_mgram<float>(h);
+// serial stage of the step + masked Gram of the next, then the Gram's fixed-order reduction (and its all-reduce over the shards)
+int enqueue_serial_mgram(psmf_filter* h, int first) {
+  int rc = h->cfg.storage == PSMF_F64 ? launch_serial_mgram_t<double>(h, first) : launch_serial_mgram_t<float>(h, first);
+  if (rc) return rc;
+  const int ne = h->cfg.r * h->cfg.r + 1;
   hipLaunchKernelGGL(psmf::psmf_mgram_reduce, dim3((ne + 63) / 64), dim3(512), 0, h->stream, (const double*)h->gpart, (int)kMGramWG, ne, h->mg);
-  if (h->use_coll) {
-    const int rc = all_reduce_sum(h, h->mg, (size_t)ne, h->stream);
-    if (rc) return rc;
-  }
-  hipLaunchKernelGGL(psmf::psmf_masked_prep, dim3(1), dim3(psmf::WG), 0, h->stream, h->sp, (const double*)h->mg, h->sc_hist);
+  if (h->use_coll) return all_reduce_sum(h, h->mg, (size_t)ne, h->stream);
   return PSMF_OK;
 }
 
@@ -686,7 +693,12 @@ int prepare(psmf_filter* h, int64_t k_begin) {
     int rc = enqueue_gram(h);
     if (rc != PSMF_OK) return rc;
   }
-  launch_serial(h, 1);
+  if (h->cfg.masked) {      // + the masked Gram of the run's first step (psmf_prepare_k set kq = k_begin)
+    const int rc = enqueue_serial_mgram(h, 1);
+    if (rc) return rc;
+  } else {
+    launch_serial(h, 1);
+  }
   HIP_TRY(h, hipGetLastError());
   h->need_prep = false;
   h->k_done = k_begin;
@@ -918,7 +930,7 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
   sp.rho_rows = nullptr; sp.rho_mean = 1.0;
   sp.recursive = cfg->recursive; sp.update_every = cfg->update_every > 0 ? cfg->update_every : 1;
   sp.track_g = ((cfg->eta_full || cfg->coef_update) && !cfg->masked) ? 1 : 0;     // masked: G is this step's masked Gram, recomputed every step
-  sp.mask = nullptr;
+  sp.mask = nullptr; sp.mg = nullptr; sp.sc_hist = nullptr; sp.mask_rows = 0;
   sp.masked_method = cfg->masked >= 2 ? cfg->masked : 0;
   sp.solve_lds = Switches::off("PSMF_STEP_WAVE_SOLVE") ? 1 : 0;
   sp.external_reduce = 0;
@@ -1101,6 +1113,9 @@ int psmf_upload_series(psmf_handle h, const void* Y, int dtype, int64_t t0, int6
       HIP_TRY(h, hipMalloc((void**)&h->sc_hist, (size_t)T_total * 2 * sizeof(double)));
       HIP_TRY(h, hipMemset(h->sc_hist, 0, (size_t)T_total * 2 * sizeof(double)));
       h->sp.mask = h->mask;
+      h->sp.mg = h->mg;
+      h->sp.sc_hist = h->sc_hist;
+      h->sp.mask_rows = (int)T_total;
     }
     HIP_TRY(h, hipMalloc(&h->Y, (size_t)T_total * dl * es));
     if (h->cfg.store_y_pred) HIP_TRY(h, hipMalloc(&h->YP, (size_t)T_total * dl * es));

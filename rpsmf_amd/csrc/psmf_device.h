@@ -34,6 +34,7 @@ struct DevState {
   double phi, omega, ee;  // scalars of the last finished step
   double s_done, eta_done, N_done;  // s, eta, N of the last finished step
   double sgd_gamma;       // masked_method 2 / 3: the pass's step size gam = 1e-6 / (pass + 1)^0.7 (MLESMF.py:59-60, TMF.py:46-48), set by the host
+  long long kq;           // masked handle: series index of the step whose masked Gram the next psmf_serial_mgram launch computes (= k + 1 during a run)
   long long k;            // number of finished steps = 0-based series index of the current step
   int err;                // != 0: numeric failure (singular system) at step err
   int ns_valid;           // != 0: Lbar / XpX / XpY describe the current state; 3: so does the f3_* dump (cleared by every host state upload);
@@ -78,6 +79,9 @@ struct StepParams {
   double rho_mean;
   // masked filter (cfg.masked, psmf_masked.hip): T_cap x d_local observation mask, time-major like Y (1 = observed); nullptr = all observed
   const uint8_t* mask;
+  const double* mg;     // masked: r*r + 1 doubles -- masked Gram G_m and observed count of the CURRENT step, summed over workgroups and ranks
+  double* sc_hist;      // masked: T_cap x 2, (s, eta) of every step (the bands of the pass metrics are formed from them)
+  int mask_rows;        // masked: rows of the mask buffer (T_cap)
   // per-step engine, random walk with Q = q I (r <= 32): the two r x r inversions of a step side by side on two waves
   // of the solve block -- P+ = M^-1, M = Lbar + kappa G, and W = (M / beta + I / q)^-1, from which the serial stage forms
   // Lbar' = Pbar'^-1 = (I / q - W / q^2) / omega for the next step (the Woodbury form of filter3): ONE sweep on

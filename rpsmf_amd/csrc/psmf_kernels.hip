@@ -41,7 +41,7 @@ template <> struct VecOf<double> { typedef double __attribute__((ext_vector_type
 
 // start of a run: step counter.  The numeric-error flag is NOT cleared here: runs may be queued back to back without a
 // sync in between, and a failure in an earlier one must still be reported by the next psmf_sync (cleared by psmf_set_state).
-__global__ void psmf_prepare_k(DevState* st, long long k) { st->k = k; if (st->ns_valid == 7) st->ns_valid = 0; }   // (7: the per-step engine's carried Lbar -- a new run re-derives it)
+__global__ void psmf_prepare_k(DevState* st, long long k) { st->k = k; st->kq = k; if (st->ns_valid == 7) st->ns_valid = 0; }   // (7: the per-step engine's carried Lbar -- a new run re-derives it)
 // end of a run: the numeric-error flag to mapped host memory (system-scope store)
 __global__ void psmf_publish_err_k(const DevState* st, int* host_flag) { __hip_atomic_store(host_flag, st->err, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 
@@ -236,6 +236,51 @@ __device__ __forceinline__ void solve_block(const StepParams& p, double* sm) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Masked step (psmf_masked.hip), start of every workgroup of the sweep: eta, N of the step from the reduced masked Gram
+//   eta = (rho n_obs + <G_m, Pbar>) / d   (divided by d, ExperimentImpute/PSMF.py:77),   N = s + eta
+// p.mg[0 .. r*r) = G_m, p.mg[r*r] = n_obs (summed over workgroups and ranks).  Every workgroup forms the same sums in the same
+// order (same bits everywhere); `publish` (block 0, before its solve): st->G (symmetrised), eta, N, kappa and the step's (s, eta)
+// for the bands.  Returns in sc[0..2]: eta, N, and the factor in front of the update direction (1 / N for PSMF / rPSMF).
+// masked_method 2 (MLE-SMF): weights m_i / rho (s does not enter), direction (gam / eta) mu_bar;  3 (TMF): kappa = 1, gam mu_bar.
+// sm: 16 doubles of LDS.  All threads of the workgroup call it.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void masked_prep_block(const StepParams& p, double* sm, const bool publish, double (&sc)[3]) {
+  DevState* st = p.st;
+  const int r = p.r, tid = threadIdx.x, nthr = blockDim.x;
+  const double* __restrict__ mg = p.mg;
+  double gp = 0.0;
+  for (int q = tid; q < r * r; q += nthr) {
+    const int i = q / r, j = q - i * r;
+    const double g = 0.5 * (mg[q] + mg[j * r + i]);     // both triangles identical
+    if (publish) st->G[q] = g;
+    gp += g * 0.5 * (st->Pbar[q] + st->Pbar[j * r + i]);
+  }
+  gp = wave_sum(gp);
+  if ((tid & 63) == 0) sm[tid >> 6] = gp;
+  __syncthreads();
+  double tr = 0.0;
+  for (int w = 0; w < (nthr >> 6); ++w) tr += sm[w];
+  const int meth = p.masked_method;
+  const double s = meth ? 0.0 : st->s, rho = st->rho;
+  const double eta = (rho * mg[r * r] + tr) / (double)p.d;
+  const double N = s + eta;
+  sc[0] = eta; sc[1] = N;
+  sc[2] = meth == 0 ? fast_rcp(N) : (meth == 2 ? st->sgd_gamma * fast_rcp(eta) : st->sgd_gamma);
+  if (publish && tid == 0) {
+    st->eta = eta;
+    st->N = N;
+    st->kappa = meth == 3 ? 1.0 : fast_rcp(rho + s);
+    st->kq = st->k + 1;               // the Gram that the serial-stage launch computes beside the serial stage is the NEXT step's
+    if (p.sc_hist) {
+      const long long t = st->k - p.series_t0;
+      p.sc_hist[2 * t] = s;
+      p.sc_hist[2 * t + 1] = eta;
+    }
+  }
+  __syncthreads();                    // sm is reused by the caller; block 0: G, kappa are in memory before its solve reads them
+}
+
+// ------------------------------------------------------------------------------------------
 // Row sweep.  GS = lanes cooperating on one row (power of two >= nv = ceil(r / VEC)); each lane
 // owns one 16-byte vector of the row; a 256-thread workgroup covers 256/GS rows per pass and
 // keeps U passes of loads in flight.
@@ -251,6 +296,11 @@ __global__ __launch_bounds__(NT) void psmf_sweep_solve(StepParams p) {
 
   // block 0 runs the r x r solve (dispatched first: it is the longest block)
   const int has_solve = p.coef_update;
+  double msc[3] = {0.0, 0.0, 0.0};
+  // masked step: eta, N from the step's Gram -- every row workgroup for itself; block 0 publishes them: by a wave of its own beside
+  // the solve waves when the solve is wave-local (r <= 32), else by the whole block before the LDS solve
+  const bool solve_here = has_solve && blockIdx.x == 0;
+  if (p.mask && !(solve_here && p.r <= 32 && !p.solve_lds)) masked_prep_block(p, sm, solve_here, msc);
   if (has_solve && blockIdx.x == 0) {
     // (raising the solve waves' issue priority on the CU they share with a row-sweep workgroup was measured neutral: the block
     //  is a chain of LDS exchanges and barriers, not short of issue slots)
@@ -275,6 +325,7 @@ __global__ __launch_bounds__(NT) void psmf_sweep_solve(StepParams p) {
     const int e = j * VEC + v;
     mub[v] = e < r ? st->mu_bar[e] : 0.0;
     wn[v] = e < r ? st->wN[e] : 0.0;
+    if (p.mask) wn[v] = e < r ? (p.masked_method == 0 ? st->w[e] : st->mu_bar[e]) * msc[2] : 0.0;      // direction of the rank-1 update of C
   }
   double hacc[VEC];
 #pragma unroll

@@ -12,9 +12,10 @@
 // m_i / rho, C += gam / eta (m o e) x_p^T, bands -+ sig sqrt(eta): MLESMF.py:57-88) and TMF (Pbar = I / nu, kappa = 1, C += gam (m o e) x_p^T:
 // TMF.py:47-66).
 //
-// A step is: psmf_mgram_mfma -> psmf_mgram_reduce (-> all-reduce of r^2 + 1 doubles) -> psmf_masked_prep (eta, N, w / N, kappa and
-// the step's (s, eta) into the history the bands are formed from) -> psmf_sweep_solve with the mask (-> all-reduce of r + 1 doubles)
-// -> psmf_serial.  The metrics of a pass (RMSE of the predictions and of C X over the held-out entries, coverage of the bands:
+// A step is: psmf_sweep_solve with the mask -- every workgroup first forms eta, N, the update direction from the step's reduced Gram
+// (masked_prep_block, psmf_kernels.hip; block 0 publishes them and the step's (s, eta) for the bands) -- (-> all-reduce of r + 1
+// doubles) -> psmf_serial_mgram: the serial stage of the step in block 0 and, beside it, the masked Gram of the NEXT step in the other
+// blocks -> psmf_mgram_reduce (-> all-reduce of r^2 + 1 doubles).  The metrics of a pass (RMSE of the predictions and of C X over the held-out entries, coverage of the bands:
 // ExperimentImpute/common.py:79-94) are reduced on the device by psmf_masked_metrics_k; nothing d x n travels.
 #pragma once
 #include "psmf_kernels.hip"
@@ -31,53 +32,69 @@ namespace psmf {
 // LDS row stride S == 16 (mod 32) doubles: the two rows a half-wave reads sit 32 banks apart (conflict-free ds_read_b64).
 __host__ __device__ constexpr int mgram_stride(int nt) { return nt == 1 ? 16 : (nt <= 3 ? 48 : 80); }
 
+__host__ __device__ constexpr int mgram_lds_doubles(int nt, int nw) {
+  return (nw * 16 * mgram_stride(nt) > nt * nt * 256 ? nw * 16 * mgram_stride(nt) : nt * nt * 256) + nw;
+}
+
+// sZ: mgram_lds_doubles(NT, NW) doubles of LDS (dynamic: the serial stage of the same kernel has its own static arrays)
 template <typename T, int NT, int NW>
-__global__ __launch_bounds__(NW * 64) void psmf_mgram_mfma(StepParams p, const uint8_t* __restrict__ mask, double* __restrict__ gpart) {
+__device__ __forceinline__ void mgram_body(const StepParams& p, double* __restrict__ gpart, const int bid, const int nblk, double* sZ) {
   constexpr int S = mgram_stride(NT);
   constexpr int NTT = NT * (NT + 1) / 2;
-  __shared__ double sZ[NW * 16 * S > NT * NT * 256 ? NW * 16 * S : NT * NT * 256];
-  __shared__ double sCnt[NW];
+  double* sCnt = sZ + (mgram_lds_doubles(NT, NW) - NW);
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, lr = lane & 15, lk = lane >> 4;
   const int r = p.r, rp = p.rp, dl = p.d_local;
   const T* __restrict__ C = reinterpret_cast<const T*>(p.C);
-  const uint8_t* __restrict__ mk = mask + (size_t)(p.st->k - p.series_t0) * dl;
+  // the step whose Gram this is: st->kq (written by the previous kernel; the serial stage running beside these blocks advances
+  // st->k, not kq); clamped: the Gram "of the step after the last" is computed and never used
+  long long trow = p.st->kq - p.series_t0;
+  if (trow > (long long)p.mask_rows - 1) trow = (long long)p.mask_rows - 1;
+  const uint8_t* __restrict__ mk = p.mask + (size_t)trow * dl;
   double* slab = sZ + w * 16 * S;
   for (int idx = lane; idx < 16 * S; idx += 64) slab[idx] = 0.0;        // columns rp .. 16 NT stay zero
   f64x4 acc[NTT];
 #pragma unroll
   for (int t = 0; t < NTT; ++t) acc[t] = f64x4{0.0, 0.0, 0.0, 0.0};
   double cnt = 0.0;
-  const int nslab = (dl + 15) / 16, stride = gridDim.x * NW;
-  const int cl = lane < rp ? lane : 0;
-  const bool con = lane < rp;
-  int sl = blockIdx.x * NW + w;
-  T v[16];
-  uint8_t m[16];
-  if (sl < nslab) {
+  const int nslab = (dl + 15) / 16, stride = nblk * NW;
+  // a slab = 16 rows x rp elements, contiguous: 16-byte vectors lane, lane + 64, ... of it (rp is a multiple of the vector length)
+  constexpr int VEC = 16 / sizeof(T);
+  constexpr int NV = (16 * 16 * NT / VEC + 63) / 64;         // vectors per lane at most (rp <= 16 NT)
+  typedef typename VecOf<T>::type VT;
+  int vrow[NV], vcol[NV];
+  bool von[NV];
 #pragma unroll
-    for (int rr = 0; rr < 16; ++rr) {
-      const int row = min(sl * 16 + rr, dl - 1);
-      v[rr] = C[(size_t)row * rp + cl];
-      m[rr] = mk[row];
-    }
+  for (int i = 0; i < NV; ++i) {
+    const int e = VEC * (lane + 64 * i);
+    von[i] = e < 16 * rp;
+    vrow[i] = von[i] ? e / rp : 0;
+    vcol[i] = von[i] ? e - vrow[i] * rp : 0;
   }
+  int sl = bid * NW + w;
+  VT v[NV];
+  uint8_t m[NV];
+  auto load_slab = [&](const int s_) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int row = min(s_ * 16 + vrow[i], dl - 1);
+      v[i] = *reinterpret_cast<const VT*>(C + (size_t)row * rp + vcol[i]);
+      m[i] = mk[row];
+    }
+  };
+  if (sl < nslab) load_slab(sl);
   for (; sl < nslab; sl += stride) {
     const int row0 = sl * 16;
 #pragma unroll
-    for (int rr = 0; rr < 16; ++rr) {
-      const bool on = (row0 + rr < dl) && m[rr] != 0;
-      if (con) slab[rr * S + lane] = on ? (double)v[rr] : 0.0;
-      cnt += on ? 1.0 : 0.0;
+    for (int i = 0; i < NV; ++i) {
+      const bool on = von[i] && (row0 + vrow[i] < dl) && m[i] != 0;
+      if (von[i]) {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) slab[vrow[i] * S + vcol[i] + j] = on ? (double)v[i][j] : 0.0;
+      }
+      cnt += (on && vcol[i] == 0) ? 1.0 : 0.0;          // the lane that holds a row's first vector counts the row
     }
     const int nx = sl + stride;
-    if (nx < nslab) {                       // the next slab's loads fly during this slab's products
-#pragma unroll
-      for (int rr = 0; rr < 16; ++rr) {
-        const int row = min(nx * 16 + rr, dl - 1);
-        v[rr] = C[(size_t)row * rp + cl];
-        m[rr] = mk[row];
-      }
-    }
+    if (nx < nslab) load_slab(nx);          // the next slab's loads fly during this slab's products
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the wave's own LDS stores (global loads stay in flight)
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -93,29 +110,41 @@ __global__ __launch_bounds__(NW * 64) void psmf_mgram_mfma(StepParams p, const u
     }
     __builtin_amdgcn_wave_barrier();        // all lanes have read the image before it is overwritten
   }
-  // ---- sum of the waves' tiles in wave order (fixed), then the workgroup's partial: both triangles
+  // ---- sum of the waves' tiles by a fixed tree (waves [h, 2h) into [0, h), h = NW / 2, NW / 4, .. 1), then the workgroup's partial
   __syncthreads();
-  double* buf = sZ;                           // [tile ta * NT + tb][q][lane]
-  for (int ww = 0; ww < NW; ++ww) {
-    if (w == ww) {
-      int tt = 0;
+  double* buf = sZ;                           // slot x [upper tile][q][lane]
+  for (int hlf = NW / 2; hlf >= 1; hlf >>= 1) {
+    if (w >= hlf && w < 2 * hlf) {
+      double* o = buf + (size_t)(w - hlf) * NTT * 256;
 #pragma unroll
-      for (int ta = 0; ta < NT; ++ta)
+      for (int tt = 0; tt < NTT; ++tt)
 #pragma unroll
-        for (int tb = ta; tb < NT; ++tb, ++tt)
+        for (int q = 0; q < 4; ++q) o[(tt * 4 + q) * 64 + lane] = acc[tt][q];
+    }
+    __syncthreads();
+    if (w < hlf) {
+      const double* o = buf + (size_t)w * NTT * 256;
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            double* o = buf + ((ta * NT + tb) * 4 + q) * 64 + lane;
-            *o = (ww == 0 ? 0.0 : *o) + acc[tt][q];
-          }
+      for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[tt][q] += o[(tt * 4 + q) * 64 + lane];
     }
     __syncthreads();
   }
-  cnt = readlane_f64(cnt, 0);                 // every lane of a wave counted the same rows
+  if (w == 0) {                               // full tile grid [ta * NT + tb] (upper tiles) for the write-out below
+    int tt = 0;
+#pragma unroll
+    for (int ta = 0; ta < NT; ++ta)
+#pragma unroll
+      for (int tb = ta; tb < NT; ++tb, ++tt)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) buf[((ta * NT + tb) * 4 + q) * 64 + lane] = acc[tt][q];
+  }
+  cnt = wave_sum(cnt);
   if (lane == 0) sCnt[w] = cnt;
   __syncthreads();
   const size_t gs = (size_t)r * r + 1;
-  double* out = gpart + (size_t)blockIdx.x * gs;
+  double* out = gpart + (size_t)bid * gs;
   for (int idx = tid; idx < r * r; idx += NW * 64) {
     int i = idx / r, j = idx - i * r;
     if ((i >> 4) > (j >> 4)) { const int t_ = i; i = j; j = t_; }      // lower tiles: the transposed entry of the upper one
@@ -127,6 +156,18 @@ __global__ __launch_bounds__(NW * 64) void psmf_mgram_mfma(StepParams p, const u
     for (int ww = 0; ww < NW; ++ww) c += sCnt[ww];
     out[(size_t)r * r] = c;
   }
+}
+
+// One launch for the serial stage of step k (block 0: psmf_serial's body, psmf_kernels.hip) AND the masked Gram of step k + 1 (blocks
+// 1 .. : mgram_body): both need only what the sweep of step k left behind -- the partial sums and P+ the one, the updated C the
+// other -- so they run side by side instead of one after the other (the serial stage is ~9 us of one workgroup's latency, the Gram
+// ~12 us of matrix-core work on every CU).  RPAD / NT / NW: serial_threads(RPAD) == 64 NW.  `first`: psmf_serial's flag (start of a run).
+template <int RPAD, typename T, int NT, int NW>
+__global__ __launch_bounds__(NW * 64) void psmf_serial_mgram(StepParams p, int first, double* __restrict__ gpart) {
+  static_assert(serial_threads(RPAD) == NW * 64, "block 0 runs the serial stage: same workgroup size");
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  if (blockIdx.x == 0) serial_body<RPAD>(p, first);
+  else mgram_body<T, NT, NW>(p, gpart, (int)blockIdx.x - 1, (int)gridDim.x - 1, reinterpret_cast<double*>(smem_raw));
 }
 
 // gpart (n_part rows of ne doubles) -> out[ne], every entry summed in the fixed order of the partials: 512 threads = 64 entries x 8
@@ -151,41 +192,6 @@ __global__ __launch_bounds__(512) void psmf_mgram_reduce(const double* __restric
 #pragma unroll
     for (int q = 0; q < 8; ++q) t += s8[q][threadIdx.x];
     out[e] = t;
-  }
-}
-
-// One workgroup: mg[0 .. r*r) = G_m, mg[r*r] = n_obs (already summed over workgroups and ranks) -> st->G, eta, N, w / N, kappa of
-// the step st->k, and (s, eta) of the step into sc_hist (bands of the metrics kernel).
-__global__ __launch_bounds__(WG) void psmf_masked_prep(StepParams p, const double* __restrict__ mg, double* __restrict__ sc_hist) {
-  DevState* st = p.st;
-  const int r = p.r, tid = threadIdx.x;
-  __shared__ double s4[4];
-  double gp = 0.0;
-  for (int q = tid; q < r * r; q += WG) {
-    const int i = q / r, j = q - i * r;
-    const double g = 0.5 * (mg[q] + mg[j * r + i]);     // both triangles identical (the partial sums are symmetric up to the order of one product)
-    st->G[q] = g;
-    gp += g * 0.5 * (st->Pbar[q] + st->Pbar[j * r + i]);
-  }
-  gp = wave_sum(gp);
-  if ((tid & 63) == 0) s4[tid >> 6] = gp;
-  __syncthreads();
-  const double tr = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-  const int meth = p.masked_method;
-  const double s = meth ? 0.0 : st->s, rho = st->rho;
-  const double eta = (rho * mg[r * r] + tr) / (double)p.d;
-  const double N = s + eta;
-  // the direction of the rank-1 update of C: PSMF  w / N (w = V mu_bar);  MLE-SMF  (gam / eta) mu_bar;  TMF  gam mu_bar
-  if (tid < r) st->wN[tid] = meth == 0 ? st->w[tid] * fast_rcp(N) : st->mu_bar[tid] * (meth == 2 ? st->sgd_gamma * fast_rcp(eta) : st->sgd_gamma);
-  if (tid == 0) {
-    st->eta = eta;
-    st->N = N;
-    st->kappa = meth == 3 ? 1.0 : fast_rcp(rho + s);
-    if (sc_hist) {
-      const long long t = st->k - p.series_t0;
-      sc_hist[2 * t] = s;
-      sc_hist[2 * t + 1] = eta;
-    }
   }
 }
 

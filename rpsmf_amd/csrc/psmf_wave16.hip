@@ -86,13 +86,53 @@ __device__ __forceinline__ void wave_sweep16m(double (&A)[4], const int r2, cons
 //   otherwise:  wave 0  -Pbar^-1, then M = Pbar^-1 + kappa G (or the weighted Gram of a non-uniform R), P+ = M^-1.
 // All other waves of the block retire at once.
 // ------------------------------------------------------------------------------------------------------------
+// masked step, block 0 of the sweep: what masked_prep_block(publish) does, by ONE wave (no workgroup barrier: the solve waves of the
+// same block start at once) -- st->G (symmetrised), eta, N, kappa, the next Gram's step index, the step's (s, eta) for the bands
+__device__ __forceinline__ void masked_prep_wave(const StepParams& p) {
+  DevState* st = p.st;
+  const int r = p.r, lane = threadIdx.x & 63;
+  const double* __restrict__ mg = p.mg;
+  // the same products summed in the same grouping as masked_prep_block does with the whole workgroup (thread t: q = t, t + nthr, ..;
+  // per-wave sums, then the waves in order): the eta published here has the bits of the eta the row workgroups update C with
+  const int nthr = blockDim.x;
+  double tr = 0.0;
+  for (int vw = 0; vw < (nthr >> 6); ++vw) {
+    double gp = 0.0;
+    for (int q = vw * 64 + lane; q < r * r; q += nthr) {
+      const int i = q / r, j = q - i * r;
+      const double g = 0.5 * (mg[q] + mg[j * r + i]);
+      st->G[q] = g;
+      gp += g * 0.5 * (st->Pbar[q] + st->Pbar[j * r + i]);
+    }
+    tr += wave_sum(gp);
+  }
+  const int meth = p.masked_method;
+  const double s = meth ? 0.0 : st->s, rho = st->rho;
+  const double eta = (rho * mg[r * r] + tr) / (double)p.d;
+  if (lane == 0) {
+    st->eta = eta;
+    st->N = s + eta;
+    st->kappa = meth == 3 ? 1.0 : fast_rcp(rho + s);
+    st->kq = st->k + 1;
+    if (p.sc_hist) {
+      const long long t = st->k - p.series_t0;
+      p.sc_hist[2 * t] = s;
+      p.sc_hist[2 * t + 1] = eta;
+    }
+  }
+}
+
 template <int NT>
 __device__ __forceinline__ void solve_block_wave_t(const StepParams& p) {
   DevState* st = p.st;
   const int r = p.r, r2 = r + (r & 1), w = threadIdx.x >> 6, lane = threadIdx.x & 63, lk = lane >> 4, lr = lane & 15;
   const bool dual = p.solve_dual != 0, carried = dual && st->ns_valid == 7;
+  if (p.mask && w == 2) { masked_prep_wave(p); return; }     // masked step: one more wave publishes eta, N, G, ... beside the solve
   if (w > (carried ? 1 : 0)) return;
-  const double kappa = st->kappa;
+  // masked step: the Gram of the step is p.mg (reduced over workgroups and ranks), not yet in st->G -- the publishing wave writes it
+  // there while this one reads it at the source; kappa = 1 / (rho + s) (MLE-SMF: 1 / rho, TMF: 1) does not wait for eta either
+  const double* __restrict__ Gsrc = p.mask ? p.mg : st->G;
+  const double kappa = p.mask ? (p.masked_method == 3 ? 1.0 : fast_rcp(st->rho + (p.masked_method ? 0.0 : st->s))) : st->kappa;
   double A[NT][NT][4], Gk[NT][NT][4];
   bool bad = false;
   auto at = [&](const double* Mx, const int i, const int c) { return 0.5 * (Mx[i * r + c] + Mx[c * r + i]); };
@@ -106,7 +146,7 @@ __device__ __forceinline__ void solve_block_wave_t(const StepParams& p) {
         (void)pad; (void)ic; (void)cc;                                                 \
         body                                                                           \
       }
-  WS_FOR({ Gk[ti][tj][q] = in ? (p.rho_rows ? st->GR[ic * r + cc] : kappa * st->G[ic * r + cc]) : 0.0; })
+  WS_FOR({ Gk[ti][tj][q] = in ? (p.rho_rows ? st->GR[ic * r + cc] : kappa * at(Gsrc, ic, cc)) : 0.0; })
   if (carried) {
     const double iq = 1.0 / st->Q[0], ib = p.robust ? 1.0 / p.beta : 1.0;
     WS_FOR({

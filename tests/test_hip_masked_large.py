@@ -91,7 +91,7 @@ def test_baseline_filters_beyond_the_small_engine():
 @pytest.mark.parametrize("robust", [False, True], ids=["PSMF", "rPSMF"])
 def test_masked_engine_two_shards_on_one_gpu(robust):
     """cfg.masked on two row shards (uneven), host communicator: gathered C, y_hat, summed metrics = the unsharded handle and the
-    oracle; replicated V, P, mu, X bit-identical across the shards; message sizes r^2 + 1 and r + 1 per step."""
+    oracle; replicated V, P, mu, X bit-identical across the shards; message sizes r^2 + 1 and r + 1 per step (the Gram one step ahead)."""
     from rpsmf_amd import _capi as c
     from test_hip_multishard import HostGroup
 
@@ -144,7 +144,9 @@ def test_masked_engine_two_shards_on_one_gpu(robust):
     assert relerr(Cg, st["C"]) < 1e-9 and relerr(out[0]["X"].T, st["X"]) < 1e-9 and relerr(ypg.T, st["Yrec"]) < 1e-9
     assert relerr(np.sqrt(m[0] / m[3]), ep[0, 1]) < 1e-9 and relerr(np.sqrt(m[1] / m[3]), ef[0, 1]) < 1e-9 and abs(m[2] / m[3] - ib) < 1e-12
     assert m[3] == Mmiss.sum() == whole["m"][3] and m[2] == whole["m"][2]                      # the two counts are integers: equal exactly
-    assert set(grp.sizes) == {r * r + 1, r + 1} and grp.sizes.count(r * r + 1) == n and grp.sizes.count(r + 1) == n
+    # one (h, ee) message per step; one masked Gram per step, computed a step ahead beside the serial stage: + the first step's at the
+    # start of the run (the Gram of 'the step after the last' of each of the two runs is computed and unused: n + 1 in all)
+    assert set(grp.sizes) == {r * r + 1, r + 1} and grp.sizes.count(r * r + 1) == n + 1 and grp.sizes.count(r + 1) == n
     # negative control: without the exchange the shards do NOT reproduce the filter
     solo = c.DeviceFilter(d, r, row0=0, d_local=shard_rows(d, nsh, 0)[1], **kw)
     bad = run(solo, 0, shard_rows(d, nsh, 0)[1])
