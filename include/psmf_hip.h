@@ -229,7 +229,8 @@ int psmf_geometry(psmf_handle h, int32_t* out7);
  * last uploaded, schedules, switches): 0 = per-step engine (psmf_sweep_solve + psmf_serial), 1 = psmf_blk_filter (general blocked
  * kernel), 2 = psmf_blk_filter2, 3 = psmf_blk_filter3, 4 = psmf_blk_filter3s, 5 = psmf_blk_filter4, 6 = psmf_blk_filter4s, 7 = psmf_blk_filter5,
  * 8 = psmf_blk_filter6 (every configuration at r <= 16 but the simplified hooks), 9 = psmf_blk_filter6d (its instantiation with the two
- * inversions side by side: random walk, Q = q I).  The same function decides what is launched (select_filter_kernel, psmf_capi.hip).
+ * inversions side by side: random walk, Q = q I), 10 = psmf_blk_filter7 (the same design on 2 x 2 tiles: what is left at 17 <= r <= 32).
+ * The same function decides what is launched (select_filter_kernel, psmf_capi.hip).
  * (New: diagnostics for tests and bench.py -- the reference has one code path, pypsmf/psmf/psmf.py:90-102.) */
 int psmf_filter_kernel(psmf_handle h);
 /* diagnostics of the blocked engine's r x r inversions since the last reset: out[0] = timesteps inverted by

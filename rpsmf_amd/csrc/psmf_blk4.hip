@@ -64,7 +64,9 @@ __device__ __forceinline__ void f4_sweep_image(const F3Lds& L, double* im, const
         const int i = lk + 4 * q;
         A[0][0][q] = (i < r2 && lr < r2) ? im[i * F3_S + lr] : (i == lr ? 1.0 : 0.0);
       }
-      wave_sweep_tiles<1>(A, r2, lk, lr, bad);
+      Sw16K swk;
+      sw16k_init(swk, lk, lr);
+      wave_sweep_tiles_m<1>(A, r2, swk, bad);
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int i = lk + 4 * q;
@@ -81,7 +83,9 @@ __device__ __forceinline__ void f4_sweep_image(const F3Lds& L, double* im, const
             const int i = 16 * ti + lk + 4 * q, c = 16 * tj + lr;
             A[ti][tj][q] = (i < r2 && c < r2) ? im[i * F3_S + c] : (i == c ? 1.0 : 0.0);
           }
-      wave_sweep_tiles<2>(A, r2, lk, lr, bad);
+      Sw16K swk;
+      sw16k_init(swk, lk, lr);
+      wave_sweep_tiles_m<2>(A, r2, swk, bad);
 #pragma unroll
       for (int ti = 0; ti < 2; ++ti)
 #pragma unroll

@@ -8,6 +8,7 @@
 #include "psmf_block.hip"
 #include "psmf_blk3.hip"
 #include "psmf_blk16.hip"
+#include "psmf_blk32.hip"
 #include "psmf_bulk.hip"
 
 #include <rccl/rccl.h>
@@ -42,11 +43,11 @@ constexpr int kGramWG = 128;
 // Environment switches ("Switches"): read ONCE per handle, at psmf_create -- tests flip them between
 // handles of one process; nothing on the per-block host path calls getenv.
 struct Switches {
-  bool block_mfma = true, bulk2 = true, filter3 = true, filter4 = true, filter6 = true, filter6_dual = true, block_dual = true, block_flags = true, block_chain = true, block_pipe = true;
+  bool block_mfma = true, bulk2 = true, filter3 = true, filter4 = true, filter6 = true, filter7 = true, filter6_dual = true, block_dual = true, block_flags = true, block_chain = true, block_pipe = true;
   bool force_collective = false;
   static bool off(const char* name) { const char* e = getenv(name); return e && atoi(e) == 0; }
   void read() {
-    block_mfma = !off("PSMF_BLOCK_MFMA"); bulk2 = !off("PSMF_BULK2"); filter3 = !off("PSMF_FILTER3"); filter4 = !off("PSMF_FILTER4"); filter6 = !off("PSMF_FILTER6"); filter6_dual = !off("PSMF_FILTER6_DUAL"); block_dual = !off("PSMF_BLOCK_DUAL");
+    block_mfma = !off("PSMF_BLOCK_MFMA"); bulk2 = !off("PSMF_BULK2"); filter3 = !off("PSMF_FILTER3"); filter4 = !off("PSMF_FILTER4"); filter6 = !off("PSMF_FILTER6"); filter7 = !off("PSMF_FILTER7"); filter6_dual = !off("PSMF_FILTER6_DUAL"); block_dual = !off("PSMF_BLOCK_DUAL");
     block_flags = !off("PSMF_BLOCK_FLAGS"); block_chain = !off("PSMF_BLOCK_CHAIN"); block_pipe = !off("PSMF_BLOCK_PIPE");
     force_collective = getenv("PSMF_FORCE_COLLECTIVE") != nullptr;
   }
@@ -343,7 +344,7 @@ bool blk_simpl_ok(const psmf_filter* h) {
 // and psmf_filter_kernel reports it (tests and bench.py quote that name as evidence of what ran).  Values = the codes of
 // psmf_filter_kernel in include/psmf_hip.h.
 enum FilterKernel { FK_STEP = 0, FK_GENERAL = 1, FK_FILTER2 = 2, FK_FILTER3 = 3, FK_FILTER3S = 4, FK_FILTER4 = 5, FK_FILTER4S = 6,
-                    FK_FILTER5 = 7, FK_FILTER6 = 8, FK_FILTER6D = 9 };
+                    FK_FILTER5 = 7, FK_FILTER6 = 8, FK_FILTER6D = 9, FK_FILTER7 = 10 };
 
 FilterKernel select_filter_kernel(const psmf_filter* h) {
   if (h->engine != 2) return FK_STEP;
@@ -353,7 +354,9 @@ FilterKernel select_filter_kernel(const psmf_filter* h) {
   if (blk_small_dual(h)) return FK_FILTER6D;      // random walk, Q = q I at r <= 16: filter6 with the two inversions side by side
   if (dual3) return h->cfg.r > 16 ? FK_FILTER3 : FK_FILTER3S;
   if (blk_dual_ok(h)) return FK_FILTER2;
-  return blk_small_ok(h) ? FK_FILTER6 : FK_GENERAL;
+  if (blk_small_ok(h)) return FK_FILTER6;
+  // 17 <= r <= 32, whatever is left (dense Jacobians, a general Q, ...): filter6's design on 2 x 2 tiles (psmf_blk32.hip)
+  return (h->sw.filter7 && h->cfg.r > psmf::F6_RMAX && h->cfg.r <= 32) ? FK_FILTER7 : FK_GENERAL;
 }
 
 void launch_blk_filter(psmf_filter* h, const psmf::BlockParams& b, hipStream_t stream = nullptr) {
@@ -381,6 +384,7 @@ void launch_blk_filter(psmf_filter* h, const psmf::BlockParams& b, hipStream_t s
       return;
     }
     case FK_FILTER6: hipLaunchKernelGGL(psmf::psmf_blk_filter6, dim3(1), dim3(psmf::WG), lds, stream, b); return;
+    case FK_FILTER7: hipLaunchKernelGGL(psmf::psmf_blk_filter7, dim3(1), dim3(psmf::WG), lds, stream, b); return;
     case FK_GENERAL:
     case FK_STEP:
       break;
@@ -890,6 +894,7 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
     const size_t flds = psmf::blk_filter_lds_bytes();
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_filter6, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_filter6d, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
+    CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_filter7, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_filter<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_filter<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));
     CREATE_TRY(hipFuncSetAttribute((const void*)psmf::psmf_blk_filter<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flds));

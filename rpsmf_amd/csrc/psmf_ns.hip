@@ -172,4 +172,84 @@ __device__ __forceinline__ void wave_sweep_tiles(double (&A)[NT][NT][4], const i
   }
 }
 
+// Per-lane constants of wave_sweep16m as numbers (lane: column lr = l & 15, rows lk + 4 q, lk = l >> 4); round j pivots on
+// rows / columns 2 j, 2 j + 1, which are register A[j >> 1] of the lane rows lk = 2 (j & 1), 2 (j & 1) + 1.
+struct Sw16K {
+  double pc0[8], pc1[8];   // lr == 2 j, lr == 2 j + 1
+  double fnp[8];           // 1 - pc0 - pc1: not a pivot column
+  double sg[8];            // lanes of the pivot rows: +1 at the pivot columns, -1 elsewhere; other lanes 0
+  double fpiv[2], fnpiv[2];   // lanes that hold the pivot rows (lk >> 1 == j & 1), and 1 - that
+  double fu, fw;           // lk even (row 2 j of the pair) / odd (row 2 j + 1)
+};
+__device__ __forceinline__ void sw16k_init(Sw16K& c, const int lk, const int lr) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    c.pc0[j] = lr == 2 * j ? 1.0 : 0.0;
+    c.pc1[j] = lr == 2 * j + 1 ? 1.0 : 0.0;
+    c.fnp[j] = 1.0 - c.pc0[j] - c.pc1[j];
+    const double piv = (lk >> 1) == (j & 1) ? 1.0 : 0.0;
+    c.sg[j] = piv * (2.0 * (c.pc0[j] + c.pc1[j]) - 1.0);
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) { c.fpiv[h] = (lk >> 1) == h ? 1.0 : 0.0; c.fnpiv[h] = 1.0 - c.fpiv[h]; }
+  c.fu = (lk & 1) == 0 ? 1.0 : 0.0;
+  c.fw = 1.0 - c.fu;
+}
+
+// wave_sweep_tiles with the lane predicates as multipliers (the form of wave_sweep16m, psmf_wave16.hip): a select of a double is two
+// v_cndmask and -- in kernels that have run out of SGPRs -- the reload of its lane mask from a spilled pair; a multiply by 0.0 / 1.0 is one
+// instruction.  The select form spent 24 v_cndmask and 8 mask reloads of the 89 instructions of a round (NT = 2, ISA of
+// psmf_blk_filter7); c: sw16k_init(lk, lr), tile-local (the pivot columns of a round lie in tile column tp only).
+template <int NT>
+__device__ __forceinline__ void wave_sweep_tiles_m(double (&A)[NT][NT][4], const int r2, const Sw16K& c, bool& bad) {
+#pragma unroll
+  for (int k = 0; k < 16 * NT; k += 2) {
+    if (k < r2) {                                  // uniform
+      const int tp = k >> 4, kl = k & 15, j = kl >> 1, h = j & 1, kq = j >> 1, b0 = h << 5, b1 = b0 + 16;
+      const double rkd = A[tp][tp][kq];
+      const double ka = readlane_f64(rkd, b0 | kl), kb = readlane_f64(rkd, b0 | (kl + 1)), ke = readlane_f64(rkd, b1 | (kl + 1));
+      const double det = ka * ke - kb * kb;
+      bad |= !(ka > 0.0) | !(det > 0.0);
+      const double x0 = __builtin_amdgcn_rcp(det);
+      const double e1 = fma(-det, x0, 1.0);
+      const double dinv = fma(x0 * e1, 1.0 + e1, x0);
+      // det * (row of Ki that belongs to this lane's pivot row): even row [ke, -kb], odd row [-kb, ka]
+      const double cu = c.fu * ke - c.fw * kb, cw = c.fw * ka - c.fu * kb;
+      double aop[NT], bop[NT];
+#pragma unroll
+      for (int tj = 0; tj < NT; ++tj) {
+        const double rk = A[tp][tj][kq];
+        const unsigned lo = __double2loint(rk), hi = __double2hiint(rk);
+        const auto l2 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        const auto h2 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        const double uj = __hiloint2double(h2[0], l2[0]), wj = __hiloint2double(h2[1], l2[1]);
+        double pre;
+        if (tj == tp) {            // (compile time) pivot columns: unit vectors -> the entries of Ki, with the opposite sign
+          const double u1 = fma(uj, c.fnp[j], c.pc0[j]), w1 = fma(wj, c.fnp[j], c.pc1[j]);
+          pre = fma(cu, u1, cw * w1) * c.sg[j];
+        } else {
+          pre = -fma(cu, uj, cw * wj) * c.fpiv[h];
+        }
+        aop[tj] = rk * c.fpiv[h];
+        bop[tj] = pre * dinv;
+      }
+#pragma unroll
+      for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < NT; ++tj) {
+          f64x4 acc = {A[ti][tj][0], A[ti][tj][1], A[ti][tj][2], A[ti][tj][3]};
+          if (tj == tp) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] *= c.fnp[j];
+          }
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(aop[ti], bop[tj], acc, 0, 0, 0);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) A[ti][tj][q] = acc[q];
+        }
+#pragma unroll
+      for (int tj = 0; tj < NT; ++tj) A[tp][tj][kq] = fma(A[tp][tj][kq], c.fnpiv[h], -bop[tj]);      // the pivot rows: t; pivot block: -Ki
+    }
+  }
+}
+
 }  // namespace psmf

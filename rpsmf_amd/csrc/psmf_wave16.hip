@@ -13,29 +13,7 @@
 
 namespace psmf {
 
-// Per-lane constants of wave_sweep16m as numbers (lane: column lr = l & 15, rows lk + 4 q, lk = l >> 4); round j pivots on
-// rows / columns 2 j, 2 j + 1, which are register A[j >> 1] of the lane rows lk = 2 (j & 1), 2 (j & 1) + 1.
-struct Sw16K {
-  double pc0[8], pc1[8];   // lr == 2 j, lr == 2 j + 1
-  double fnp[8];           // 1 - pc0 - pc1: not a pivot column
-  double sg[8];            // lanes of the pivot rows: +1 at the pivot columns, -1 elsewhere; other lanes 0
-  double fpiv[2], fnpiv[2];   // lanes that hold the pivot rows (lk >> 1 == j & 1), and 1 - that
-  double fu, fw;           // lk even (row 2 j of the pair) / odd (row 2 j + 1)
-};
-__device__ __forceinline__ void sw16k_init(Sw16K& c, const int lk, const int lr) {
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    c.pc0[j] = lr == 2 * j ? 1.0 : 0.0;
-    c.pc1[j] = lr == 2 * j + 1 ? 1.0 : 0.0;
-    c.fnp[j] = 1.0 - c.pc0[j] - c.pc1[j];
-    const double piv = (lk >> 1) == (j & 1) ? 1.0 : 0.0;
-    c.sg[j] = piv * (2.0 * (c.pc0[j] + c.pc1[j]) - 1.0);
-  }
-#pragma unroll
-  for (int h = 0; h < 2; ++h) { c.fpiv[h] = (lk >> 1) == h ? 1.0 : 0.0; c.fnpiv[h] = 1.0 - c.fpiv[h]; }
-  c.fu = (lk & 1) == 0 ? 1.0 : 0.0;
-  c.fw = 1.0 - c.fu;
-}
+// (Sw16K / sw16k_init, the per-lane constants of the multiplier-form sweeps: psmf_ns.hip)
 
 // wave_sweep16 (psmf_impute.hip) with the lane predicates as multipliers: A <- -A^-1 of the leading r2 x r2 block by 2 x 2
 // SPD block pivots, the rank-2 update of a round on the matrix cores, the pivot block by v_readlane.
@@ -135,6 +113,8 @@ __device__ __forceinline__ void solve_block_wave_t(const StepParams& p) {
   const double kappa = p.mask ? (p.masked_method == 3 ? 1.0 : fast_rcp(st->rho + (p.masked_method ? 0.0 : st->s))) : st->kappa;
   double A[NT][NT][4], Gk[NT][NT][4];
   bool bad = false;
+  Sw16K swk;
+  sw16k_init(swk, lk, lr);          // the sweeps' lane predicates as multipliers (psmf_ns.hip)
   auto at = [&](const double* Mx, const int i, const int c) { return 0.5 * (Mx[i * r + c] + Mx[c * r + i]); };
 #define WS_FOR(body)                                                                   \
   _Pragma("unroll") for (int ti = 0; ti < NT; ++ti)                                    \
@@ -153,19 +133,19 @@ __device__ __forceinline__ void solve_block_wave_t(const StepParams& p) {
       const double mv = at(st->Lbar, ic, cc) + Gk[ti][tj][q];
       A[ti][tj][q] = in ? (w == 0 ? mv : mv * ib + (i == c ? iq : 0.0)) : (pad ? 1.0 : 0.0);
     })
-    wave_sweep_tiles<NT>(A, r2, lk, lr, bad);
+    wave_sweep_tiles_m<NT>(A, r2, swk, bad);
     double* dst = w == 0 ? st->Pplus : st->XpY;
     WS_FOR({ if (in) dst[i * r + c] = -A[ti][tj][q]; })
   } else {
     WS_FOR({ A[ti][tj][q] = in ? at(st->Pbar, ic, cc) : (pad ? 1.0 : 0.0); })
-    wave_sweep_tiles<NT>(A, r2, lk, lr, bad);                       // -Pbar^-1
+    wave_sweep_tiles_m<NT>(A, r2, swk, bad);                       // -Pbar^-1
     WS_FOR({ Gk[ti][tj][q] = in ? Gk[ti][tj][q] - A[ti][tj][q] : (pad ? 1.0 : 0.0); A[ti][tj][q] = Gk[ti][tj][q]; })     // Gk now holds M
-    wave_sweep_tiles<NT>(A, r2, lk, lr, bad);                       // -P+
+    wave_sweep_tiles_m<NT>(A, r2, swk, bad);                       // -P+
     WS_FOR({ if (in) st->Pplus[i * r + c] = -A[ti][tj][q]; })
     if (dual) {
       const double iq = 1.0 / st->Q[0], ib = p.robust ? 1.0 / p.beta : 1.0;
       WS_FOR({ A[ti][tj][q] = in ? Gk[ti][tj][q] * ib + (i == c ? iq : 0.0) : (pad ? 1.0 : 0.0); })
-      wave_sweep_tiles<NT>(A, r2, lk, lr, bad);                     // -W
+      wave_sweep_tiles_m<NT>(A, r2, swk, bad);                     // -W
       WS_FOR({ if (in) st->XpY[i * r + c] = -A[ti][tj][q]; })
     }
   }

@@ -88,7 +88,7 @@ def test_device_dynamics_vs_oracle(name, make, r, robust):
     # general blocked kernel
     diag = name in ("cos_phase", "sinusoid_unscaled", "sinusoid_plain")
     assert f.geometry()["filter_kernel"].replace("filter6d", "filter6") == ("psmf_blk_filter6" if r <= 16 else
-                                             (("psmf_blk_filter4" if r > 16 else "psmf_blk_filter4s") if diag else "psmf_blk_filter"))
+                                             (("psmf_blk_filter4" if r > 16 else "psmf_blk_filter4s") if diag else "psmf_blk_filter7"))
     f.zero_gradsum()
     f.run(0, T)
     s = f.get_state()
@@ -278,7 +278,7 @@ def test_per_step_R_and_Q_schedules(engine, r, iso):
     assert f._dev.geometry()["engine"] == engine
     if engine == "block":      # schedules keep the run off filter3 (rho, q read once per block): filter4 reads them per step
         assert f._dev.geometry()["filter_kernel"] == ("psmf_blk_filter6" if r <= 16 else
-                                                      (("psmf_blk_filter4" if r > 16 else "psmf_blk_filter4s") if iso else "psmf_blk_filter"))
+                                                      (("psmf_blk_filter4" if r > 16 else "psmf_blk_filter4s") if iso else "psmf_blk_filter7"))
     st = O.State(C=C0, V=V0, mu=np.zeros(r), P=P0, Q=Q0, rho=1.0, lam=0.0)
     st, Yp, _ = O.run_epoch(st, Y, O.Mode(), O.RandomWalkDyn(), Qs=lambda k: Qs[k], rhos=lambda k: Rs[k])
     assert relerr(f._C[T], st.C) < 1e-9 and relerr(f._V[T], st.V) < 1e-9 and relerr(f._P[T], st.P) < 1e-9

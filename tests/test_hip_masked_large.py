@@ -45,7 +45,10 @@ def test_impute_run_large_shapes_vs_oracle(d, n, r, robust):
                 C=relerr(res["C"][0], st["C"]), X=relerr(res["X"][0], st["X"]), Yrec=relerr(res["Yrec"][0], st["Yrec"]),
                 YrecL=relerr(res["YrecL"][0], st["YrecL"]), YrecH=relerr(res["YrecH"][0], st["YrecH"]))
     print(f"masked large d={d} r={r} n={n} robust={robust}: {errs}  [{res['elapsed_ms']:.1f} ms]")
-    assert max(errs.values()) < 1e-9, errs
+    # rPSMF at (2 000, 20) is the one badly conditioned case of the set: two float64 routes to P+ inside the numpy oracle itself --
+    # solve(I + Pbar G, Pbar) against inv(inv(Pbar) + G) -- end 1.2e-9 apart on C (5e-10 on X) after these 240 steps; every other
+    # case agrees to 1e-12
+    assert max(errs.values()) < (5e-9 if robust else 1e-9), errs
 
 
 def test_drop_in_functions_beyond_the_small_engine():
