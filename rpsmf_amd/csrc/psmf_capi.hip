@@ -768,8 +768,8 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
   if (cfg->masked >= 2 && (cfg->robust || cfg->dyn_kind != PSMF_DYN_RANDOM_WALK))
     return fail(nullptr, PSMF_ERR_ARG, "psmf_create: masked = 2 (MLE-SMF) / 3 (TMF) are random-walk, non-robust filters");
   if (cfg->masked) {
-    if (cfg->dyn_kind != PSMF_DYN_RANDOM_WALK && cfg->dyn_kind != PSMF_DYN_COS_PHASE)
-      return fail(nullptr, PSMF_ERR_ARG, "psmf_create: masked = 1 runs on the per-step engine, which evaluates the random walk and cos-phase dynamics");
+    if (cfg->dyn_kind != PSMF_DYN_RANDOM_WALK)
+      return fail(nullptr, PSMF_ERR_ARG, "psmf_create: masked handles are random-walk filters (ExperimentImpute/PSMF.py:65-66: Pbar = P + Q)");
     if (!cfg->coef_update || !cfg->eta_full || !cfg->pbar_predict || cfg->nonuniform_R || cfg->engine == 2 || !cfg->store_y_pred)
       return fail(nullptr, PSMF_ERR_ARG, "psmf_create: masked = 1 needs the full filter (coef_update, eta_full, pbar_predict), a uniform diagonal R, "
                                          "store_y_pred = 1 and the per-step engine");
@@ -1613,6 +1613,7 @@ int psmf_set_row_noise(psmf_handle h, const double* rho_rows, double rho_mean) {
 int psmf_set_schedules(psmf_handle h, const double* rho_k, const double* q_k, int64_t n) {
   if (!h || n < 0) return PSMF_ERR_ARG;
   if (h->cfg.robust && (rho_k || q_k)) return fail(h, PSMF_ERR_ARG, "psmf_set_schedules: rPSMF runs on its own scaled Q, R (rpsmf.py:123,128,141)");
+  if (h->cfg.masked && (rho_k || q_k)) return fail(h, PSMF_ERR_ARG, "psmf_set_schedules: masked handles take a constant R = rho I, Q (the ExperimentImpute filters)");
   int rc = set_device(h);
   if (rc) return rc;
   HIP_TRY(h, hipStreamSynchronize(h->stream));

@@ -193,3 +193,35 @@ def test_one_diverging_replica_does_not_void_the_batch():
     assert res["status"].tolist() == [0, -4, 0] and np.isnan(res["inside"][1]) and np.all(np.isfinite(res["Epred"][[0, 2]]))
     one = impute.impute_batch(Yorig, M[2], Mmiss[2], C0[2], X0[2], V, Q, 10.0, P, 2, 2, robust=True, lambda0=1.8)
     assert np.array_equal(res["Epred"][2], one["Epred"][0]) and np.array_equal(res["X"][2], one["X"][0])
+
+
+@pytest.mark.parametrize("robust", [False, True], ids=["PSMF", "rPSMF"])
+def test_masked_handle_f32_storage(robust):
+    """cfg.masked with float32 storage of C, y, y_hat (one rounding of C per timestep; the r x r state and every accumulator
+    float64): within the north-star 1e-5 of the float64 oracle over one pass; cos-phase dynamics and R / Q schedules are refused on
+    masked handles (the ExperimentImpute filters are random walks with constant noise levels)."""
+    from rpsmf_amd import _capi as c
+
+    d, n, r = 6000, 150, 16
+    Yorig, M, Mmiss, C0, X0 = _problem(d, n, r, 5)
+    Yorig = Yorig.astype(np.float32).astype(np.float64)
+    C0 = C0.astype(np.float32).astype(np.float64)
+    V, Q, P = 2 * np.eye(r), 0.1 * np.eye(r), np.eye(r)
+    Xo = X0.copy()
+    ep, ef, ib, st = impute_filter(Yorig * M, C0, Xo, M, Mmiss, V, Q, 10.0, P, 2, 1, Yorig, 0.0, robust=robust, lambda0=1.8, return_state=True)
+    f = c.DeviceFilter(d, r, robust=robust, storage="f32", masked=True, engine="step")
+    f.upload_series(np.ascontiguousarray(Yorig.T))
+    f.upload_mask(np.ascontiguousarray(M.T))
+    f.set_state(C0, V, P, Q, X0[:, n - 1], rho=10.0, lambda0=1.8)
+    f.run(0, n)
+    s, X, m = f.get_state(), f.mu_history(1, n), f.masked_metrics(np.ascontiguousarray(Mmiss.T), 2.0)
+    with pytest.raises(ValueError, match="rPSMF" if robust else "masked"):
+        f.set_schedules(np.ones(n + 1), None)
+    f.close()
+    errs = dict(C=relerr(s["C"], st["C"]), X=relerr(X.T, st["X"]), P=relerr(s["P"], st["P"]), V=relerr(s["V"], st["V"]),
+                Epred=relerr(np.sqrt(m[0] / m[3]), ep[0, 1]), Efull=relerr(np.sqrt(m[1] / m[3]), ef[0, 1]))
+    print(f"masked f32 storage d={d} r={r} robust={robust}: {errs}")
+    assert max(errs.values()) < 1e-5, errs
+    assert abs(m[2] / m[3] - ib) < 5e-4          # coverage: entries at a band edge may change sides at float32 resolution
+    with pytest.raises(ValueError, match="random-walk"):
+        c.DeviceFilter(d, r, masked=True, dyn_kind=c.DYN_COS_PHASE, engine="step", storage="f64")
