@@ -4,6 +4,8 @@ recursive classes, and the per-step R_k / Q_k schedules of PSMFIter -- against t
 same callables) and the reference-generated golden fixtures.  GPU only: `pytest -m gpu`.
 """
 
+import os
+
 import numpy as np
 import pytest
 
@@ -11,6 +13,9 @@ from conftest import load_golden, relerr
 from oracle import psmf_oracle as O
 import rpsmf_amd as psmf
 from rpsmf_amd import nonlinearities as NL
+
+# what runs the configurations no specialised kernel takes at 17 <= r <= 32 (PSMF_FILTER7=0: the one-group general kernel)
+GENERAL_17_32 = "psmf_blk_filter" if os.environ.get("PSMF_FILTER7") == "0" else "psmf_blk_filter7"
 
 pytestmark = pytest.mark.gpu
 
@@ -88,7 +93,7 @@ def test_device_dynamics_vs_oracle(name, make, r, robust):
     # general blocked kernel
     diag = name in ("cos_phase", "sinusoid_unscaled", "sinusoid_plain")
     assert f.geometry()["filter_kernel"].replace("filter6d", "filter6") == ("psmf_blk_filter6" if r <= 16 else
-                                             (("psmf_blk_filter4" if r > 16 else "psmf_blk_filter4s") if diag else "psmf_blk_filter7"))
+                                             (("psmf_blk_filter4" if r > 16 else "psmf_blk_filter4s") if diag else GENERAL_17_32))
     f.zero_gradsum()
     f.run(0, T)
     s = f.get_state()
@@ -278,7 +283,7 @@ def test_per_step_R_and_Q_schedules(engine, r, iso):
     assert f._dev.geometry()["engine"] == engine
     if engine == "block":      # schedules keep the run off filter3 (rho, q read once per block): filter4 reads them per step
         assert f._dev.geometry()["filter_kernel"] == ("psmf_blk_filter6" if r <= 16 else
-                                                      (("psmf_blk_filter4" if r > 16 else "psmf_blk_filter4s") if iso else "psmf_blk_filter7"))
+                                                      (("psmf_blk_filter4" if r > 16 else "psmf_blk_filter4s") if iso else GENERAL_17_32))
     st = O.State(C=C0, V=V0, mu=np.zeros(r), P=P0, Q=Q0, rho=1.0, lam=0.0)
     st, Yp, _ = O.run_epoch(st, Y, O.Mode(), O.RandomWalkDyn(), Qs=lambda k: Qs[k], rhos=lambda k: Rs[k])
     assert relerr(f._C[T], st.C) < 1e-9 and relerr(f._V[T], st.V) < 1e-9 and relerr(f._P[T], st.P) < 1e-9
