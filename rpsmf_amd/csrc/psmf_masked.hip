@@ -3,7 +3,7 @@
 //
 //   e_i   = m_i (y_i - c_i . mu_bar)             rows with m_i = 0 are neither used nor updated; y_hat is stored unmasked
 //   G_m   = sum_i m_i c_i c_i^T                  the mask changes with every step, so neither the algebraically tracked Gram
-//                                                nor time-blocking apply: one masked Gram pass per step (psmf_mgram_mfma)
+//                                                nor time-blocking apply: one masked Gram pass per step (mgram_body)
 //   eta   = (rho n_obs + <G_m, P_bar>) / d       divided by d, NOT by the observed count (PSMF.py:77)
 //   kappa_i = m_i / (rho + s)                    =>  P+ = (P_bar^-1 + kappa G_m)^-1,  b = kappa h,  q = kappa ee  (uniform rho)
 //   lambda <- lambda + d                         (d again, rPSMF.py:135)

@@ -225,3 +225,35 @@ def test_masked_handle_f32_storage(robust):
     assert abs(m[2] / m[3] - ib) < 5e-4          # coverage: entries at a band edge may change sides at float32 resolution
     with pytest.raises(ValueError, match="random-walk"):
         c.DeviceFilter(d, r, masked=True, dyn_kind=c.DYN_COS_PHASE, engine="step", storage="f64")
+
+
+def test_masked_engine_random_shapes_and_methods():
+    """Shapes, ranks, methods and pass counts drawn at random (fixed seed) beyond the small-shape engine: d in 513 .. 3000 with any
+    r <= 48, or r in 17 .. 48 with a small d -- every rank parity (odd / even: the identity-padded 2 x 2 pivot), both tile counts of
+    the wave-local solve and the LDS solve (r > 32), the four methods -- against the oracle."""
+    from oracle.impute_oracle import mle_smf_filter, tmf_filter
+
+    rng = np.random.default_rng(20261004)
+    for case in range(8):
+        if case % 2 == 0:
+            d, r = int(rng.integers(513, 3000)), int(rng.integers(1, 49))
+        else:
+            d, r = int(rng.integers(20, 200)), int(rng.integers(17, 49))
+        n, iters = int(rng.integers(25, 70)), int(rng.integers(1, 3))
+        method = ("psmf", "rpsmf", "mle_smf", "tmf")[case % 4]
+        Yorig, M, Mmiss, C0, X0 = _problem(d, n, r, 1000 + case, empty_column=(method != "mle_smf"))
+        V, Q, P = 2 * np.eye(r), 0.1 * np.eye(r), np.eye(r)
+        Xo = X0.copy()
+        if method in ("psmf", "rpsmf"):
+            ep, ef, ib, st = impute_filter(Yorig * M, C0, Xo, M, Mmiss, V, Q, 10.0, P, 2, iters, Yorig, 0.0, robust=(method == "rpsmf"), lambda0=1.8, return_state=True)
+        elif method == "mle_smf":
+            ep, ef, ib, st = mle_smf_filter(Yorig * M, C0, Xo, M, Mmiss, Q, 10.0, P, 2, iters, Yorig, 0.0, return_state=True)
+        else:
+            ep, ef, st = tmf_filter(Yorig * M, C0, Xo, M, Mmiss, iters, Yorig, 0.0, return_state=True)
+            ib = 0.0
+        res = impute.impute_batch(Yorig, M, Mmiss, C0, X0, V, Q, 10.0, P, 2 if method != "tmf" else 0.0, iters, method=method, lambda0=1.8)
+        assert res["kernel"] == "masked per-step engine" and res["status"][0] == 0
+        errs = dict(Epred=relerr(res["Epred"][0], ep[0, 1:]), Efull=relerr(res["Efull"][0], ef[0, 1:]), inside=abs(res["inside"][0] - ib),
+                    C=relerr(res["C"][0], st["C"]), X=relerr(res["X"][0], st["X"]))
+        print(f"masked random case {case}: d={d} r={r} n={n} passes={iters} {method}: {errs}")
+        assert max(errs.values()) < 5e-9, (case, d, r, method, errs)
