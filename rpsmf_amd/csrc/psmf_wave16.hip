@@ -104,17 +104,19 @@ template <int NT>
 __device__ __forceinline__ void solve_block_wave_t(const StepParams& p) {
   DevState* st = p.st;
   const int r = p.r, r2 = r + (r & 1), w = threadIdx.x >> 6, lane = threadIdx.x & 63, lk = lane >> 4, lr = lane & 15;
-  const bool dual = p.solve_dual != 0, carried = dual && st->ns_valid == 7;
+  const bool dual = p.solve_dual != 0;
   if (p.mask && w == 2) { masked_prep_wave(p); return; }     // masked step: one more wave publishes eta, N, G, ... beside the solve
-  if (w > (carried ? 1 : 0)) return;
+  if (w > 1) return;
+  // Every load the block depends on is issued HERE, before the first branch on a loaded value (carried): the scalars, G and Lbar
+  // arrive in ONE memory round trip instead of two (the block is a latency chain: 11 us of which the sweep itself is 4.7).
   // masked step: the Gram of the step is p.mg (reduced over workgroups and ranks), not yet in st->G -- the publishing wave writes it
-  // there while this one reads it at the source; kappa = 1 / (rho + s) (MLE-SMF: 1 / rho, TMF: 1) does not wait for eta either
-  const double* __restrict__ Gsrc = p.mask ? p.mg : st->G;
-  const double kappa = p.mask ? (p.masked_method == 3 ? 1.0 : fast_rcp(st->rho + (p.masked_method ? 0.0 : st->s))) : st->kappa;
-  double A[NT][NT][4], Gk[NT][NT][4];
+  // there while this one reads it at the source (both triangles: the reduced partials are symmetric up to the order of one product);
+  // kappa = 1 / (rho + s) (MLE-SMF: 1 / rho, TMF: 1) does not wait for eta either.  st->G and st->Lbar are written bitwise symmetric
+  // by the serial stage: one load per element.
+  const int nsv = st->ns_valid;
+  const double l_rho = st->rho, l_s = st->s, l_kap = st->kappa, q0 = st->Q[0];
+  double A[NT][NT][4], Gk[NT][NT][4], Ll[NT][NT][4];
   bool bad = false;
-  Sw16K swk;
-  sw16k_init(swk, lk, lr);          // the sweeps' lane predicates as multipliers (psmf_ns.hip)
   auto at = [&](const double* Mx, const int i, const int c) { return 0.5 * (Mx[i * r + c] + Mx[c * r + i]); };
 #define WS_FOR(body)                                                                   \
   _Pragma("unroll") for (int ti = 0; ti < NT; ++ti)                                    \
@@ -126,11 +128,20 @@ __device__ __forceinline__ void solve_block_wave_t(const StepParams& p) {
         (void)pad; (void)ic; (void)cc;                                                 \
         body                                                                           \
       }
-  WS_FOR({ Gk[ti][tj][q] = in ? (p.rho_rows ? st->GR[ic * r + cc] : kappa * at(Gsrc, ic, cc)) : 0.0; })
+  WS_FOR({
+    Gk[ti][tj][q] = p.rho_rows ? st->GR[ic * r + cc] : (p.mask ? at(p.mg, ic, cc) : st->G[ic * r + cc]);
+    Ll[ti][tj][q] = dual ? st->Lbar[ic * r + cc] : 0.0;
+  })
+  const bool carried = dual && nsv == 7;
+  if (w > (carried ? 1 : 0)) return;
+  const double kappa = p.mask ? (p.masked_method == 3 ? 1.0 : fast_rcp(l_rho + (p.masked_method ? 0.0 : l_s))) : l_kap;
+  Sw16K swk;
+  sw16k_init(swk, lk, lr);          // the sweeps' lane predicates as multipliers (psmf_ns.hip)
+  WS_FOR({ Gk[ti][tj][q] = in ? (p.rho_rows ? Gk[ti][tj][q] : kappa * Gk[ti][tj][q]) : 0.0; })
   if (carried) {
-    const double iq = 1.0 / st->Q[0], ib = p.robust ? 1.0 / p.beta : 1.0;
+    const double iq = 1.0 / q0, ib = p.robust ? 1.0 / p.beta : 1.0;
     WS_FOR({
-      const double mv = at(st->Lbar, ic, cc) + Gk[ti][tj][q];
+      const double mv = Ll[ti][tj][q] + Gk[ti][tj][q];
       A[ti][tj][q] = in ? (w == 0 ? mv : mv * ib + (i == c ? iq : 0.0)) : (pad ? 1.0 : 0.0);
     })
     wave_sweep_tiles_m<NT>(A, r2, swk, bad);
@@ -143,7 +154,7 @@ __device__ __forceinline__ void solve_block_wave_t(const StepParams& p) {
     wave_sweep_tiles_m<NT>(A, r2, swk, bad);                       // -P+
     WS_FOR({ if (in) st->Pplus[i * r + c] = -A[ti][tj][q]; })
     if (dual) {
-      const double iq = 1.0 / st->Q[0], ib = p.robust ? 1.0 / p.beta : 1.0;
+      const double iq = 1.0 / q0, ib = p.robust ? 1.0 / p.beta : 1.0;
       WS_FOR({ A[ti][tj][q] = in ? Gk[ti][tj][q] * ib + (i == c ? iq : 0.0) : (pad ? 1.0 : 0.0); })
       wave_sweep_tiles_m<NT>(A, r2, swk, bad);                     // -W
       WS_FOR({ if (in) st->XpY[i * r + c] = -A[ti][tj][q]; })
