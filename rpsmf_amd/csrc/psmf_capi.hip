@@ -594,8 +594,16 @@ int enqueue_serial_mgram(psmf_filter* h, int first) {
   int rc = h->cfg.storage == PSMF_F64 ? launch_serial_mgram_t<double>(h, first) : launch_serial_mgram_t<float>(h, first);
   if (rc) return rc;
   const int ne = h->cfg.r * h->cfg.r + 1;
-  hipLaunchKernelGGL(psmf::psmf_mgram_reduce, dim3((ne + 63) / 64), dim3(512), 0, h->stream, (const double*)h->gpart, (int)kMGramWG, ne, h->mg);
-  if (h->use_coll) return all_reduce_sum(h, h->mg, (size_t)ne, h->stream);
+  // the shares of <G_m, Pbar> for the next sweep's eta: by the reduction itself, or -- row shards -- behind the all-reduce of the Gram
+  const int ntr = (ne + 63) / 64;
+  double* tpart = h->mg + ne + 1;
+  hipLaunchKernelGGL(psmf::psmf_mgram_reduce, dim3(ntr), dim3(512), 0, h->stream, (const double*)h->gpart, (int)kMGramWG, ne, h->mg,
+                     h->use_coll ? (const double*)nullptr : (const double*)h->st->Pbar, h->cfg.r, tpart);
+  if (h->use_coll) {
+    const int rc2 = all_reduce_sum(h, h->mg, (size_t)ne, h->stream);
+    if (rc2) return rc2;
+    hipLaunchKernelGGL(psmf::psmf_mgram_trace, dim3(ntr), dim3(64), 0, h->stream, (const double*)h->mg, (const double*)h->st->Pbar, h->cfg.r, tpart);
+  }
   return PSMF_OK;
 }
 
@@ -800,7 +808,7 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
   CREATE_TRY(hipMalloc(&h->C, (size_t)cfg->d_local * h->geo.rp * h->elem()));
   CREATE_TRY(hipMalloc((void**)&h->partials, (size_t)h->geo.n_sweep_wg * h->geo.ps * sizeof(double)));
   CREATE_TRY(hipMalloc((void**)&h->gpart, (size_t)(cfg->masked ? 256 : kGramWG) * (cfg->r * cfg->r + 1) * sizeof(double)));
-  if (cfg->masked) CREATE_TRY(hipMalloc((void**)&h->mg, (size_t)(cfg->r * cfg->r + 2) * sizeof(double)));
+  if (cfg->masked) CREATE_TRY(hipMalloc((void**)&h->mg, (size_t)(cfg->r * cfg->r + 2 + (cfg->r * cfg->r + 64) / 64 + 1) * sizeof(double)));     // Gram, count | trace shares
   {
     const bool can_block = cfg->r <= psmf::RM / 2 && cfg->dyn_kind != PSMF_DYN_HOST && !cfg->nonuniform_R && !cfg->masked;
     if (cfg->engine == 2 && !can_block) { h->err = "psmf_create: the blocked engine needs r <= 32, device-evaluated dynamics and a uniform diagonal R"; return bail(PSMF_ERR_ARG); }
@@ -935,7 +943,7 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
   sp.rho_rows = nullptr; sp.rho_mean = 1.0;
   sp.recursive = cfg->recursive; sp.update_every = cfg->update_every > 0 ? cfg->update_every : 1;
   sp.track_g = ((cfg->eta_full || cfg->coef_update) && !cfg->masked) ? 1 : 0;     // masked: G is this step's masked Gram, recomputed every step
-  sp.mask = nullptr; sp.mg = nullptr; sp.sc_hist = nullptr; sp.mask_rows = 0;
+  sp.mask = nullptr; sp.mg = nullptr; sp.mg_tr = nullptr; sp.mg_ntr = 0; sp.sc_hist = nullptr; sp.mask_rows = 0;
   sp.masked_method = cfg->masked >= 2 ? cfg->masked : 0;
   sp.solve_lds = Switches::off("PSMF_STEP_WAVE_SOLVE") ? 1 : 0;
   sp.external_reduce = 0;
@@ -1119,6 +1127,8 @@ int psmf_upload_series(psmf_handle h, const void* Y, int dtype, int64_t t0, int6
       HIP_TRY(h, hipMemset(h->sc_hist, 0, (size_t)T_total * 2 * sizeof(double)));
       h->sp.mask = h->mask;
       h->sp.mg = h->mg;
+      h->sp.mg_tr = h->mg + (h->cfg.r * h->cfg.r + 1) + 1;
+      h->sp.mg_ntr = (h->cfg.r * h->cfg.r + 1 + 63) / 64;
       h->sp.sc_hist = h->sc_hist;
       h->sp.mask_rows = (int)T_total;
     }

@@ -80,6 +80,8 @@ struct StepParams {
   // masked filter (cfg.masked, psmf_masked.hip): T_cap x d_local observation mask, time-major like Y (1 = observed); nullptr = all observed
   const uint8_t* mask;
   const double* mg;     // masked: r*r + 1 doubles -- masked Gram G_m and observed count of the CURRENT step, summed over workgroups and ranks
+  const double* mg_tr;  // masked: partial sums of <G_m, Pbar> (mg_ntr of them, one per workgroup of the Gram's reduction; summed in order)
+  int mg_ntr;
   double* sc_hist;      // masked: T_cap x 2, (s, eta) of every step (the bands of the pass metrics are formed from them)
   int mask_rows;        // masked: rows of the mask buffer (T_cap)
   // per-step engine, random walk with Q = q I (r <= 32): the two r x r inversions of a step side by side on two waves

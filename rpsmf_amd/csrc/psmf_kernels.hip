@@ -200,6 +200,8 @@ __device__ __forceinline__ void solve_block_t(const StepParams& p, double* sm) {
   int* errflag = reinterpret_cast<int*>(sm + 4 * RM);
   if (tid == 0) *errflag = 0;
   const double kappa = st->kappa;
+  const double* __restrict__ gsrc = p.rho_rows ? st->GR : (p.mask ? p.mg : st->G);
+  const double gsc = p.rho_rows ? 1.0 : kappa;
   double A[M], Gk[M];
 #pragma unroll
   for (int m = 0; m < M; ++m) {
@@ -207,7 +209,10 @@ __device__ __forceinline__ void solve_block_t(const StepParams& p, double* sm) {
     const bool in = (i < r && c < r);
     const double pv = in ? 0.5 * (st->Pbar[i * r + c] + st->Pbar[c * r + i]) : 0.0;
     A[m] = in ? pv : ((i == c && i < r2) ? 1.0 : 0.0);
-    Gk[m] = in ? (p.rho_rows ? st->GR[i * r + c] : kappa * st->G[i * r + c]) : 0.0;   // non-uniform R: sum_i c_i c_i^T / (rho_i + s), this step's
+    // non-uniform R: sum_i c_i c_i^T / (rho_i + s), this step's; masked step: the step's reduced Gram p.mg (both triangles averaged)
+    double gv = gsrc[in ? i * r + c : 0];
+    if (p.mask) gv = 0.5 * (gv + gsrc[in ? c * r + i : 0]);
+    Gk[m] = in ? gv * gsc : 0.0;
   }
   spd_update_solve<RPAD>(A, Gk, r2, c, rg, rowbuf, errflag);
 #pragma unroll
@@ -238,35 +243,27 @@ __device__ __forceinline__ void solve_block(const StepParams& p, double* sm) {
 // ------------------------------------------------------------------------------------------
 // Masked step (psmf_masked.hip), start of every workgroup of the sweep: eta, N of the step from the reduced masked Gram
 //   eta = (rho n_obs + <G_m, Pbar>) / d   (divided by d, ExperimentImpute/PSMF.py:77),   N = s + eta
-// p.mg[0 .. r*r) = G_m, p.mg[r*r] = n_obs (summed over workgroups and ranks).  Every workgroup forms the same sums in the same
-// order (same bits everywhere); `publish` (block 0, before its solve): st->G (symmetrised), eta, N, kappa and the step's (s, eta)
+// p.mg[0 .. r*r) = G_m, p.mg[r*r] = n_obs (summed over workgroups and ranks); p.mg_tr: the shares of <G_m, Pbar>.  Every thread forms
+// the same sum in the same order (same bits everywhere); `publish` (block 0, before its solve): eta, N, kappa and the step's (s, eta)
 // for the bands.  Returns in sc[0..2]: eta, N, and the factor in front of the update direction (1 / N for PSMF / rPSMF).
 // masked_method 2 (MLE-SMF): weights m_i / rho (s does not enter), direction (gam / eta) mu_bar;  3 (TMF): kappa = 1, gam mu_bar.
 // sm: 16 doubles of LDS.  All threads of the workgroup call it.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void masked_prep_block(const StepParams& p, double* sm, const bool publish, double (&sc)[3]) {
+  (void)sm;
   DevState* st = p.st;
-  const int r = p.r, tid = threadIdx.x, nthr = blockDim.x;
-  const double* __restrict__ mg = p.mg;
-  double gp = 0.0;
-  for (int q = tid; q < r * r; q += nthr) {
-    const int i = q / r, j = q - i * r;
-    const double g = 0.5 * (mg[q] + mg[j * r + i]);     // both triangles identical
-    if (publish) st->G[q] = g;
-    gp += g * 0.5 * (st->Pbar[q] + st->Pbar[j * r + i]);
-  }
-  gp = wave_sum(gp);
-  if ((tid & 63) == 0) sm[tid >> 6] = gp;
-  __syncthreads();
+  const int r = p.r;
+  // <G_m, Pbar> arrives as p.mg_ntr shares (psmf_mgram_reduce / psmf_mgram_trace): every thread sums them in order -- a handful of
+  // broadcast loads in the same round trip as the other r-sized operands of the sweep, no pass over G, no barrier
   double tr = 0.0;
-  for (int w = 0; w < (nthr >> 6); ++w) tr += sm[w];
+  for (int w = 0; w < p.mg_ntr; ++w) tr += p.mg_tr[w];
   const int meth = p.masked_method;
   const double s = meth ? 0.0 : st->s, rho = st->rho;
-  const double eta = (rho * mg[r * r] + tr) / (double)p.d;
+  const double eta = (rho * p.mg[r * r] + tr) / (double)p.d;
   const double N = s + eta;
   sc[0] = eta; sc[1] = N;
   sc[2] = meth == 0 ? fast_rcp(N) : (meth == 2 ? st->sgd_gamma * fast_rcp(eta) : st->sgd_gamma);
-  if (publish && tid == 0) {
+  if (publish && threadIdx.x == 0) {
     st->eta = eta;
     st->N = N;
     st->kappa = meth == 3 ? 1.0 : fast_rcp(rho + s);
@@ -277,7 +274,7 @@ __device__ __forceinline__ void masked_prep_block(const StepParams& p, double* s
       p.sc_hist[2 * t + 1] = eta;
     }
   }
-  __syncthreads();                    // sm is reused by the caller; block 0: G, kappa are in memory before its solve reads them
+  if (publish) __syncthreads();       // block 0 with the LDS solve (r > 32): eta, kappa are in memory before the solve reads them
 }
 
 // ------------------------------------------------------------------------------------------

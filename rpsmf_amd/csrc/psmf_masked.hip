@@ -171,8 +171,10 @@ __global__ __launch_bounds__(NW * 64) void psmf_serial_mgram(StepParams p, int f
 }
 
 // gpart (n_part rows of ne doubles) -> out[ne], every entry summed in the fixed order of the partials: 512 threads = 64 entries x 8
-// segments of the partial rows (all loads of a thread independent), then the 8 segment sums in order.
-__global__ __launch_bounds__(512) void psmf_mgram_reduce(const double* __restrict__ gpart, int n_part, int ne, double* __restrict__ out) {
+// segments of the partial rows (all loads of a thread independent), then the 8 segment sums in order.  Pbar != nullptr (ne = r*r + 1):
+// also this workgroup's share of <G_m, Pbar> -> tpart[blockIdx.x] (the sweep sums the shares in order: eta without a pass over G).
+__global__ __launch_bounds__(512) void psmf_mgram_reduce(const double* __restrict__ gpart, int n_part, int ne, double* __restrict__ out,
+                                                         const double* __restrict__ Pbar, int r, double* __restrict__ tpart) {
   __shared__ double s8[8][64];
   const int e = blockIdx.x * 64 + (threadIdx.x & 63), sg = threadIdx.x >> 6;
   const int per = (n_part + 7) / 8, a0 = sg * per, a1 = min(a0 + per, n_part);
@@ -187,12 +189,27 @@ __global__ __launch_bounds__(512) void psmf_mgram_reduce(const double* __restric
   }
   s8[sg][threadIdx.x & 63] = a;
   __syncthreads();
-  if (sg == 0 && e < ne) {
+  if (sg == 0) {
     double t = 0.0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) t += s8[q][threadIdx.x];
-    out[e] = t;
+    if (e < ne) out[e] = t;
+    if (Pbar) {
+      double tp = 0.0;
+      if (e < r * r) { const int i = e / r, j = e - i * r; tp = t * (0.5 * (Pbar[e] + Pbar[j * r + i])); }
+      tp = wave_sum(tp);
+      if (threadIdx.x == 0) tpart[blockIdx.x] = tp;
+    }
   }
+}
+
+// the same shares from an already reduced Gram (row-sharded filter: the all-reduce over the ranks sits between the reduction and this)
+__global__ __launch_bounds__(64) void psmf_mgram_trace(const double* __restrict__ mg, const double* __restrict__ Pbar, int r, double* __restrict__ tpart) {
+  const int e = blockIdx.x * 64 + threadIdx.x;
+  double tp = 0.0;
+  if (e < r * r) { const int i = e / r, j = e - i * r; tp = mg[e] * (0.5 * (Pbar[e] + Pbar[j * r + i])); }
+  tp = wave_sum(tp);
+  if (threadIdx.x == 0) tpart[blockIdx.x] = tp;
 }
 
 // Metrics of a pass over the held-out entries (Mmiss = 1) of this handle's rows, steps t0 .. t0 + nt:

@@ -64,30 +64,18 @@ __device__ __forceinline__ void wave_sweep16m(double (&A)[4], const int r2, cons
 //   otherwise:  wave 0  -Pbar^-1, then M = Pbar^-1 + kappa G (or the weighted Gram of a non-uniform R), P+ = M^-1.
 // All other waves of the block retire at once.
 // ------------------------------------------------------------------------------------------------------------
-// masked step, block 0 of the sweep: what masked_prep_block(publish) does, by ONE wave (no workgroup barrier: the solve waves of the
-// same block start at once) -- st->G (symmetrised), eta, N, kappa, the next Gram's step index, the step's (s, eta) for the bands
+// masked step, block 0 of the sweep: what masked_prep_block(publish) does, by one lane of a wave of its own (the solve waves of the same
+// block start at once) -- eta, N, kappa, the next Gram's step index, the step's (s, eta) for the bands
 __device__ __forceinline__ void masked_prep_wave(const StepParams& p) {
-  DevState* st = p.st;
-  const int r = p.r, lane = threadIdx.x & 63;
-  const double* __restrict__ mg = p.mg;
-  // the same products summed in the same grouping as masked_prep_block does with the whole workgroup (thread t: q = t, t + nthr, ..;
-  // per-wave sums, then the waves in order): the eta published here has the bits of the eta the row workgroups update C with
-  const int nthr = blockDim.x;
-  double tr = 0.0;
-  for (int vw = 0; vw < (nthr >> 6); ++vw) {
-    double gp = 0.0;
-    for (int q = vw * 64 + lane; q < r * r; q += nthr) {
-      const int i = q / r, j = q - i * r;
-      const double g = 0.5 * (mg[q] + mg[j * r + i]);
-      st->G[q] = g;
-      gp += g * 0.5 * (st->Pbar[q] + st->Pbar[j * r + i]);
-    }
-    tr += wave_sum(gp);
-  }
-  const int meth = p.masked_method;
-  const double s = meth ? 0.0 : st->s, rho = st->rho;
-  const double eta = (rho * mg[r * r] + tr) / (double)p.d;
-  if (lane == 0) {
+  double sc[3];
+  if ((threadIdx.x & 63) == 0) {        // (one lane: masked_prep_block's publishing branch looks at threadIdx.x == 0 -- do it here)
+    DevState* st = p.st;
+    const int r = p.r;
+    double tr = 0.0;
+    for (int w = 0; w < p.mg_ntr; ++w) tr += p.mg_tr[w];
+    const int meth = p.masked_method;
+    const double s = meth ? 0.0 : st->s, rho = st->rho;
+    const double eta = (rho * p.mg[r * r] + tr) / (double)p.d;
     st->eta = eta;
     st->N = s + eta;
     st->kappa = meth == 3 ? 1.0 : fast_rcp(rho + s);
@@ -98,6 +86,7 @@ __device__ __forceinline__ void masked_prep_wave(const StepParams& p) {
       p.sc_hist[2 * t + 1] = eta;
     }
   }
+  (void)sc;
 }
 
 template <int NT>

@@ -5,7 +5,7 @@
 #include <vector>
 using namespace psmf;
 int main() {
-  const int r = 32, nwg = 447, ps = r + 1;
+  const int r = 32, nwg = 224, ps = r + 1;      // 224 sweep workgroups at d = 1e5 (512-thread sweep)
   DevState* st; hipMalloc((void**)&st, sizeof(DevState)); hipMemset(st, 0, sizeof(DevState));
   std::vector<double> I(r * r, 0.0); for (int i = 0; i < r; ++i) I[i * r + i] = 1.0;
   hipMemcpy(st->V, I.data(), r * r * 8, hipMemcpyHostToDevice); hipMemcpy(st->P, I.data(), r * r * 8, hipMemcpyHostToDevice);
