@@ -136,6 +136,17 @@ int psmf_set_schedules(psmf_handle h, const double* rho_k, const double* q_k, in
  * scalar in front (1 to start with; rPSMF multiplies it by omega_k, rpsmf.py:169). */
 int psmf_set_row_noise(psmf_handle h, const double* rho_rows, double rho_mean);
 
+/* A NON-DIAGONAL R (the dense d x d branch of psmf.py:150-152, rpsmf.py:150-152), cfg.nonuniform_R = 1, one shard (d_local = d):
+ * R = U diag(lam) U^T with U (d x d, row-major, eigenvectors in its COLUMNS, orthonormal) and lam[d] >= 0 from the caller's
+ * symmetric eigen-solver (LAPACK dsyevd / numpy.linalg.eigh; O(d^3), once).  The recursion is equivariant under the orthogonal
+ * change of observation coordinates y -> U^T y, C -> U^T C (eta and the residual norms are invariant), so the handle keeps the
+ * series and the dictionary ROTATED, runs the non-uniform-diagonal step with rho_rows = lam, and rotates at its boundary:
+ * psmf_set_state / psmf_upload_series on the way in, psmf_get_state's C, psmf_download_y_pred, psmf_predict, psmf_project on the
+ * way out (float64 GEMMs against the resident U on the matrix cores) -- callers see original coordinates everywhere; no d x d
+ * inverse is formed and a step stays O(d r^2).  Call it before the first psmf_set_state / psmf_upload_series.  U stays resident:
+ * 8 d^2 bytes. */
+int psmf_set_noise_rotation(psmf_handle h, const double* U, const double* lam);
+
 /* ---- series ---------------------------------------------------------------------------- */
 /* Y: nt x d_local time-major block holding y_{t0+1} .. y_{t0+nt}; T_total sizes the device
  * buffers on first use.  replaces the dict y[k] of (d,1) arrays passed to step (psmf.py:85-88) */

@@ -332,7 +332,8 @@ def lowrank_step(st: State, y, k, mode: Mode, dyn: Dynamics, Qk=None, rhok=None,
 # one step, reference-shaped dense algebra (O(d^2 r))
 # --------------------------------------------------------------------------
 def literal_step(st: State, y, k, mode: Mode, dyn: Dynamics, Qk=None, rhok=None):
-    """Same step with the d x d matrices formed explicitly, unmasked only.
+    """Same step with the d x d matrices formed explicitly, unmasked only.  st.rho (or rhok) may be a d x d matrix: a
+    non-diagonal R, which only this function takes (dense inverse of the innovation covariance, psmf.py:150-152).
 
     This is what the reference costs: dense R, kron(s, I_d), d x d inverse-innovation
     matrix, d x d trace argument (psmf.py:121-125,140-165).  Used for the
@@ -341,8 +342,9 @@ def literal_step(st: State, y, k, mode: Mode, dyn: Dynamics, Qk=None, rhok=None)
     C, V, P, mu = st.C, st.V, st.P, st.mu
     d, r = C.shape
     Q = st.Q if Qk is None else Qk
-    rho = _rho_vec(st.rho if rhok is None else rhok, d)
-    Rm = np.diag(rho)
+    rho_in = st.rho if rhok is None else rhok
+    dense_R = np.ndim(rho_in) == 2        # a d x d matrix R: the reference's non-diagonal branch (psmf.py:150-152, rpsmf.py:150-152)
+    Rm = np.asarray(rho_in, dtype=float) if dense_R else np.diag(_rho_vec(rho_in, d))
     theta = st.theta if st.theta is not None else np.zeros(0)
     col = lambda v: v.reshape(-1, 1)
 
@@ -366,10 +368,13 @@ def literal_step(st: State, y, k, mode: Mode, dyn: Dynamics, Qk=None, rhok=None)
 
     Rbar = Rm + sv * np.eye(d)
     if mode.coef_update:
-        Ri = np.diag(1.0 / np.diag(Rbar))
-        RiC = Ri @ C
-        inner = np.linalg.inv(Pb) + C.T @ RiC
-        Sinv = Ri - RiC @ np.linalg.inv(inner) @ RiC.T
+        if dense_R:
+            Sinv = np.linalg.inv(C @ Pb @ C.T + Rbar)          # psmf.py:150-152: no Woodbury form for a non-diagonal R
+        else:
+            Ri = np.diag(1.0 / np.diag(Rbar))
+            RiC = Ri @ C
+            inner = np.linalg.inv(Pb) + C.T @ RiC
+            Sinv = Ri - RiC @ np.linalg.inv(inner) @ RiC.T
         mu_new = xb + Pb @ C.T @ Sinv @ resid
         P_new = Pb - Pb @ C.T @ Sinv @ C @ Pb
     else:

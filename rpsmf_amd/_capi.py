@@ -55,6 +55,7 @@ SIGNATURES = {
     "psmf_set_adam": (C.c_int, [C.c_void_p, _dp, _dp]),
     "psmf_set_schedules": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int64]),
     "psmf_set_row_noise": (C.c_int, [C.c_void_p, _dp, C.c_double]),
+    "psmf_set_noise_rotation": (C.c_int, [C.c_void_p, _dp, _dp]),
     "psmf_step_host": (C.c_int, [C.c_void_p, C.c_int64, _dp, _dp, _dp, _dp, _dp, _dp]),
     "psmf_project": (C.c_int, [C.c_void_p, _dp, C.c_int64, _dp]),
     "psmf_predict_sq_error": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, _dp, _dp]),
@@ -277,6 +278,12 @@ class DeviceFilter:
         if rho_mean is None:
             rho_mean = float(rho_rows.sum()) / self.d
         self._check(self._lib.psmf_set_row_noise(self._h, _ptr(rho_rows), float(rho_mean)))
+
+    def set_noise_rotation(self, U, lam):
+        """A non-diagonal R = U diag(lam) U^T (eigenvectors in the columns of U): the handle keeps the series and C rotated and
+        runs the non-uniform-diagonal step (psmf_set_noise_rotation); one shard, before set_state / upload_series."""
+        U, lam = _f64(U, (self.d, self.d)), _f64(lam, (self.d,))
+        self._check(self._lib.psmf_set_noise_rotation(self._h, _ptr(U), _ptr(lam)))
 
     def set_schedules(self, rho_k=None, q_k=None):
         """R_k = rho_k[k] I, Q_k = q_k[k] Q for the 1-based step k (entry 0 unused); None = constant."""

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(HERE)
 LIB_DIR = os.path.join(HERE, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libpsmf_hip.so")
 SOURCES = [os.path.join(HERE, "csrc", "psmf_capi.hip")]
-DEPS = [os.path.join(HERE, "csrc", f) for f in ("psmf_capi.hip", "psmf_kernels.hip", "psmf_block.hip", "psmf_impute.hip", "psmf_impute3.hip", "psmf_ns.hip", "psmf_blk3.hip", "psmf_blk4.hip", "psmf_blk16.hip", "psmf_blk32.hip", "psmf_masked.hip", "psmf_wave16.hip", "psmf_bulk.hip", "psmf_dyn.hip", "psmf_device.h")] + [
+DEPS = [os.path.join(HERE, "csrc", f) for f in ("psmf_capi.hip", "psmf_kernels.hip", "psmf_block.hip", "psmf_impute.hip", "psmf_impute3.hip", "psmf_ns.hip", "psmf_blk3.hip", "psmf_blk4.hip", "psmf_blk16.hip", "psmf_blk32.hip", "psmf_masked.hip", "psmf_wave16.hip", "psmf_rotate.hip", "psmf_bulk.hip", "psmf_dyn.hip", "psmf_device.h")] + [
     os.path.join(ROOT, "include", "psmf_hip.h")
 ]
 

@@ -10,6 +10,7 @@
 #include "psmf_blk16.hip"
 #include "psmf_blk32.hip"
 #include "psmf_bulk.hip"
+#include "psmf_rotate.hip"
 
 #include <rccl/rccl.h>
 
@@ -67,6 +68,9 @@ struct psmf_filter {
   double* thbuf = nullptr;     // theta | gradsum | adam_m | adam_v, th_cap doubles each
   size_t th_cap = 0;
   double* rho_rows = nullptr;  // d_local per-row diag(R) (cfg.nonuniform_R)
+  double* rotU = nullptr;      // d x d: eigenvectors of a non-diagonal R in its columns (psmf_set_noise_rotation); series, C, y_hat are kept rotated
+  void* rot_tmp = nullptr;     // staging of a rotation (the GEMM is out of place)
+  size_t rot_tmp_bytes = 0;
   // masked filter (cfg.masked, psmf_masked.hip)
   uint8_t* mask = nullptr;     // T_cap x d_local observation mask (psmf_upload_mask)
   uint8_t* mmiss = nullptr;    // staging of the held-out mask for psmf_masked_metrics (mmiss_cap bytes)
@@ -641,6 +645,44 @@ int ensure_scratch(psmf_filter* h, size_t bytes) {
   return PSMF_OK;
 }
 
+int ensure_rot_tmp(psmf_filter* h, size_t bytes) {
+  if (h->rot_tmp_bytes >= bytes) return PSMF_OK;
+  if (h->rot_tmp) HIP_TRY(h, hipFree(h->rot_tmp));
+  h->rot_tmp = nullptr;
+  h->rot_tmp_bytes = 0;
+  HIP_TRY(h, hipMalloc(&h->rot_tmp, bytes));
+  h->rot_tmp_bytes = bytes;
+  return PSMF_OK;
+}
+
+// O[M x N] = A[M x K] B[K x N] on the handle's stream (psmf_rotate.hip); the caller synchronises
+template <typename TA, typename TB, typename TO>
+int rot_gemm(psmf_filter* h, const TA* A, long long a_i, long long a_k, const TB* B, long long b_k, long long b_j, TO* O, long long o_i,
+             long long M, long long N, long long K) {
+  if (M <= 0 || N <= 0 || K <= 0) return PSMF_OK;
+  if (!A || !B || !O || (M + psmf::ROT_T - 1) / psmf::ROT_T > 65535) return fail(h, PSMF_ERR_ARG, "rotation: bad operand");
+  dim3 grid((unsigned)((N + psmf::ROT_T - 1) / psmf::ROT_T), (unsigned)((M + psmf::ROT_T - 1) / psmf::ROT_T));
+  hipLaunchKernelGGL((psmf::psmf_rot_gemm<TA, TB, TO>), grid, dim3(256), 0, h->stream, A, a_i, a_k, B, b_k, b_j, O, o_i, (int)M, (int)N, (int)K);
+  HIP_TRY(h, hipGetLastError());
+  return PSMF_OK;
+}
+
+// rows of X (n x d, storage type, row stride d) times U (fwd: into rotated coordinates) or U^T (back), out of place: src -> dst
+int rot_rows(psmf_filter* h, const void* src, void* dst, long long n, bool fwd) {
+  const long long d = h->cfg.d_local;
+  const long long bk = fwd ? d : 1, bj = fwd ? 1 : d;
+  if (h->cfg.storage == PSMF_F64) return rot_gemm(h, (const double*)src, d, 1LL, (const double*)h->rotU, bk, bj, (double*)dst, d, n, d, d);
+  return rot_gemm(h, (const float*)src, d, 1LL, (const double*)h->rotU, bk, bj, (float*)dst, d, n, d, d);
+}
+
+// the dictionary (d x rp, storage type): dst = U^T src (fwd) or U src (back)
+int rot_dict(psmf_filter* h, const void* src, void* dst, bool fwd) {
+  const long long d = h->cfg.d_local, rp = h->geo.rp, r = h->cfg.r;
+  const long long ai = fwd ? 1 : d, ak = fwd ? d : 1;
+  if (h->cfg.storage == PSMF_F64) return rot_gemm(h, (const double*)h->rotU, ai, ak, (const double*)src, rp, 1LL, (double*)dst, rp, d, r, d);
+  return rot_gemm(h, (const double*)h->rotU, ai, ak, (const float*)src, rp, 1LL, (float*)dst, rp, d, r, d);
+}
+
 void compute_geometry(const psmf_config& c, Geometry& g) {
   g.vec = c.storage == PSMF_F64 ? 2 : 4;
   g.nv = (c.r + g.vec - 1) / g.vec;
@@ -979,6 +1021,8 @@ void psmf_destroy(psmf_handle h) {
   if (h->thbuf) hipFree(h->thbuf);
   if (h->sched) hipFree(h->sched);
   if (h->rho_rows) hipFree(h->rho_rows);
+  if (h->rotU) hipFree(h->rotU);
+  if (h->rot_tmp) hipFree(h->rot_tmp);
   if (h->mask) hipFree(h->mask);
   if (h->mmiss) hipFree(h->mmiss);
   if (h->mg) hipFree(h->mg);
@@ -1021,6 +1065,15 @@ int psmf_set_state(psmf_handle h, const double* C, const double* V, const double
       std::vector<float> buf((size_t)dl * rp);
       pack_rows<float>(C, buf.data(), dl, r, rp);
       HIP_TRY(h, hipMemcpy(h->C, buf.data(), buf.size() * 4, hipMemcpyHostToDevice));
+    }
+    if (h->rotU) {                       // non-diagonal R: the handle keeps U^T C
+      const size_t cb = (size_t)dl * rp * h->elem();
+      rc = ensure_rot_tmp(h, cb);
+      if (rc) return rc;
+      HIP_TRY(h, hipMemcpy(h->rot_tmp, h->C, cb, hipMemcpyDeviceToDevice));
+      rc = rot_dict(h, h->rot_tmp, h->C, true);
+      if (rc) return rc;
+      HIP_TRY(h, hipStreamSynchronize(h->stream));
     }
   }
   const size_t rr = (size_t)r * r * sizeof(double);
@@ -1073,13 +1126,24 @@ int psmf_get_state(psmf_handle h, double* C, double* V, double* P, double* Q, do
   if (rc) return rc;
   const int r = h->cfg.r, dl = h->cfg.d_local, rp = h->geo.rp;
   if (C) {
+    const void* Csrc = h->C;
+    if (h->rotU) {                       // non-diagonal R: back to the caller's coordinates, C = U (U^T C)
+      const size_t cb = (size_t)dl * rp * h->elem();
+      rc = ensure_rot_tmp(h, cb);
+      if (rc) return rc;
+      HIP_TRY(h, hipMemset(h->rot_tmp, 0, cb));
+      rc = rot_dict(h, h->C, h->rot_tmp, false);
+      if (rc) return rc;
+      HIP_TRY(h, hipStreamSynchronize(h->stream));
+      Csrc = h->rot_tmp;
+    }
     if (h->cfg.storage == PSMF_F64) {
       std::vector<double> buf((size_t)dl * rp);
-      HIP_TRY(h, hipMemcpy(buf.data(), h->C, buf.size() * 8, hipMemcpyDeviceToHost));
+      HIP_TRY(h, hipMemcpy(buf.data(), Csrc, buf.size() * 8, hipMemcpyDeviceToHost));
       for (int i = 0; i < dl; ++i) for (int c = 0; c < r; ++c) C[(size_t)i * r + c] = buf[(size_t)i * rp + c];
     } else {
       std::vector<float> buf((size_t)dl * rp);
-      HIP_TRY(h, hipMemcpy(buf.data(), h->C, buf.size() * 4, hipMemcpyDeviceToHost));
+      HIP_TRY(h, hipMemcpy(buf.data(), Csrc, buf.size() * 4, hipMemcpyDeviceToHost));
       for (int i = 0; i < dl; ++i) for (int c = 0; c < r; ++c) C[(size_t)i * r + c] = (double)buf[(size_t)i * rp + c];
     }
   }
@@ -1165,6 +1229,14 @@ int psmf_upload_series(psmf_handle h, const void* Y, int dtype, int64_t t0, int6
         HIP_TRY(h, hipMemcpy(dst + a * 8, buf.data(), m * 8, hipMemcpyHostToDevice));
       }
     }
+  }
+  if (h->rotU && n) {                    // non-diagonal R: the handle keeps the rows y^T U
+    rc = ensure_rot_tmp(h, n * es);
+    if (rc) return rc;
+    HIP_TRY(h, hipMemcpy(h->rot_tmp, dst, n * es, hipMemcpyDeviceToDevice));
+    rc = rot_rows(h, h->rot_tmp, dst, nt, true);
+    if (rc) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
   }
   return PSMF_OK;
 }
@@ -1431,6 +1503,14 @@ int psmf_download_y_pred(psmf_handle h, void* out, int dtype, int64_t t0, int64_
   if (rc) return rc;
   const size_t dl = h->cfg.d_local, es = h->elem(), n = (size_t)nt * dl;
   const char* src = (const char*)h->YP + (size_t)t0 * dl * es;
+  if (h->rotU && n) {                    // non-diagonal R: y_hat = U (U^T y_hat)
+    rc = ensure_rot_tmp(h, n * es);
+    if (rc) return rc;
+    rc = rot_rows(h, src, h->rot_tmp, nt, false);
+    if (rc) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    src = (const char*)h->rot_tmp;
+  }
   if ((dtype == PSMF_F64) == (h->cfg.storage == PSMF_F64)) {
     HIP_TRY(h, hipMemcpy(out, src, n * es, hipMemcpyDeviceToHost));
   } else if (h->cfg.storage == PSMF_F32) {
@@ -1497,6 +1577,16 @@ int psmf_project(psmf_handle h, const double* mu, int64_t n_pred, double* out) {
     hipLaunchKernelGGL(psmf::psmf_predict_rows<float>, dim3(grid), dim3(psmf::WG), lds, h->stream,
                        (const float*)h->C, dl, r, h->geo.rp, (const double*)dmu, (int)n_pred, dout);
   HIP_TRY(h, hipGetLastError());
+  if (h->rotU) {                         // non-diagonal R: C here is U^T C -- rotate the projections back
+    rc = ensure_rot_tmp(h, obytes);
+    if (rc) return rc;
+    rc = rot_gemm(h, (const double*)dout, (long long)dl, 1LL, (const double*)h->rotU, 1LL, (long long)dl, (double*)h->rot_tmp, (long long)dl,
+                  (long long)n_pred, (long long)dl, (long long)dl);
+    if (rc) return rc;
+    HIP_TRY(h, hipStreamSynchronize(h->stream));
+    HIP_TRY(h, hipMemcpy(out, h->rot_tmp, obytes, hipMemcpyDeviceToHost));
+    return PSMF_OK;
+  }
   HIP_TRY(h, hipStreamSynchronize(h->stream));
   HIP_TRY(h, hipMemcpy(out, dout, obytes, hipMemcpyDeviceToHost));
   return PSMF_OK;
@@ -1568,6 +1658,7 @@ int psmf_comm_unique_id(void* id_out) {
 
 int psmf_comm_init(psmf_handle h, int nranks, int rank, const void* unique_id) {
   if (!h || !unique_id || nranks < 1 || rank < 0 || rank >= nranks) return fail(h, PSMF_ERR_ARG, "psmf_comm_init: bad argument");
+  if (h->rotU) return fail(h, PSMF_ERR_STATE, "psmf_comm_init: a handle with a noise rotation (non-diagonal R) is one shard by construction");
   int rc = set_device(h);
   if (rc) return rc;
   ncclUniqueId id;
@@ -1617,6 +1708,35 @@ int psmf_set_row_noise(psmf_handle h, const double* rho_rows, double rho_mean) {
   h->sp.rho_mean = rho_mean;
   destroy_graph(h);
   h->need_prep = true;
+  return PSMF_OK;
+}
+
+int psmf_set_noise_rotation(psmf_handle h, const double* U, const double* lam) {
+  if (!h || !U || !lam) return fail(h, PSMF_ERR_ARG, "psmf_set_noise_rotation: bad argument");
+  if (!h->cfg.nonuniform_R) return fail(h, PSMF_ERR_STATE, "psmf_set_noise_rotation: the handle was created with nonuniform_R = 0");
+  if (h->cfg.masked) return fail(h, PSMF_ERR_STATE, "psmf_set_noise_rotation: a masked handle filters per row of the ORIGINAL coordinates; not with a rotation");
+  if (h->use_coll || h->cfg.d_local != h->cfg.d)
+    return fail(h, PSMF_ERR_STATE, "psmf_set_noise_rotation: a non-diagonal R couples all rows: one shard only (d_local = d, no communicator)");
+  if (h->Y || h->have_state) return fail(h, PSMF_ERR_STATE, "psmf_set_noise_rotation: call it before psmf_set_state / psmf_upload_series");
+  const size_t d = (size_t)h->cfg.d;
+  double tr = 0.0;
+  for (size_t i = 0; i < d; ++i) {
+    if (!(lam[i] >= 0.0)) return fail(h, PSMF_ERR_ARG, "psmf_set_noise_rotation: eigenvalues of R must be non-negative");
+    tr += lam[i];
+  }
+  if (!(tr > 0.0)) return fail(h, PSMF_ERR_ARG, "psmf_set_noise_rotation: tr(R) must be positive");
+  // a cheap look at orthonormality (the full check is O(d^3)): first and last column of unit length and orthogonal
+  double n0 = 0.0, n1 = 0.0, dot = 0.0;
+  for (size_t k = 0; k < d; ++k) {
+    const double a = U[k * d], b = U[k * d + d - 1];
+    n0 += a * a; n1 += b * b; dot += a * b;
+  }
+  if (std::fabs(n0 - 1.0) > 1e-8 || std::fabs(n1 - 1.0) > 1e-8 || (d > 1 && std::fabs(dot) > 1e-8))
+    return fail(h, PSMF_ERR_ARG, "psmf_set_noise_rotation: the columns of U are not orthonormal");
+  int rc = psmf_set_row_noise(h, lam, tr / (double)d);
+  if (rc) return rc;
+  if (!h->rotU) HIP_TRY(h, hipMalloc((void**)&h->rotU, d * d * sizeof(double)));
+  HIP_TRY(h, hipMemcpy(h->rotU, U, d * d * sizeof(double), hipMemcpyHostToDevice));
   return PSMF_OK;
 }
 
@@ -1807,6 +1927,7 @@ int psmf_measure_copy_bandwidth(int device, size_t bytes, int iters, double* gbp
 
 int psmf_comm_init_host(psmf_handle h, int nranks, int rank, psmf_allreduce_fn fn, void* ctx) {
   if (!h || !fn || nranks < 1 || rank < 0 || rank >= nranks) return fail(h, PSMF_ERR_ARG, "psmf_comm_init_host: bad argument");
+  if (h->rotU) return fail(h, PSMF_ERR_STATE, "psmf_comm_init_host: a handle with a noise rotation (non-diagonal R) is one shard by construction");
   if (h->comm) return fail(h, PSMF_ERR_STATE, "psmf_comm_init_host: the handle already has an RCCL communicator");
   int rc = set_device(h);
   if (rc) return rc;

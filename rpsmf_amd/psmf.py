@@ -436,11 +436,31 @@ class PSMFIter:
         dg = _diag_of(Rk, self._d)
         rho = None if dg is None else _as_scalar_if_uniform(dg)
         if rho is None:
-            if dg is not None and np.array_equal(dg, self._row_noise()):
+            if dg is not None and self._dense_noise() is None and np.array_equal(dg, self._row_noise()):
                 return 1.0          # the scalar in front of diag(rho_rows) (psmf_set_row_noise)
-            raise NotImplementedError("the device path needs a diagonal R: R_k = rho_k * I, or one constant non-uniform diagonal; "
-                                      "use backend='numpy'")
+            if dg is None and self._dense_noise() is not None and (Rk is self._first_R() or np.array_equal(Rk, self._first_R())):
+                return 1.0          # the scalar in front of U diag(lam) U^T (psmf_set_noise_rotation)
+            raise NotImplementedError("the device path needs R_k = rho_k * I, or ONE constant matrix R (a non-uniform diagonal or a "
+                                      "symmetric positive semi-definite dense matrix); use backend='numpy'")
         return rho
+
+    def _dense_noise(self):
+        """(lam, U) of a NON-DIAGONAL R = U diag(lam) U^T (the reference's dense branch, psmf.py:150-152) or None.  The device
+        keeps the series and C in the eigenbasis of R, where the step is the non-uniform-diagonal one (psmf_set_noise_rotation);
+        the O(d^3) symmetric eigen-decomposition is done once, here, by LAPACK."""
+        if not hasattr(self, "_dense_noise_cache"):
+            R = self._first_R()
+            out = None
+            if np.ndim(R) == 2 and np.shape(R) == (self._d, self._d) and self._d > 1 and _diag_of(R, self._d) is None:
+                R = np.asarray(R, dtype=float)
+                if not np.allclose(R, R.T, rtol=1e-12, atol=1e-14 * np.max(np.abs(R))):
+                    raise NotImplementedError("the device path needs a symmetric R (a covariance); use backend='numpy'")
+                lam, U = np.linalg.eigh(0.5 * (R + R.T))
+                if lam[0] < -1e-12 * max(lam[-1], 0.0) or not lam[-1] > 0.0:
+                    raise NotImplementedError("the device path needs a positive semi-definite R (a covariance); use backend='numpy'")
+                out = (np.maximum(lam, 0.0), np.ascontiguousarray(U))
+            self._dense_noise_cache = out
+        return self._dense_noise_cache
 
     def _first_R(self):
         R = self._R
@@ -449,8 +469,12 @@ class PSMFIter:
     def _row_noise(self):
         """diag(R) as a (d,) vector when R is a NON-uniform diagonal (the device then weights every row, per-step engine), else None."""
         if not hasattr(self, "_row_noise_cache"):
-            dg = _diag_of(self._first_R(), self._d)
-            self._row_noise_cache = None if (dg is None or np.ndim(dg) == 0 or _as_scalar_if_uniform(dg) is not None) else np.asarray(dg, dtype=float)
+            dn = self._dense_noise()
+            if dn is not None:          # a non-diagonal R: diagonal in its eigenbasis, where the device works
+                self._row_noise_cache = dn[0]
+            else:
+                dg = _diag_of(self._first_R(), self._d)
+                self._row_noise_cache = None if (dg is None or np.ndim(dg) == 0 or _as_scalar_if_uniform(dg) is not None) else np.asarray(dg, dtype=float)
         return self._row_noise_cache
 
     def _q_matrix(self, Qk):
@@ -529,7 +553,10 @@ class PSMFIter:
     def _ensure_device(self):
         if self._dev is None:
             self._dev = _capi.DeviceFilter(self._d, self._r, **self._device_kwargs())
-            if self._row_noise() is not None:
+            if self._dense_noise() is not None:
+                lam, U = self._dense_noise()
+                self._dev.set_noise_rotation(U, lam)
+            elif self._row_noise() is not None:
                 self._dev.set_row_noise(self._row_noise())
         return self._dev
 

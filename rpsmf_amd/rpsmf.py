@@ -113,7 +113,8 @@ class rPSMFIter(PSMFIter):
     def _after_device_epoch(self, s, T):
         self._lambda = defaultdict(lambda: self.lambda0) if self.fixed_lambda else {T: s["lam"]}
         self._Q = {T: s["Q"]}
-        self._R = {T: s["rho"]}
+        # R_T = (product of the omega_k) R0 (rpsmf.py:169); with a uniform R0 the scalar stands for the multiple of the identity
+        self._R = {T: s["rho"] if self._row_noise() is None else s["rho"] * np.asarray(self.R0, dtype=float)}
 
 
 class rPSMFIterMissing(rPSMFIter):

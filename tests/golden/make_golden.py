@@ -183,6 +183,44 @@ def case_full(robust, seed, d=20, r=5, T=200, keep=(1, 2, 10, 200)):
     return out
 
 
+def case_dense_R(robust, seed, d=24, r=4, T=60, keep=(1, 2, 7, 60)):
+    """A non-diagonal (dense, symmetric positive definite) R: the reference's d x d branch (psmf.py:150-152, rpsmf.py:150-152),
+    two epochs.  R0 is stored; the rPSMF snapshots' `rho` is R_k[0, 0] (R_k = omega_k R_{k-1}: a multiple of R0)."""
+    rng = np.random.default_rng(seed)
+    Ctrue = rng.standard_normal((d, r))
+    A = rng.standard_normal((d, d)) / np.sqrt(d)
+    R0 = 0.2 * np.eye(d) + 0.8 * (A @ A.T)
+    L = np.linalg.cholesky(R0)
+    x = rng.standard_normal(r)
+    Y = np.empty((T, d))
+    for t in range(T):
+        x = x + 0.1 * rng.standard_normal(r)
+        noise = rng.standard_t(3.0, d) if robust else rng.standard_normal(d)
+        Y[t] = Ctrue @ x + L @ noise
+    C0 = 0.1 * rng.standard_normal((d, r))
+    V0 = 0.1 * np.eye(r)
+    mu0 = np.zeros((r, 1))
+    P0 = np.eye(r)
+    Q = 0.1 * np.eye(r)
+    theta0 = np.zeros((0, 1))
+    nl = RandomWalk()
+    if robust:
+        cls = snapshotting(refpkg.rPSMFIter, set(keep))
+        obj = cls(theta0, C0, V0, mu0, P0, Q, R0.copy(), 1.8, nl)
+    else:
+        cls = snapshotting(refpkg.PSMFIter, set(keep))
+        obj = cls(theta0, C0, V0, mu0, P0, {k: Q for k in range(T + 1)},
+                  {k: R0 for k in range(T + 1)}, nl)
+    obj.optim_init()
+    obj.step(ydict(Y), 1, T)
+    obj.optim_update(1)
+    obj.step(ydict(Y), 2, T)
+    out = dict(Y=Y, C0=C0, V0=V0, mu0=mu0.reshape(-1), P0=P0, Q=Q, R0=R0, lambda0=1.8,
+               y_pred_e2=ypred_arr(obj, T))
+    out.update(flat_snaps("s", obj._snaps))
+    return out
+
+
 def cos_nl(theta, x, t):
     return np.cos(2 * np.pi * theta * t + x)
 
@@ -482,6 +520,8 @@ def main():
         "psmf_recursive": lambda: case_recursive(False, 14),
         "rpsmf_recursive": lambda: case_recursive(True, 15),
         "rpsmf_scaling": case_scaling,
+        "psmf_dense_R": lambda: case_dense_R(False, 21),
+        "rpsmf_dense_R": lambda: case_dense_R(True, 22),
         "impute_synth": case_impute_synth,
         "impute_kat_pm25": case_impute_kat,
         "impute_kat_pm10": lambda: case_impute_kat("LondonAir_PM10"),
