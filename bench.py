@@ -436,7 +436,8 @@ def exchange_info(world, args, per_rank, geo, r):
             "ranks": [p["comm"]["ranks"] for p in per_rank], "world_size": world,
             "rank_devices": [{"rank": p["rank"], "hip_device": p["device"], "pci_bus_id": p["pci_bus_id"]} for p in per_rank],
             "distinct_gpus": len({p["pci_bus_id"] for p in per_rank}), "messages": msgs,
-            "forced_single_rank": bool(os.environ.get("PSMF_FORCE_COLLECTIVE")) and world == 1}
+            "forced_single_rank": bool(os.environ.get("PSMF_FORCE_COLLECTIVE")) and world == 1,
+            "rccl_init_error": per_rank[0].get("rccl_error")}          # not None: RCCL was asked for and failed; the transport above is the fallback
 
 
 def load_pmc(name):
@@ -474,19 +475,21 @@ def main():
     st0 = init_state(d, r, seed)
 
     if args.one_device:
-        if args.comm != "gloo":
-            raise SystemExit("--one-device needs --comm gloo (RCCL refuses two ranks on one GPU)")
-        local_rank = 0
-    f = _capi.DeviceFilter(d, r, robust=bool(args.robust), storage=args.storage, store_y_pred=not args.no_y_pred,
-                           device=local_rank, row0=row0, d_local=d_local, n_workgroups=args.workgroups, engine=args.engine)
-    if world > 1 and args.comm == "gloo":
+        local_rank = 0      # (with --comm rccl RCCL refuses the second rank on the device: that run rehearses the fallback below)
+    def make_filter():
+        return _capi.DeviceFilter(d, r, robust=bool(args.robust), storage=args.storage, store_y_pred=not args.no_y_pred,
+                                  device=local_rank, row0=row0, d_local=d_local, n_workgroups=args.workgroups, engine=args.engine)
+
+    def host_allreduce(v):          # same bits on every rank (gloo reduces in a fixed order)
         import torch
 
-        def host_allreduce(v):          # same bits on every rank (gloo reduces in a fixed order)
-            t = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float64))
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            return t.numpy()
+        t = torch.from_numpy(np.ascontiguousarray(v, dtype=np.float64))
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t.numpy()
 
+    f = make_filter()
+    rccl_error = None
+    if world > 1 and args.comm == "gloo":
         f.comm_init_host(world, rank, host_allreduce)
     elif world > 1:
         import torch
@@ -497,7 +500,21 @@ def main():
             uid = np.zeros(_capi.UNIQUE_ID_BYTES, dtype=np.uint8)
         t = torch.from_numpy(uid)
         dist.broadcast(t, 0)
-        f.comm_init(world, rank, t.numpy().tobytes())
+        try:
+            f.comm_init(world, rank, t.numpy().tobytes())
+        except Exception as e:          # noqa: BLE001 -- whatever RCCL reports, every rank has to learn of it
+            rccl_error = f"rank {rank}: {e}"
+        errs = [None] * world
+        dist.all_gather_object(errs, rccl_error)
+        if any(errs):
+            # RCCL did not come up on every rank: rather than lose the N-GPU measurement, carry the r-sized sums over the host
+            # (gloo) -- a different, slower transport, and config.exchange says so with RCCL's own message
+            rccl_error = "; ".join(e for e in errs if e)
+            if rank == 0:
+                print(f"[bench] RCCL communicator failed ({rccl_error}); falling back to the host-mediated all-reduce over gloo", file=sys.stderr, flush=True)
+            f.close()
+            f = make_filter()
+            f.comm_init_host(world, rank, host_allreduce)
 
     elif os.environ.get("PSMF_FORCE_COLLECTIVE"):
         # N = 1 with the RCCL calls of the sharded engine in the loop (a 1-rank communicator: the all-reduce kernels really sit on
@@ -583,7 +600,7 @@ def main():
     # ---- what the exchange really was: the communicator as RCCL reports it, which GPU every rank drives, and per rank the time
     # between consecutive blocks of the chained filter launch (an all-reduce that landed on the critical path shows there)
     cinfo = f.comm_info()
-    mine = dict(rank=rank, device=local_rank, pci_bus_id=_capi.device_pci_bus_id(local_rank), comm=cinfo,
+    mine = dict(rank=rank, device=local_rank, pci_bus_id=_capi.device_pci_bus_id(local_rank), comm=cinfo, rccl_error=rccl_error,
                 gap_between_blocks_us=insitu["filter_gap_us_mean"] if insitu else None,
                 block_us_in_kernel=insitu["filter_us_mean"] if insitu and insitu["filter_launches"] > 0 else None)
     per_rank = [mine]

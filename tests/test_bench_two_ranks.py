@@ -48,6 +48,28 @@ def test_bench_two_ranks_one_gpu(engine, d, r):
         assert ex["messages"]["per_timestep_bytes"] == (r + 1) * 8
 
 
+def test_bench_falls_back_to_gloo_when_rccl_does_not_come_up():
+    """The driver's N > 1 run asks for RCCL (the default).  If the communicator cannot be built on every rank the bench must still
+    deliver its line -- over the host-mediated transport, saying so with RCCL's own message -- instead of losing the measurement.
+    Provoked here the one way a one-GPU box can: two ranks on ONE device, which RCCL refuses."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rows", "8000",
+           "--latent-rank", "32", "--timesteps", "400", "--cpu-steps", "150", "--no-extras", "--one-device"]
+    env = dict(os.environ, OMP_NUM_THREADS="4")
+    pr = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=env, cwd=ROOT)
+    assert pr.returncode == 0, pr.stdout[-2000:] + pr.stderr[-3000:]
+    lines = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, pr.stdout[-2000:]
+    out = json.loads(lines[0])
+    ex = out["config"]["exchange"]
+    assert ex["rccl_init_error"] and ex["transport"].startswith("host-mediated") and ex["rccl_ranks"] is None and ex["ranks"] == [2, 2]
+    par = out["parity_vs_cpu_oracle"]
+    assert par["ranks"] == 2 and max(par["C"], par["V"], par["mu"], par["P"]) < 1e-5 and par["replicated_state_bit_identical"] is True
+
+
 def test_bench_two_ranks_parity_against_stored_answers(tmp_path):
     """The in-run parity of a sharded run at BASELINE size cannot re-run the oracle (0.1 s per timestep): bench.py compares with
     STORED oracle answers of the unsharded workload (tests/golden/fullsize_E_*.npz at d = 100 000; format of
