@@ -586,7 +586,7 @@ __device__ __forceinline__ void f3_ns_program(const BlockParams& b, const F3Blk&
     // `par` = parity of the dump that holds the columns published by the last iteration that ran
     const bool from_img = !done;
     if (!done) {
-      if (try_ns) { ++ctl.c_fail; ctl.ns_skip = 3; }
+      if (try_ns) { ++ctl.c_fail; ctl.ns_skip = p.ns_skip_n; }
       ++ctl.c_sw;
       double* im = isX ? imgX : imgY;
 #pragma unroll
@@ -918,7 +918,7 @@ __device__ __forceinline__ void f3_v_program(const BlockParams& b, const F3Blk& 
       }
     }
     if (!done) {
-      if (try_ns) { ++ctl.c_fail; ctl.ns_skip = 3; }
+      if (try_ns) { ++ctl.c_fail; ctl.ns_skip = p.ns_skip_n; }
       ++ctl.c_sw;
       f3_barrier();
       f3_sweep_images(L, r2, tid);

@@ -186,6 +186,13 @@ int all_reduce_sum(psmf_filter* h, double* buf, size_t count, hipStream_t s) {
 typedef void (*sweep_fn_t)(StepParams);
 typedef void (*serial_fn_t)(StepParams, int);
 
+// loads in flight per lane of the row sweep.  The 256-thread instances of r > 32 (GS lanes x VEC elements > 32 columns) run ONE wave
+// per SIMD -- their solve block keeps 3 x 3 / 4 x 4 tile arrays in a wave's 512 registers, and a kernel has one register allocation --
+// so the row workgroups make up in depth what they lack in occupancy: 16 passes in flight instead of 4 (rows alone at d = 2e4, r = 40:
+// 17.5 us -> see docs/MEASUREMENTS.md).
+template <typename T, int GS, int NT>
+constexpr int sweep_unroll() { return (NT == 256 && GS * (int)(16 / sizeof(T)) > 32) ? 16 : kUnroll; }
+
 template <typename T, int NT>
 sweep_fn_t sweep_for_gs(int gs) {
   switch (gs) {
@@ -193,8 +200,8 @@ sweep_fn_t sweep_for_gs(int gs) {
     case 2: return psmf::psmf_sweep_solve<T, 2, kUnroll, NT>;
     case 4: return psmf::psmf_sweep_solve<T, 4, kUnroll, NT>;
     case 8: return psmf::psmf_sweep_solve<T, 8, kUnroll, NT>;
-    case 16: return psmf::psmf_sweep_solve<T, 16, kUnroll, NT>;
-    case 32: return psmf::psmf_sweep_solve<T, 32, kUnroll, NT>;
+    case 16: return psmf::psmf_sweep_solve<T, 16, sweep_unroll<T, 16, NT>(), NT>;
+    case 32: return psmf::psmf_sweep_solve<T, 32, sweep_unroll<T, 32, NT>(), NT>;
   }
   return nullptr;
 }
@@ -368,8 +375,17 @@ void launch_blk_filter(psmf_filter* h, const psmf::BlockParams& b, hipStream_t s
   const size_t lds3 = psmf::blk_filter3_lds_bytes(), lds = psmf::blk_filter_lds_bytes();
   switch (select_filter_kernel(h)) {
     case FK_FILTER5: hipLaunchKernelGGL(psmf::psmf_blk_filter5, dim3(1), dim3(psmf::F3_NT), lds3, stream, b); return;
-    case FK_FILTER4: hipLaunchKernelGGL(psmf::psmf_blk_filter4, dim3(1), dim3(psmf::F3_NT), lds3, stream, b); return;
-    case FK_FILTER4S: hipLaunchKernelGGL(psmf::psmf_blk_filter4s, dim3(1), dim3(psmf::F3_NT), lds3, stream, b); return;
+    case FK_FILTER4:
+    case FK_FILTER4S: {
+      // filter4's fallback is the wave-local sweep (~5 us, five to six iterations' worth; filter3's LDS sweep: 15 us): a start
+      // beyond ||R||_F = 0.6 is cheaper swept than iterated (PSMF_NS_FAR4)
+      static const double far4 = getenv("PSMF_NS_FAR4") ? atof(getenv("PSMF_NS_FAR4")) : 0.6;
+      psmf::BlockParams b4 = b;
+      if (!getenv("PSMF_NS_FAR")) b4.sp.ns_far2 = far4 * far4;
+      if (select_filter_kernel(h) == FK_FILTER4) hipLaunchKernelGGL(psmf::psmf_blk_filter4, dim3(1), dim3(psmf::F3_NT), lds3, stream, b4);
+      else hipLaunchKernelGGL(psmf::psmf_blk_filter4s, dim3(1), dim3(psmf::F3_NT), lds3, stream, b4);
+      return;
+    }
     case FK_FILTER6D: {
       psmf::BlockParams b2 = b;
       b2.dual6 = 1;
@@ -694,7 +710,8 @@ void compute_geometry(const psmf_config& c, Geometry& g) {
   const size_t solve_lds = c.coef_update ? (size_t)(4 * psmf::RM + 2) * 8 : 0;
   const size_t red_lds = (size_t)(g.nt / 64) * (g.gs * g.vec + 1) * 8;
   g.sweep_lds = ((solve_lds > red_lds ? solve_lds : red_lds) + 15) & ~(size_t)15;
-  int target = c.n_workgroups > 0 ? c.n_workgroups : (g.nt == 512 ? 256 : 512);
+  // (r > 32: one 256-thread workgroup per CU -- one wave per SIMD, see sweep_unroll -- so ONE round of workgroups, a few CUs left to the solve block)
+  int target = c.n_workgroups > 0 ? c.n_workgroups : (c.r > 32 ? 248 : (g.nt == 512 ? 256 : 512));
   int rows = (c.d_local + target - 1) / target;
   rows = ((rows + g.rpp - 1) / g.rpp) * g.rpp;
   if (rows < g.rpp) rows = g.rpp;
@@ -704,12 +721,12 @@ void compute_geometry(const psmf_config& c, Geometry& g) {
 }
 
 // StepParams.solve_dual: can the per-step solve block run its two inversions side by side?  (random walk, Q = q I as last uploaded,
-// full filter, uniform R, r <= 32 on the 512-thread sweep, no Q_k schedule: q of the next step is q -- or omega q -- of this one)
+// full filter, uniform R, wave-local solve, no Q_k schedule: q of the next step is q -- or omega q -- of this one)
 void update_solve_dual(psmf_filter* h) {
   static const bool off = Switches::off("PSMF_STEP_DUAL");
   const psmf_config& c = h->cfg;
   const int v = (!off && h->engine == 1 && h->q_iso && c.masked < 2 && c.dyn_kind == PSMF_DYN_RANDOM_WALK && c.coef_update && c.pbar_predict && !c.nonuniform_R &&
-                 c.r <= 32 && !h->sp.solve_lds && !h->sp.q_sched) ? 1 : 0;
+                 !h->sp.solve_lds && !h->sp.q_sched) ? 1 : 0;
   if (v != h->sp.solve_dual) {
     h->sp.solve_dual = v;
     destroy_graph(h);        // the captured launches carry the old parameter block
@@ -987,7 +1004,7 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
   sp.track_g = ((cfg->eta_full || cfg->coef_update) && !cfg->masked) ? 1 : 0;     // masked: G is this step's masked Gram, recomputed every step
   sp.mask = nullptr; sp.mg = nullptr; sp.mg_tr = nullptr; sp.mg_ntr = 0; sp.sc_hist = nullptr; sp.mask_rows = 0;
   sp.masked_method = cfg->masked >= 2 ? cfg->masked : 0;
-  sp.solve_lds = Switches::off("PSMF_STEP_WAVE_SOLVE") ? 1 : 0;
+  sp.solve_lds = (Switches::off("PSMF_STEP_WAVE_SOLVE") || (cfg->r > 32 && Switches::off("PSMF_STEP_WAVE_BIG"))) ? 1 : 0;
   sp.external_reduce = 0;
   sp.use_ns = (getenv("PSMF_NS") && atoi(getenv("PSMF_NS")) == 0) ? 0 : 1;
   sp.ns_predict = getenv("PSMF_NS_PREDICT") ? atoi(getenv("PSMF_NS_PREDICT")) : 7;      // bits: 1 a / b (phase F), 2 core (wave 7), 4 applied
@@ -996,8 +1013,15 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
   // against the float64 oracle measured at 1e-4 / 3e-4 / 1e-3 in DESIGN section 5: unchanged up to 3e-4).  PSMF_NS_TOL overrides.
   const double ns_tol = getenv("PSMF_NS_TOL") ? atof(getenv("PSMF_NS_TOL")) : (cfg->storage == PSMF_F64 ? 3e-7 : 3e-4);
   sp.ns_tol2 = ns_tol * ns_tol;
+  // A start with ||I - M X0||_F >= 0.3 is given up for the direct sweep, and the next three steps sweep unasked (PSMF_NS_FAR,
+  // PSMF_NS_SKIP).  Below 1 the iteration would converge -- from 0.9 in seven iterations of 0.9 us against a 15 us sweep -- and
+  // 0.9 / 0 takes config E's cold pass from 36.4 to 35.5 ms (111 -> 10 sweeps in its first 480 timesteps, tools/probe_cold.py);
+  // NOT taken: the iteration stops at a residual (1e-7), the sweep is pivot-exact, and where Lbar' = (I / q - W / q^2) / omega
+  // cancels (q = 1e-8, tests/adversarial_cases.py:tiny_Q) every early step iterated instead of swept costs accuracy -- y_hat error
+  // 6.4e-7 (0.3 / 3), 4.0e-6 (0.3 / 0), 9.2e-6 (0.6 / 1), 1.26e-5 (0.6 / 0) against the 1e-5 bar (profiles/r4_adversarial_ns_far.txt).
   const double ns_far = getenv("PSMF_NS_FAR") ? atof(getenv("PSMF_NS_FAR")) : 0.3;
   sp.ns_far2 = ns_far * ns_far;
+  sp.ns_skip_n = getenv("PSMF_NS_SKIP") ? atoi(getenv("PSMF_NS_SKIP")) : 3;
   sp.alpha = cfg->alpha; sp.beta = cfg->beta;
   sp.lr = cfg->adam_lr; sp.lr_end = cfg->adam_lr_end; sp.lr_steps = cfg->adam_lr_steps;
   sp.b1 = cfg->adam_b1; sp.b2 = cfg->adam_b2;
@@ -1070,7 +1094,7 @@ int psmf_set_state(psmf_handle h, const double* C, const double* V, const double
       const size_t cb = (size_t)dl * rp * h->elem();
       rc = ensure_rot_tmp(h, cb);
       if (rc) return rc;
-      HIP_TRY(h, hipMemcpy(h->rot_tmp, h->C, cb, hipMemcpyDeviceToDevice));
+      HIP_TRY(h, hipMemcpyAsync(h->rot_tmp, h->C, cb, hipMemcpyDeviceToDevice, h->stream));     // (stream-ordered with the GEMM: a plain D2D hipMemcpy does not wait on the host side)
       rc = rot_dict(h, h->rot_tmp, h->C, true);
       if (rc) return rc;
       HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1131,7 +1155,7 @@ int psmf_get_state(psmf_handle h, double* C, double* V, double* P, double* Q, do
       const size_t cb = (size_t)dl * rp * h->elem();
       rc = ensure_rot_tmp(h, cb);
       if (rc) return rc;
-      HIP_TRY(h, hipMemset(h->rot_tmp, 0, cb));
+      HIP_TRY(h, hipMemsetAsync(h->rot_tmp, 0, cb, h->stream));
       rc = rot_dict(h, h->C, h->rot_tmp, false);
       if (rc) return rc;
       HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1233,7 +1257,7 @@ int psmf_upload_series(psmf_handle h, const void* Y, int dtype, int64_t t0, int6
   if (h->rotU && n) {                    // non-diagonal R: the handle keeps the rows y^T U
     rc = ensure_rot_tmp(h, n * es);
     if (rc) return rc;
-    HIP_TRY(h, hipMemcpy(h->rot_tmp, dst, n * es, hipMemcpyDeviceToDevice));
+    HIP_TRY(h, hipMemcpyAsync(h->rot_tmp, dst, n * es, hipMemcpyDeviceToDevice, h->stream));
     rc = rot_rows(h, h->rot_tmp, dst, nt, true);
     if (rc) return rc;
     HIP_TRY(h, hipStreamSynchronize(h->stream));
@@ -1382,6 +1406,7 @@ int psmf_time_kernel(psmf_handle h, int which, int iters, float* avg_us) {
     HIP_TRY(h, hipMemcpy(Csave, h->C, cbytes, hipMemcpyDeviceToDevice));
     HIP_TRY(h, hipMemcpy(ssave, h->st, sizeof(DevState), hipMemcpyDeviceToDevice));
     HIP_TRY(h, hipMemcpy(thsave, h->thbuf, thbytes, hipMemcpyDeviceToDevice));
+    HIP_TRY(h, hipDeviceSynchronize());      // (device-to-device copies on the null stream are not ordered against the handle's non-blocking stream)
     launch_blk_gram(h, b);           // a valid K for the filter / apply measurements
     launch_blk_filter(h, b);
     auto one = [&]() {
@@ -1425,6 +1450,7 @@ int psmf_time_kernel(psmf_handle h, int which, int iters, float* avg_us) {
   HIP_TRY(h, hipMalloc((void**)&ssave, sizeof(DevState)));
   HIP_TRY(h, hipMemcpy(Csave, h->C, cbytes, hipMemcpyDeviceToDevice));
   HIP_TRY(h, hipMemcpy(ssave, h->st, sizeof(DevState), hipMemcpyDeviceToDevice));
+  HIP_TRY(h, hipDeviceSynchronize());
   {  // the sweep reads y_k / writes y_hat_k at the step counter: point it at a valid row of the series
     long long k0 = h->sp.series_t0;
     HIP_TRY(h, hipMemcpy(&h->st->k, &k0, sizeof(k0), hipMemcpyHostToDevice));

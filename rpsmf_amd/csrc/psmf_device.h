@@ -20,9 +20,9 @@ struct DevState {
   double G[RM * RM];      // Gram matrix C^T C of the current C (tracked algebraically)
   double GR[RM * RM];     // non-uniform diagonal R: weighted Gram sum_i c_i c_i^T / (rho_i + s) of the CURRENT step (psmf_gram_partial)
   // carried across the blocks of the blocked engine (valid while ns_valid != 0):
-  double Lbar[RM * RM / 4];   // r x r (r <= 32): Pbar^-1 of the next step
-  double XpX[RM * RM / 4];    // last P+ (Newton-Schulz start of half X)
-  double XpY[RM * RM / 4];    // last W  (Newton-Schulz start of half Y)
+  double Lbar[RM * RM];       // r x r: Pbar^-1 of the next step (blocked engine: r <= 32; per-step engine with solve_dual: any r <= RM)
+  double XpX[RM * RM / 4];    // last P+ (Newton-Schulz start of half X; blocked engine only: r <= 32)
+  double XpY[RM * RM];        // last W  (Newton-Schulz start of half Y; per-step engine with solve_dual: W of the step, any r <= RM)
   double mu[RM];          // posterior mean mu_{k-1}
   double mu_bar[RM];      // predictive mean of the current step
   double w[RM];           // V mu_bar
@@ -97,6 +97,7 @@ struct StepParams {
   int external_reduce;  // 1: partial sums were reduced into st->red (multi-GPU)
   int use_ns;           // 1: Newton-Schulz refinement of the r x r inverses (f64 MFMA), sweep as fallback
   int ns_predict;       // 1: filter3 starts the iteration from the rank-2 downdated, kappa-rescaled previous inverse
+  int ns_skip_n;        // filter3: timesteps that go straight to the direct sweep after a failed Newton-Schulz start
   double alpha, beta, lr, lr_end, lr_steps, b1, b2;
   double ns_tol2;       // Newton-Schulz: squared Frobenius residual accepted BEFORE the last update (the update squares it)
   double ns_far2;       // Newton-Schulz: squared residual beyond which the start is given up for the direct sweep (filter3)

@@ -226,12 +226,20 @@ __device__ __forceinline__ void solve_block_t(const StepParams& p, double* sm) {
 // r <= 32: wave-local sweeps on the matrix cores, no LDS, no barrier -- and, for the random walk with Q = q I, the two inversions
 // side by side on two waves (psmf_wave16.hip: solve_block_wave, defined after the helpers it needs; same translation unit)
 __device__ void solve_block_wave(const StepParams& p);
+__device__ __forceinline__ void solve_block_wave_big(const StepParams& p);      // 33 <= r <= 64 (psmf_wave16.hip)
 
+template <bool BIGWAVE>      // the kernel instance is the 256-thread one of r > 32: wave-local tile sweeps there too
 __device__ __forceinline__ void solve_block(const StepParams& p, double* sm) {
   const int r = p.r;
   if (r <= 32 && !p.solve_lds) {
     solve_block_wave(p);
     return;
+  }
+  if constexpr (BIGWAVE) {
+    if (r > 32 && !p.solve_lds) {
+      solve_block_wave_big(p);
+      return;
+    }
   }
   if (blockDim.x > WG && threadIdx.x >= WG) return;   // the LDS sweep uses 4 waves; surplus waves retire (barriers count live waves)
   if (r <= 8) solve_block_t<8>(p, sm);
@@ -297,11 +305,12 @@ __global__ __launch_bounds__(NT) void psmf_sweep_solve(StepParams p) {
   // masked step: eta, N from the step's Gram -- every row workgroup for itself; block 0 publishes them: by a wave of its own beside
   // the solve waves when the solve is wave-local (r <= 32), else by the whole block before the LDS solve
   const bool solve_here = has_solve && blockIdx.x == 0;
-  if (p.mask && !(solve_here && p.r <= 32 && !p.solve_lds)) masked_prep_block(p, sm, solve_here, msc);
+  constexpr bool BIGWAVE = NT == 256 && GS * VEC > 32;         // (r > 32 runs the 256-thread instances only: a wave there may hold 512 registers)
+  if (p.mask && !(solve_here && (p.r <= 32 || BIGWAVE) && !p.solve_lds)) masked_prep_block(p, sm, solve_here, msc);
   if (has_solve && blockIdx.x == 0) {
     // (raising the solve waves' issue priority on the CU they share with a row-sweep workgroup was measured neutral: the block
     //  is a chain of LDS exchanges and barriers, not short of issue slots)
-    solve_block(p, sm);
+    solve_block<BIGWAVE>(p, sm);
     return;
   }
   const int wgid = (int)blockIdx.x - has_solve;

@@ -158,4 +158,74 @@ __device__ void solve_block_wave(const StepParams& p) {
   else solve_block_wave_t<2>(p);
 }
 
+// 33 <= r <= 64: the same on 3 x 3 (r <= 48) or 4 x 4 tiles.  Only in the 256-thread instances of psmf_sweep_solve (r > 32 runs no
+// other): there a wave may hold 512 registers, which the 64-double tile arrays need -- inlined into the 512-thread instances they took
+// the row-sweep workgroups' registers with them (docs/HISTORY.md, round 4).  Leaner on registers than solve_block_wave_t: operands are
+// loaded where they are used (a second memory round trip on a run's first step only; the carried step still loads everything at once).
+template <int NT>
+__device__ __forceinline__ void solve_block_wave_big_t(const StepParams& p) {
+  DevState* st = p.st;
+  const int r = p.r, r2 = r + (r & 1), w = threadIdx.x >> 6, lane = threadIdx.x & 63, lk = lane >> 4, lr = lane & 15;
+  const bool dual = p.solve_dual != 0;
+  if (p.mask && w == 2) { masked_prep_wave(p); return; }
+  if (w > 1) return;
+  const int nsv = st->ns_valid;
+  const double l_rho = st->rho, l_s = st->s, l_kap = st->kappa, q0 = st->Q[0];
+  const bool carried = dual && nsv == 7;
+  if (w > (carried ? 1 : 0)) return;
+  const double kappa = p.mask ? (p.masked_method == 3 ? 1.0 : fast_rcp(l_rho + (p.masked_method ? 0.0 : l_s))) : l_kap;
+  const double* __restrict__ gsrc = p.rho_rows ? st->GR : (p.mask ? p.mg : st->G);
+  const double gsc = p.rho_rows ? 1.0 : kappa;
+  const bool gsym = p.mask != nullptr;              // the masked step's reduced Gram: both triangles averaged
+  const double iq = 1.0 / q0, ib = p.robust ? 1.0 / p.beta : 1.0;
+  Sw16K swk;
+  sw16k_init(swk, lk, lr);
+  double A[NT][NT][4];
+  bool bad = false;
+#define WB_FOR(body)                                                                   \
+  _Pragma("unroll") for (int ti = 0; ti < NT; ++ti)                                    \
+    _Pragma("unroll") for (int tj = 0; tj < NT; ++tj)                                  \
+      _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                  \
+        const int i = 16 * ti + lk + 4 * q, c = 16 * tj + lr;                          \
+        const bool in = i < r && c < r, pad = (i == c) && i >= r;                      \
+        const int ic = in ? i : 0, cc = in ? c : 0;                                    \
+        (void)pad; (void)ic; (void)cc;                                                 \
+        body                                                                           \
+      }
+#define WB_GK() ((gsym ? 0.5 * (gsrc[ic * r + cc] + gsrc[cc * r + ic]) : gsrc[ic * r + cc]) * gsc)
+  if (carried) {
+    WB_FOR({
+      const double mv = st->Lbar[ic * r + cc] + WB_GK();
+      A[ti][tj][q] = in ? (w == 0 ? mv : mv * ib + (i == c ? iq : 0.0)) : (pad ? 1.0 : 0.0);
+    })
+    wave_sweep_tiles_m<NT>(A, r2, swk, bad);
+    double* dst = w == 0 ? st->Pplus : st->XpY;
+    WB_FOR({ if (in) dst[i * r + c] = -A[ti][tj][q]; })
+  } else {
+    WB_FOR({ A[ti][tj][q] = in ? 0.5 * (st->Pbar[ic * r + cc] + st->Pbar[cc * r + ic]) : (pad ? 1.0 : 0.0); })
+    wave_sweep_tiles_m<NT>(A, r2, swk, bad);                       // -Pbar^-1
+    if (dual) {
+      double Mx[NT][NT][4];
+      WB_FOR({ Mx[ti][tj][q] = in ? WB_GK() - A[ti][tj][q] : (pad ? 1.0 : 0.0); A[ti][tj][q] = Mx[ti][tj][q]; })
+      wave_sweep_tiles_m<NT>(A, r2, swk, bad);                     // -P+
+      WB_FOR({ if (in) st->Pplus[i * r + c] = -A[ti][tj][q]; })
+      WB_FOR({ A[ti][tj][q] = in ? Mx[ti][tj][q] * ib + (i == c ? iq : 0.0) : (pad ? 1.0 : 0.0); })
+      wave_sweep_tiles_m<NT>(A, r2, swk, bad);                     // -W
+      WB_FOR({ if (in) st->XpY[i * r + c] = -A[ti][tj][q]; })
+    } else {
+      WB_FOR({ A[ti][tj][q] = in ? WB_GK() - A[ti][tj][q] : (pad ? 1.0 : 0.0); })
+      wave_sweep_tiles_m<NT>(A, r2, swk, bad);                     // -P+
+      WB_FOR({ if (in) st->Pplus[i * r + c] = -A[ti][tj][q]; })
+    }
+  }
+#undef WB_GK
+#undef WB_FOR
+  if (__builtin_amdgcn_readfirstlane(__any((int)bad)) && lane == 0 && st->err == 0) st->err = (int)(st->k + 1);
+}
+
+__device__ __forceinline__ void solve_block_wave_big(const StepParams& p) {
+  if (p.r <= 48) solve_block_wave_big_t<3>(p);
+  else solve_block_wave_big_t<4>(p);
+}
+
 }  // namespace psmf

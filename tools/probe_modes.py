@@ -26,6 +26,9 @@ cases = [
     ("per-step engine r=32 f64", dict(r=32, engine="step", storage="f64")),
     ("per-step engine r=40 f64", dict(r=40, storage="f64")),
 ]
+only = os.environ.get("ONLY")
+if only:
+    cases = [c for c in cases if only in c[0]]
 for name, kw in cases:
     r = kw.pop("r")
     ser = bench.Series(d, r, T, 4711, 0, d, bool(kw.get("robust", False)))
