@@ -220,12 +220,17 @@ sweep_fn_t sweep_kernel(const psmf_filter* h) {
   return h->cfg.storage == PSMF_F64 ? sweep_for_gs<double, 256>(gs) : sweep_for_gs<float, 256>(gs);
 }
 
+bool serial_wide(const psmf_filter* h) {
+  static const bool off = Switches::off("PSMF_SERIAL_WIDE");
+  return h->geo.rpad >= 64 && !off;
+}
+
 serial_fn_t serial_kernel(const psmf_filter* h) {
   switch (h->geo.rpad) {
     case 8: return psmf::psmf_serial<8>;
     case 16: return psmf::psmf_serial<16>;
     case 32: return psmf::psmf_serial<32>;
-    default: return psmf::psmf_serial<64>;
+    default: return serial_wide(h) ? psmf::psmf_serial_wide : psmf::psmf_serial<64>;
   }
 }
 
@@ -235,7 +240,7 @@ void launch_sweep(psmf_filter* h) {
 }
 
 void launch_serial(psmf_filter* h, int first) {
-  hipLaunchKernelGGL(serial_kernel(h), dim3(1), dim3(psmf::serial_threads(h->geo.rpad)), 0, h->stream, h->sp, first);
+  hipLaunchKernelGGL(serial_kernel(h), dim3(1), dim3(serial_wide(h) ? psmf::SERIAL_WIDE_NT : psmf::serial_threads(h->geo.rpad)), 0, h->stream, h->sp, first);
 }
 
 // one filter step on the stream (captured into the graph or launched eagerly)

@@ -465,9 +465,9 @@ constexpr int SWG = 1024;
 // 512 threads the stage spilled 196 registers to scratch and took 33 us per timestep, profiles/r4_step_engine.txt)
 __host__ __device__ constexpr int serial_threads(int rpad) { return rpad >= 64 ? WG : (rpad >= 32 ? 512 : SWG); }
 
-template <int RPAD>
+template <int RPAD, int NWK = WG>
 __device__ __forceinline__ void col_reduce(double partial, double* s_red, double* s_out) {
-  constexpr int RG = WG / RPAD;
+  constexpr int RG = NWK / RPAD;
   const int tid = threadIdx.x;
   s_red[tid] = partial;  // index = (tid / RPAD) * RPAD + tid % RPAD
   __syncthreads();
@@ -480,29 +480,40 @@ __device__ __forceinline__ void col_reduce(double partial, double* s_red, double
   __syncthreads();
 }
 
+#ifndef PSMF_SERIAL_BUTTERFLY
+#define PSMF_SERIAL_BUTTERFLY 1
+#endif
+constexpr bool SERIAL_BUTTERFLY = PSMF_SERIAL_BUTTERFLY != 0;      // the r-long dot products of the serial stage as wave butterflies (0: every thread sums RPAD products from LDS)
+
+template <int NWK = WG>
 __device__ __forceinline__ double block_sum(double x, double* s4) {   // worker waves only
   x = wave_sum(x);
   if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = x;
   __syncthreads();
-  return (s4[0] + s4[1]) + (s4[2] + s4[3]);
+  double a = 0.0;
+#pragma unroll
+  for (int g = 0; g < NWK / 64; g += 4) a += (s4[g] + s4[g + 1]) + (s4[g + 2] + s4[g + 3]);      // fixed order
+  return a;
 }
 
-template <int RPAD>
+// NWK = worker threads (the r x r work): 256, or 1024 for RPAD = 64 (psmf_serial_wide: 4 elements of every matrix per thread
+// instead of 16 -- the live state fits the 128 registers a wave of a 1024-thread workgroup may hold)
+template <int RPAD, int NWK = WG>
 __device__ __forceinline__ void serial_body(const StepParams& p, const int first) {
-  constexpr int RG = WG / RPAD;
-  constexpr int M = (RPAD * RPAD) / WG > 0 ? (RPAD * RPAD) / WG : 1;
+  constexpr int RG = NWK / RPAD;
+  constexpr int M = (RPAD * RPAD) / NWK > 0 ? (RPAD * RPAD) / NWK : 1;
   constexpr int NSEG = 32;
   DevState* st = p.st;
   const int r = p.r, tid = threadIdx.x;
-  const bool worker = tid < WG;
-  const int j = tid % RPAD, ig = (tid % WG) / RPAD;
+  const bool worker = tid < NWK;
+  const int j = tid % RPAD, ig = (tid % NWK) / RPAD;
   const double dd = (double)p.d;
 
-  __shared__ double s_red[WG];
+  __shared__ double s_red[NWK];
   __shared__ double s_he[2 * (RM + 1)];   // h[0..r), ee at [r]; non-uniform R: b[r+1 .. 2r], q at [2r+1]
   __shared__ double s_w[RM], s_mub[RM], s_f[RM], s_vec[RM];
   __shared__ double s_part[NSEG][2 * (RM + 1)];
-  __shared__ double s4[4];
+  __shared__ double s4[NWK / 64];
 
   PSMF_STAMP(0);
   // ---------------- every global load of the stage, issued up front ----------------
@@ -611,10 +622,16 @@ __device__ __forceinline__ void serial_body(const StepParams& p, const int first
       double part = 0.0;
 #pragma unroll
       for (int m = 0; m < M; ++m) part += val[m] ? Pv[m] * s_b[min(ii[m], r - 1)] : 0.0;
-      col_reduce<RPAD>(part, s_red, s_vec);   // s_vec = Pplus b / bsc
+      col_reduce<RPAD, NWK>(part, s_red, s_vec);   // s_vec = Pplus b / bsc
       double bPb = 0.0;
+      if constexpr (SERIAL_BUTTERFLY) {       // r <= 64 = one wave's width: a butterfly instead of 2 RPAD LDS reads per thread
+        static_assert(NWK == WG || RPAD == 64, "wide serial stage: RPAD = 64");
+        const int l = tid & 63;
+        bPb = wave_sum(l < r ? s_b[l] * s_vec[l] : 0.0);       // (s_vec is written up to RPAD only: select the product, do not multiply by 0)
+      } else {
 #pragma unroll
-      for (int l = 0; l < RPAD; ++l) bPb += (l < r ? s_b[l] : 0.0) * s_vec[l];   // s_vec[l >= r] = 0
+        for (int l = 0; l < RPAD; ++l) bPb += (l < r ? s_b[l] : 0.0) * s_vec[l];   // s_vec[l >= r] = 0
+      }
       quad -= bsc * bsc * bPb;
       if (vl) mu_new = mub_t + bsc * s_vec[tid];
     } else {
@@ -753,13 +770,18 @@ __device__ __forceinline__ void serial_body(const StepParams& p, const int first
     }
   }
   PSMF_STAMP(6);
-  col_reduce<RPAD>(part, s_red, s_vec);   // s_vec = V mu_bar
+  col_reduce<RPAD, NWK>(part, s_red, s_vec);   // s_vec = V mu_bar
   PSMF_STAMP(7);
   double s = 0.0;
+  if constexpr (SERIAL_BUTTERFLY) {
+    const int l = tid & 63;
+    s = wave_sum(l < r ? s_mub[l] * s_vec[l] : 0.0);
+  } else {
 #pragma unroll
-  for (int l = 0; l < RPAD; ++l) s += s_mub[l] * s_vec[l];       // both are 0 beyond r
+    for (int l = 0; l < RPAD; ++l) s += s_mub[l] * s_vec[l];       // both are 0 beyond r
+  }
   double eta = rho * p.rho_mean;                   // tr(R) / d  (rho_mean = 1 unless R is a non-uniform diagonal)
-  if (p.eta_full) eta += block_sum(gp, s4) / dd;   // (tr R + <G, Pbar>) / d   psmf.py:121-125
+  if (p.eta_full) eta += block_sum<NWK>(gp, s4) / dd;   // (tr R + <G, Pbar>) / d   psmf.py:121-125
   const double N = s + eta;
   if (vl) {
     st->w[tid] = s_vec[tid];
@@ -777,6 +799,12 @@ __device__ __forceinline__ void serial_body(const StepParams& p, const int first
 template <int RPAD>
 __global__ __launch_bounds__(serial_threads(RPAD)) void psmf_serial(StepParams p, int first) {
   serial_body<RPAD>(p, first);
+}
+
+// r > 32 (RPAD = 64) with every thread of a 1024-thread workgroup a worker (PSMF_SERIAL_WIDE=0: psmf_serial<64>, 256 workers)
+constexpr int SERIAL_WIDE_NT = 512;
+__global__ __launch_bounds__(SERIAL_WIDE_NT) void psmf_serial_wide(StepParams p, int first) {
+  serial_body<64, SERIAL_WIDE_NT>(p, first);
 }
 
 // local reduction of the per-workgroup partials into st->red (multi-GPU: input of the all-reduce)
