@@ -36,7 +36,10 @@ struct Geometry {
   size_t sweep_lds;
 };
 
-constexpr int kUnroll = 4;
+#ifndef PSMF_SWEEP_UNROLL
+#define PSMF_SWEEP_UNROLL 4
+#endif
+constexpr int kUnroll = PSMF_SWEEP_UNROLL;      // row passes (16-byte loads per lane) in flight in the sweep
 constexpr int kGramWG = 128;
 
 }  // namespace
