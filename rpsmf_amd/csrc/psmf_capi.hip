@@ -712,7 +712,7 @@ void compute_geometry(const psmf_config& c, Geometry& g) {
   g.nv = (c.r + g.vec - 1) / g.vec;
   g.rp = g.nv * g.vec;
   g.gs = next_pow2(g.nv);
-  g.nt = c.r > 32 ? 256 : sweep_threads();      // r > 32: the solve block (16 matrix elements per thread) needs a 256-thread kernel's register budget
+  g.nt = c.r > 32 ? 256 : sweep_threads();      // r > 32: the solve block (3 x 3 / 4 x 4 tiles of 16 x 16 in ONE wave's registers) needs a 256-thread kernel's register budget
   g.rpp = g.nt / g.gs;
   g.rpad = next_pow2(c.r < 8 ? 8 : c.r);
   const size_t solve_lds = c.coef_update ? (size_t)(4 * psmf::RM + 2) * 8 : 0;

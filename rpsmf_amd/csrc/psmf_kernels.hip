@@ -461,8 +461,10 @@ __global__ __launch_bounds__(NT) void psmf_sweep_solve(StepParams p) {
 // ------------------------------------------------------------------------------------------
 constexpr int SWG = 1024;
 // r > 16: the worker threads keep 4 matrices x (4..16) elements in registers -- 8 waves (256 VGPRs each) instead of 16 (128: spills);
-// r > 32 (RPAD = 64: 16 elements of each matrix per thread): the 4 worker waves alone, a whole SIMD's register file each (with
-// 512 threads the stage spilled 196 registers to scratch and took 33 us per timestep, profiles/r4_step_engine.txt)
+// r > 32 (RPAD = 64): psmf_serial_wide -- 512 WORKERS, 8 elements of each matrix per thread (12.9 us per timestep).  psmf_serial<64>
+// (256 workers x 16 elements, a whole SIMD's register file per wave: 20 us, 18.5 k of its 41.5 k cycles spent issuing loads) remains
+// behind PSMF_SERIAL_WIDE=0 and as block 0 of psmf_serial_mgram<64, ...>; with 512 threads and 256 workers the stage had spilled 196
+// registers and taken 33 us (profiles/r4_step_engine.txt)
 __host__ __device__ constexpr int serial_threads(int rpad) { return rpad >= 64 ? WG : (rpad >= 32 ? 512 : SWG); }
 
 template <int RPAD, int NWK = WG>
@@ -496,8 +498,8 @@ __device__ __forceinline__ double block_sum(double x, double* s4) {   // worker 
   return a;
 }
 
-// NWK = worker threads (the r x r work): 256, or 1024 for RPAD = 64 (psmf_serial_wide: 4 elements of every matrix per thread
-// instead of 16 -- the live state fits the 128 registers a wave of a 1024-thread workgroup may hold)
+// NWK = worker threads (the r x r work): 256, or SERIAL_WIDE_NT = 512 for RPAD = 64 (psmf_serial_wide: 8 elements of every matrix
+// per thread instead of 16; 1 024 workers x 4 elements spill under the 128-register cap: 32.7 us per timestep at r = 40 against 29.9)
 template <int RPAD, int NWK = WG>
 __device__ __forceinline__ void serial_body(const StepParams& p, const int first) {
   constexpr int RG = NWK / RPAD;
@@ -801,7 +803,7 @@ __global__ __launch_bounds__(serial_threads(RPAD)) void psmf_serial(StepParams p
   serial_body<RPAD>(p, first);
 }
 
-// r > 32 (RPAD = 64) with every thread of a 1024-thread workgroup a worker (PSMF_SERIAL_WIDE=0: psmf_serial<64>, 256 workers)
+// r > 32 (RPAD = 64) with every thread of a 512-thread workgroup a worker (PSMF_SERIAL_WIDE=0: psmf_serial<64>, 256 workers)
 constexpr int SERIAL_WIDE_NT = 512;
 __global__ __launch_bounds__(SERIAL_WIDE_NT) void psmf_serial_wide(StepParams p, int first) {
   serial_body<64, SERIAL_WIDE_NT>(p, first);
