@@ -447,6 +447,11 @@ def load_pmc(name):
 
 def main():
     args = parse()
+    # The contract is ONE JSON line on stdout.  Libraries underneath write there too (gloo's "Rank 0 is connected to ..." line, RCCL's
+    # version banner at communicator creation -- from C, straight to file descriptor 1): everything but the final line goes to stderr.
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -758,7 +763,10 @@ def main():
                 except Exception as e:
                     other["D_100_repeats"] = {"error": repr(e)}
                 line["other_configs"] = other
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
         print(json.dumps(line), flush=True)
+        os.dup2(2, 1)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -30,6 +30,8 @@ def test_bench_two_ranks_one_gpu(engine, d, r):
     assert pr.returncode == 0, pr.stdout[-2000:] + pr.stderr[-3000:]
     lines = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, pr.stdout[-2000:]          # rank 0 prints ONE JSON line
+    # ... and nothing else reaches stdout (gloo's connection line and RCCL's version banner used to: bench.py sends them to stderr)
+    assert [ln for ln in pr.stdout.splitlines() if ln.strip()] == lines, pr.stdout[:2000]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0 and out["config"]["engine"] == engine
     par = out["parity_vs_cpu_oracle"]
