@@ -957,6 +957,7 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
       int* dres = nullptr;
       CREATE_TRY(hipMalloc((void**)&dres, sizeof(int)));
       CREATE_TRY(hipMemset(dres, 0, sizeof(int)));
+      CREATE_TRY(hipDeviceSynchronize());      // hipMemset is asynchronous on the null stream, the probe's streams are non-blocking: the zeroes (of dres and of h->flags above) first
       hipLaunchKernelGGL(psmf::psmf_probe_wait_k, dim3(1), dim3(1), 0, h->fstream, h->flags + 7, 1LL, 5000000LL, dres);
       hipLaunchKernelGGL(psmf::psmf_flag_set_k, dim3(1), dim3(1), 0, h->bulk, h->flags + 7, 1LL);
       CREATE_TRY(hipStreamSynchronize(h->fstream));
@@ -1033,6 +1034,8 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
   sp.alpha = cfg->alpha; sp.beta = cfg->beta;
   sp.lr = cfg->adam_lr; sp.lr_end = cfg->adam_lr_end; sp.lr_steps = cfg->adam_lr_steps;
   sp.b1 = cfg->adam_b1; sp.b2 = cfg->adam_b2;
+  // the zero-fills above ran on the null stream; the handle's own streams are non-blocking
+  if (hipDeviceSynchronize() != hipSuccess) { h->err = "hipDeviceSynchronize at the end of psmf_create failed"; return bail(PSMF_ERR_HIP); }
   *out = h;
   return PSMF_OK;
 }
@@ -1515,7 +1518,7 @@ int psmf_counters(psmf_handle h, int64_t* out8, int reset) {
   if (getenv("PSMF_DBG_BREAKDOWN") && c[7] > 0)
     fprintf(stderr, "[psmf] filter3 per launch: hand-off %.2f us, K %.2f, init %.2f, steps %.2f, end %.2f\n", 0.01 * g[0] / c[7], 0.01 * g[1] / c[7],
             0.01 * g[2] / c[7], 0.01 * g[3] / c[7], 0.01 * g[4] / c[7]);
-  if (reset) { HIP_TRY(h, hipMemset(h->st->cnt, 0, sizeof(c))); HIP_TRY(h, hipMemset(h->st->dbg, 0, sizeof(g))); }
+  if (reset) { HIP_TRY(h, hipMemset(h->st->cnt, 0, sizeof(c))); HIP_TRY(h, hipMemset(h->st->dbg, 0, sizeof(g))); HIP_TRY(h, hipDeviceSynchronize()); }   // (before the next run's kernels on the non-blocking stream count)
   return PSMF_OK;
 }
 
@@ -1938,6 +1941,7 @@ int psmf_measure_copy_bandwidth(int device, size_t bytes, int iters, double* gbp
   HIP_TRY(h, hipMalloc(&src, n16 * 16));
   HIP_TRY(h, hipMalloc(&dst, n16 * 16));
   HIP_TRY(h, hipMemset(src, 1, n16 * 16));
+  HIP_TRY(h, hipDeviceSynchronize());
   HIP_TRY(h, hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
   HIP_TRY(h, hipEventCreate(&e0));
   HIP_TRY(h, hipEventCreate(&e1));
