@@ -16,8 +16,118 @@
 // Same recursion and float64 arithmetic as psmf_blk_filter (summation orders differ).  PSMF_FILTER7=0: back to psmf_blk_filter<32>.
 #pragma once
 #include "psmf_blk16.hip"
+#ifndef PSMF_F7_FWD
+#define PSMF_F7_FWD 1
+#endif
 
 namespace psmf {
+
+// dyn_forward (psmf_dyn.hip) for the dense trigonometric kinds (scaled sinusoid, Fourier basis with N <= 2) at 17 <= r <= 32, theta in
+// LDS: what f6_dyn_forward (psmf_blk16.hip) is for r <= 16, on 32-wide index maps -- thread = (term, column) for the trig values,
+// thread = (row group, column) for six elements of F, no integer division by the runtime r, the matrix elements and gains an element
+// of F needs cached in registers for the block when theta cannot change inside it (no in-loop optimiser), TWO barriers instead of
+// three (mu_bar_i: one thread per row walks the terms, no partial sums across threads).  The generic routine took 7 000 of a
+// FourierBasis step's 31 700 cycles at r = 20 (tools/blk32_prof.hip): every sum waited for its LDS operands one by one and every
+// element divided twice.  Same sums in the same order.  tid = 0 .. 191 (waves 1-3); the matrix wave keeps the barrier count (2).
+struct F7Jac {
+  double m[6][4], c[4];
+};
+__device__ __forceinline__ bool f7_fwd_ok(const StepParams& p) {
+  if (!(p.dyn_kind == DYN_FOURIER || p.dyn_kind == DYN_SINUSOID) || !dyn_dense(p.dyn_kind, p.dyn_flags)) return false;
+  const int nt = dyn_n_terms(p.dyn_kind, p.dyn_terms);
+  if (nt < 1 || nt > 4 || p.r > 32) return false;
+  for (int t = 0; t < nt; ++t)
+    if (dyn_term(p.dyn_kind, p.dyn_flags, p.dyn_terms, p.r, t).m_off < 0) return false;      // (every term of these kinds has its matrix)
+  return true;
+}
+__device__ __forceinline__ void f7_jac_cache(F7Jac& jc, const StepParams& p, const double* th, const int tid) {
+  const int r = p.r, nt = dyn_n_terms(p.dyn_kind, p.dyn_terms), j = tid & 31, jc_ = min(j, r - 1);
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt) {
+    const DynTerm dt = dyn_term(p.dyn_kind, p.dyn_flags, p.dyn_terms, r, min(tt, nt - 1));
+    jc.c[tt] = tt < nt ? (dt.c_off >= 0 ? th[dt.c_off + jc_] : 1.0) : 0.0;                   // a slot beyond nt adds nothing
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const int i = (tid >> 5) + 6 * k;
+      jc.m[k][tt] = (tt < nt && i < r && j < r) ? th[dt.m_off + i * r + j] : 0.0;
+    }
+  }
+}
+__device__ __forceinline__ void f7_dyn_forward(const StepParams& p, const double* th, const F7Jac& jc, const bool cached, const double tk,
+                                               const double* s_x, double* s_mub, double* sF, const int ldf, double* s_val, double* s_tp,
+                                               const int tid) {
+  const int r = p.r, kind = p.dyn_kind, flags = p.dyn_flags, N = p.dyn_terms;
+  const int nt = dyn_n_terms(kind, N);
+  const int t = tid >> 5, j = tid & 31;
+  if (t < nt && j < r) {
+    const DynTerm d = dyn_term(kind, flags, N, r, t);
+    const double c = d.c_off >= 0 ? th[d.c_off + j] : 1.0;
+    double sn, cs;
+    dyn_sincospi(2.0 * th[d.b_off + j] * tk + (c * s_x[j]) * 0.31830988618379067154, sn, cs);
+    s_val[t * RM + j] = d.is_cos ? cs : sn;
+    s_tp[t * RM + j] = d.is_cos ? -sn : cs;
+  }
+  __syncthreads();
+  {     // F[i][j] = sum_t M_t[i][j] trig_t'(arg_tj) c_t[j]: six elements per thread, the four term slots straight-line
+    const int jl = min(j, r - 1);
+    double tp[4];
+    if (cached) {
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) tp[tt] = s_tp[min(tt, nt - 1) * RM + jl] * jc.c[tt];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const int i = (tid >> 5) + 6 * k;
+        double a = 0.0;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) a += jc.m[k][tt] * tp[tt];
+        if (i < r && j < r) sF[i * ldf + j] = a;
+      }
+    } else {            // theta moves inside the block (PSMFRecursive): the operands from LDS, all in flight before the first use
+      int mo[4];
+#pragma unroll
+      for (int tt = 0; tt < 4; ++tt) {
+        const DynTerm dt = dyn_term(kind, flags, N, r, min(tt, nt - 1));
+        mo[tt] = dt.m_off;
+        const double cj = dt.c_off >= 0 ? th[dt.c_off + jl] : 1.0;
+        tp[tt] = tt < nt ? s_tp[tt * RM + jl] * cj : 0.0;
+      }
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+        const int i = (tid >> 5) + 6 * k, il = min(i, r - 1);
+        double mv[4];
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) mv[tt] = th[mo[tt] + il * r + jl];
+        double a = 0.0;
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) a += mv[tt] * tp[tt];
+        if (i < r && j < r) sF[i * ldf + j] = a;
+      }
+    }
+  }
+  if (tid < 64) {       // mu_bar_i = sum_t (M_t trig_t)_i: lane = (row i, half h); half h walks the terms h, h + 2 -- a lone wave pays per
+                        // INSTRUCTION (one per 5-9 cycles), so the 32-long sums of two terms side by side, then one lane swap
+    const int i = min(tid & 31, r - 1), hf = tid >> 5;
+    double a = 0.0;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int tt = hf + 2 * u;
+      if (tt < nt) {
+        const DynTerm dt = dyn_term(kind, flags, N, r, tt);
+        const double* row = th + dt.m_off + i * r;
+        double mv[32], sv[32];
+#pragma unroll
+        for (int q = 0; q < 32; ++q) { mv[q] = row[min(q, r - 1)]; sv[q] = s_val[tt * RM + q]; }      // s_val is zero beyond column r
+        double at = 0.0;
+#pragma unroll
+        for (int q = 0; q < 32; ++q) at += mv[q] * sv[q];
+        a += at;
+      }
+    }
+    a = xor32_sum_f64(a);
+    if (tid < r) s_mub[tid] = a;
+  }
+  __syncthreads();
+}
 
 template <int ROLE>
 __device__ __forceinline__ void f7_program(const BlockParams& b) {
@@ -76,7 +186,9 @@ __device__ __forceinline__ void f7_program(const BlockParams& b) {
   if (tid < RM) { s_mub[tid] = 0.0; s_h[tid] = 0.0; s_w[tid] = 0.0; s_f[tid] = 1.0; s_munew[tid] = 0.0; s_gf[tid] = 0.0; }
   for (int idx = tid; idx < (RM / 2) * RS; idx += WG) sF[idx] = 0.0;        // wave 0 reads whole tiles: zero outside r x r
   for (int idx = tid; idx < DYN_MAX_TERMS * RM; idx += WG) { s_val[idx] = 0.0; s_tp[idx] = 0.0; }
-  const int nbar_fwd = f6_dyn_barriers(p, false);
+  // the 32-wide forward pass of the dense trigonometric kinds (PSMF_F7_FWD=0 at build time: the generic dyn_forward)
+  const bool f7fwd = PSMF_F7_FWD && th_lds && f7_fwd_ok(p);
+  const int nbar_fwd = f7fwd ? 2 : f6_dyn_barriers(p, false);
   if (tid < r) s_mu[tid] = st->mu[tid];
   // ---- lane predicates as multipliers, per dimension: element (16 ti + lk + 4 q, 16 tj + lr) ----
   double frow[2][4], fcol[2], dgq[4], raug[2][4], caug[2];
@@ -121,6 +233,8 @@ __device__ __forceinline__ void f7_program(const BlockParams& b) {
   double rho = st->rho, lam = st->lam;
   bool bad = false;
   __syncthreads();
+  F7Jac jcache;
+  if (wv != 0 && f7fwd && !p.recursive) f7_jac_cache(jcache, p, s_theta, tid - 64);      // (s_theta is complete behind the barrier above)
   // A_0 = [I; 0], K A_0 = first r columns of K, G_0 = K[0:r, 0:r]; columns r .. RS - 1 zero
   for (int idx = tid; idx < RB * RS; idx += WG) {
     const int m = idx / RS, c = idx - m * RS;
@@ -146,6 +260,7 @@ __device__ __forceinline__ void f7_program(const BlockParams& b) {
     const long long kstep = b.k0 + jb + 1;   // 1-based step index
     // ---- mu_bar = f(theta, mu, k), F = df/dx (psmf.py:104-115; psmf_dyn.hip): waves 1-3; the matrix wave joins the barriers ----
     if (wv == 0) { for (int q = 0; q < nbar_fwd; ++q) __syncthreads(); }
+    else if (f7fwd) f7_dyn_forward(p, s_theta, jcache, !p.recursive, (double)kstep, s_mu, s_mub, sF, RS, s_val, s_tp, tid - 64);
     else dyn_forward<WG - 64>(pd, (double)kstep, s_mu, s_mub, s_f, sF, RS, s_val, s_tp, sT, tid - 64);
     BLK_T(0);
     const double qs = p.q_sched ? p.q_sched[kstep - p.series_t0] : 1.0;
