@@ -296,7 +296,9 @@ __device__ __forceinline__ void f7_program(const BlockParams& b) {
 #pragma unroll
               for (int tk = 0; tk < 2; ++tk)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Pm[tk][ti][q], Fr[tj][tk][q], acc, 0, 0, 0);
+                for (int q = 0; q < 4; ++q)
+                  if (16 * tk + 4 * q < r)            // (uniform) inner indices beyond r are zero padding: r = 20 runs 5 of the 8 k-steps
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Pm[tk][ti][q], Fr[tj][tk][q], acc, 0, 0, 0);
               T[ti][tj] = acc;                                        // (P F^T)(ti, tj)
             }
 #pragma unroll
@@ -307,7 +309,9 @@ __device__ __forceinline__ void f7_program(const BlockParams& b) {
 #pragma unroll
               for (int tk = 0; tk < 2; ++tk)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Fr[ti][tk][q], T[tk][tj][q], acc, 0, 0, 0);
+                for (int q = 0; q < 4; ++q)
+                  if (16 * tk + 4 * q < r)
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Fr[ti][tk][q], T[tk][tj][q], acc, 0, 0, 0);
 #pragma unroll
               for (int q = 0; q < 4; ++q) {
                 Pb[ti][tj][q] = fma(qs, Qm[ti][tj][q], acc[q]);
