@@ -37,7 +37,7 @@ constexpr int RB = 64;           // r + B, padded coefficient dimension (r <= 32
 constexpr int RS = RM / 2 + 1;   // LDS row stride of the RB x r coefficient matrices (odd: lane = row reads are conflict-free)
 constexpr int BLK_GRAM_WG = 256; // workgroups (= partials) of the block Gram
 constexpr int XGB = 64;          // column capacity of the cross-Gram (>= block length)
-constexpr int BLK_TH_CAP = 2048; // psmf_blk_filter: theta / gradient sums of at most this many parameters live in LDS during a block
+constexpr int BLK_TH_CAP = 2304; // theta / gradient sums of at most this many parameters live in LDS during a block (FourierBasis N = 1 at r = 32: 2176; 147 KB of LDS in all)
 
 struct BlockParams {
   StepParams sp;
