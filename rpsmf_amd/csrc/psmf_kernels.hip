@@ -541,21 +541,19 @@ __device__ __forceinline__ void serial_body(const StepParams& p, const int first
     ii[m] = ig + m * RG;
     val[m] = worker && (j < r) && (ii[m] < r);
     const int idx = val[m] ? ii[m] * r + j : 0;
-    const int idt = val[m] ? j * r + ii[m] : 0;
-    const double lv = st->V[idx], lg = st->G[idx], lq = st->Q[idx], lp = psrc[idx], lt = psrc[idt];   // unconditional
+    const double lv = st->V[idx], lg = st->G[idx], lq = st->Q[idx], lp = psrc[idx];   // unconditional
     Vv[m] = val[m] ? lv : 0.0;
     Gv[m] = val[m] ? lg : 0.0;
     Qv[m] = val[m] ? lq : 0.0;
-    Pv[m] = val[m] ? 0.5 * (lp + lt) : 0.0;
+    Pv[m] = lp;           // as stored; symmetrised through LDS below
   }
   // inversions side by side (solve_dual): W of this step -> Lbar of the next (written with the r x r updates below)
   const bool dual = p.solve_dual && !first;
   double Wv[M];
 #pragma unroll
   for (int m = 0; m < M; ++m) {
-    const int idx = val[m] ? ii[m] * r + j : 0, idt = val[m] ? j * r + ii[m] : 0;
-    const double lw = st->XpY[idx], lwt = st->XpY[idt];
-    Wv[m] = (dual && val[m]) ? 0.5 * (lw + lwt) : 0.0;
+    const int idx = val[m] ? ii[m] * r + j : 0;
+    Wv[m] = st->XpY[idx];
   }
   const double q_old = st->Q[0];
   double rho = st->rho, lam = st->lam;
@@ -581,6 +579,31 @@ __device__ __forceinline__ void serial_body(const StepParams& p, const int first
 
   asm volatile("" :: "v"(psum), "v"(Vv[0]), "v"(Pv[0]));
   PSMF_STAMP(1);
+  // P+ (P at a run's start) and W come from the solve block symmetric only up to round-off: (X + X^T) / 2, the transpose taken through
+  // LDS -- s_part's memory, free until the partial rows are staged below.  (As transposed GLOBAL loads -- 64 cache lines per wave
+  // instruction -- they were 8 000 of the 18 000 cycles the stage spent on its loads at RPAD = 64, tools/serial_prof.hip.)
+  {
+    constexpr int TS = RPAD + 1;
+    static_assert(RPAD * TS <= NSEG * 2 * (RM + 1), "transposition buffer aliases s_part");
+    double* s_T = &s_part[0][0];
+#pragma unroll
+    for (int m = 0; m < M; ++m) if (val[m]) s_T[ii[m] * TS + j] = Pv[m];
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < M; ++m) Pv[m] = val[m] ? 0.5 * (Pv[m] + s_T[j * TS + ii[m]]) : 0.0;
+    if (dual) {        // uniform
+      __syncthreads();
+#pragma unroll
+      for (int m = 0; m < M; ++m) if (val[m]) s_T[ii[m] * TS + j] = Wv[m];
+      __syncthreads();
+#pragma unroll
+      for (int m = 0; m < M; ++m) Wv[m] = val[m] ? 0.5 * (Wv[m] + s_T[j * TS + ii[m]]) : 0.0;
+    } else {
+#pragma unroll
+      for (int m = 0; m < M; ++m) Wv[m] = 0.0;
+    }
+    __syncthreads();
+  }
   if (tid < 2 * (RM + 1)) s_he[tid] = 0.0;
   if (tid < RM) { s_mub[tid] = 0.0; s_w[tid] = 0.0; }
   if (!first) {

@@ -2,6 +2,7 @@
 #define PSMF_SERIAL_STAMPS 1
 #include "../rpsmf_amd/csrc/psmf_kernels.hip"
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 using namespace psmf;
 #ifndef PROF_R
@@ -25,7 +26,7 @@ int main() {
   // the stage loads theta / gradsum / Adam moments unconditionally (RM entries each, masked afterwards): they must point at memory
   double* th; hipMalloc((void**)&th, 4 * RM * 8); hipMemset(th, 0, 4 * RM * 8);
   p.theta = th; p.gradsum = th + RM; p.adam_m = th + 2 * RM; p.adam_v = th + 3 * RM; p.rp = (r + 3) / 4 * 4; p.nv = (r + 3) / 4; p.rows_per_wg = 224; p.solve_dual = PROF_R > 32 ? 1 : 0;
-  for (int it = 0; it < 3; ++it) { psmf_serial<RPAD><<<1, serial_threads(RPAD)>>>(p, 0); hipDeviceSynchronize(); }
+  for (int it = 0; it < 3; ++it) { if (RPAD == 64 && !getenv("NARROW")) psmf_serial_wide<<<1, SERIAL_WIDE_NT>>>(p, 0); else psmf_serial<RPAD><<<1, serial_threads(RPAD)>>>(p, 0); hipDeviceSynchronize(); }
   unsigned long long h[16]; hipMemcpy(h, reinterpret_cast<unsigned long long*>(part) + 4096, 16 * 8, hipMemcpyDeviceToHost);
   const char* nm[8] = {"issue loads", "partials->LDS reduce (+wait for loads)", "P+h col-reduce, mu", "gradient/robust scalars", "elementwise V,P,G + stores", "prep: mu_bar, Pbar, partials", "col-reduce V mu_bar", "s, <G,Pbar>, N, stores"};
   for (int q = 0; q < 8; ++q) printf("%-44s %6llu cycles\n", nm[q], h[q + 1] - h[q]);
