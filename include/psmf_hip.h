@@ -108,7 +108,10 @@ typedef struct {
 /* replaces PSMFIter.__init__ / rPSMFIter.__init__  (psmf.py:18-46, rpsmf.py:12-51) */
 int psmf_create(psmf_handle* out, const psmf_config* cfg);
 void psmf_destroy(psmf_handle h);
-const char* psmf_last_error(psmf_handle h); /* h may be NULL: error of the last failed create */
+const char* psmf_last_error(psmf_handle h);
+/* SHA-256 (hex) of the sources and compiler flags this library was built from (rpsmf_amd/build.py compares it with the sources on
+ * disk: a stale binary is rebuilt, never silently used).  (New: the reference is interpreted Python.) */
+const char* psmf_build_id(void); /* h may be NULL: error of the last failed create */
 int psmf_device_count(void);
 
 /* ---- state ----------------------------------------------------------------------------- */
@@ -240,7 +243,8 @@ int psmf_geometry(psmf_handle h, int32_t* out7);
  * last uploaded, schedules, switches): 0 = per-step engine (psmf_sweep_solve + psmf_serial), 1 = psmf_blk_filter (general blocked
  * kernel), 2 = psmf_blk_filter2, 3 = psmf_blk_filter3, 4 = psmf_blk_filter3s, 5 = psmf_blk_filter4, 6 = psmf_blk_filter4s, 7 = psmf_blk_filter5,
  * 8 = psmf_blk_filter6 (every configuration at r <= 16 but the simplified hooks), 9 = psmf_blk_filter6d (its instantiation with the two
- * inversions side by side: random walk, Q = q I), 10 = psmf_blk_filter7 (the same design on 2 x 2 tiles: what is left at 17 <= r <= 32).
+ * inversions side by side: random walk, Q = q I), 10 = psmf_blk_filter7 (the same design on 2 x 2 tiles: what is left at 17 <= r <= 32),
+ * 11 = psmf_pstep_k, the per-step engine as ONE persistent launch per run (C on chip, device-flag hand-offs; psmf_pstep.hip).
  * The same function decides what is launched (select_filter_kernel, psmf_capi.hip).
  * (New: diagnostics for tests and bench.py -- the reference has one code path, pypsmf/psmf/psmf.py:90-102.) */
 int psmf_filter_kernel(psmf_handle h);

@@ -48,6 +48,7 @@ SIGNATURES = {
     "psmf_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(PsmfConfig)]),
     "psmf_destroy": (None, [C.c_void_p]),
     "psmf_last_error": (C.c_char_p, [C.c_void_p]),
+    "psmf_build_id": (C.c_char_p, []),
     "psmf_device_count": (C.c_int, []),
     "psmf_set_state": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _dp, C.c_double, C.c_double, _dp]),
     "psmf_zero_gradsum": (C.c_int, [C.c_void_p]),
@@ -344,7 +345,7 @@ class DeviceFilter:
         g = (C.c_int32 * 7)()
         self._check(self._lib.psmf_geometry(self._h, g))
         kern = {0: "psmf_sweep_solve", 1: "psmf_blk_filter", 2: "psmf_blk_filter2", 3: "psmf_blk_filter3", 4: "psmf_blk_filter3s",
-                5: "psmf_blk_filter4", 6: "psmf_blk_filter4s", 7: "psmf_blk_filter5", 8: "psmf_blk_filter6", 9: "psmf_blk_filter6d", 10: "psmf_blk_filter7"}.get(self._lib.psmf_filter_kernel(self._h), "?")
+                5: "psmf_blk_filter4", 6: "psmf_blk_filter4s", 7: "psmf_blk_filter5", 8: "psmf_blk_filter6", 9: "psmf_blk_filter6d", 10: "psmf_blk_filter7", 11: "psmf_pstep_k"}.get(self._lib.psmf_filter_kernel(self._h), "?")
         return dict(n_sweep_wg=g[0], rows_per_wg=g[1], row_stride=g[2], lanes_per_row=g[3], graph_chunk=g[4],
                     engine={1: "step", 2: "block"}.get(g[5], g[5]), block_steps=g[6], filter_kernel=kern)
 

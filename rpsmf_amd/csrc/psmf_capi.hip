@@ -11,6 +11,7 @@
 #include "psmf_blk32.hip"
 #include "psmf_bulk.hip"
 #include "psmf_rotate.hip"
+#include "psmf_pstep.h"       // persistent per-step engine: its kernels are a translation unit of their own (psmf_pstep.hip)
 
 #include <rccl/rccl.h>
 
@@ -20,6 +21,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -49,11 +51,13 @@ constexpr int kGramWG = 128;
 struct Switches {
   bool block_mfma = true, bulk2 = true, filter3 = true, filter4 = true, filter6 = true, filter7 = true, filter6_dual = true, block_dual = true, block_flags = true, block_chain = true, block_pipe = true;
   bool force_collective = false;
+  bool step_persistent = true;      // per-step engine: one persistent launch per run (psmf_pstep.hip) where it applies; PSMF_STEP_PERSISTENT=0: two launches per timestep
   static bool off(const char* name) { const char* e = getenv(name); return e && atoi(e) == 0; }
   void read() {
     block_mfma = !off("PSMF_BLOCK_MFMA"); bulk2 = !off("PSMF_BULK2"); filter3 = !off("PSMF_FILTER3"); filter4 = !off("PSMF_FILTER4"); filter6 = !off("PSMF_FILTER6"); filter7 = !off("PSMF_FILTER7"); filter6_dual = !off("PSMF_FILTER6_DUAL"); block_dual = !off("PSMF_BLOCK_DUAL");
     block_flags = !off("PSMF_BLOCK_FLAGS"); block_chain = !off("PSMF_BLOCK_CHAIN"); block_pipe = !off("PSMF_BLOCK_PIPE");
     force_collective = getenv("PSMF_FORCE_COLLECTIVE") != nullptr;
+    step_persistent = !off("PSMF_STEP_PERSISTENT");
   }
 };
 
@@ -116,6 +120,11 @@ struct psmf_filter {
   hipGraph_t graph = nullptr;
   hipGraphExec_t gexec = nullptr;
   int chunk = 0;
+  // persistent per-step engine (psmf_pstep.hip): geometry of a launch and its communication block (flags | packet | partial rows)
+  psmf::PstepPlan ps_plan = {};
+  bool ps_ok = false;
+  void* ps_comm = nullptr;
+  long long ps_launches = 0;
   bool have_state = false;
   bool need_prep = true;
   int64_t k_done = 0;
@@ -363,10 +372,17 @@ bool blk_simpl_ok(const psmf_filter* h) {
 // and psmf_filter_kernel reports it (tests and bench.py quote that name as evidence of what ran).  Values = the codes of
 // psmf_filter_kernel in include/psmf_hip.h.
 enum FilterKernel { FK_STEP = 0, FK_GENERAL = 1, FK_FILTER2 = 2, FK_FILTER3 = 3, FK_FILTER3S = 4, FK_FILTER4 = 5, FK_FILTER4S = 6,
-                    FK_FILTER5 = 7, FK_FILTER6 = 8, FK_FILTER6D = 9, FK_FILTER7 = 10 };
+                    FK_FILTER5 = 7, FK_FILTER6 = 8, FK_FILTER6D = 9, FK_FILTER7 = 10, FK_PSTEP = 11 };
+
+// Can the handle's next run go through the persistent per-step kernel?  (one rank, uniform diagonal R, no mask, random walk or
+// cos-phase dynamics, r <= 32, rows that fit the row workgroups' registers; everything else keeps the two launches per timestep)
+bool pstep_usable(const psmf_filter* h) {
+  return h->engine == 1 && h->ps_ok && h->sw.step_persistent && !h->use_coll && !h->host_fn && !h->sp.rho_rows && !h->cfg.masked &&
+         !h->cfg.nonuniform_R && h->cfg.dyn_kind <= PSMF_DYN_COS_PHASE && !h->sp.solve_lds;
+}
 
 FilterKernel select_filter_kernel(const psmf_filter* h) {
-  if (h->engine != 2) return FK_STEP;
+  if (h->engine != 2) return pstep_usable(h) ? FK_PSTEP : FK_STEP;
   if (blk_simpl_ok(h)) return FK_FILTER5;
   const bool dual3 = blk_dual_ok(h) && blk_use_filter3(h);
   if (!dual3 && blk_seq_ok(h)) return h->cfg.r > 16 ? FK_FILTER4 : FK_FILTER4S;
@@ -415,6 +431,7 @@ void launch_blk_filter(psmf_filter* h, const psmf::BlockParams& b, hipStream_t s
     case FK_FILTER7: hipLaunchKernelGGL(psmf::psmf_blk_filter7, dim3(1), dim3(psmf::WG), lds, stream, b); return;
     case FK_GENERAL:
     case FK_STEP:
+    case FK_PSTEP:
       break;
   }
   switch (h->geo.rpad) {
@@ -741,6 +758,40 @@ void update_solve_dual(psmf_filter* h) {
   }
 }
 
+// Persistent kernels spin on device flags: two of them resident at once (two handles of one process on one device) could each
+// hold compute units the other needs.  They are serialised per device with an event chain.
+std::mutex g_ps_mutex;
+hipEvent_t g_ps_event[64] = {};
+
+int launch_pstep(psmf_filter* h, int64_t k_begin, int64_t n) {
+  while (n > 0) {
+    const int64_t chunk = n > (int64_t)1 << 30 ? (int64_t)1 << 30 : n;
+    psmf::PstepParams q;
+    memset(&q, 0, sizeof(q));
+    q.sp = h->sp;
+    q.k_begin = k_begin;
+    q.n_steps = (int)chunk;
+    q.n_row_wg = h->ps_plan.n_row_wg;
+    q.rows_per_wg = h->ps_plan.rows_per_wg;
+    q.np = h->ps_plan.np;
+    q.ncol2 = h->ps_plan.ncol2;
+    q.flags = reinterpret_cast<unsigned*>(h->ps_comm);
+    q.pkt = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(h->ps_comm) + h->ps_plan.off_pkt);
+    q.part = reinterpret_cast<double*>(reinterpret_cast<char*>(h->ps_comm) + h->ps_plan.off_part);
+    std::lock_guard<std::mutex> lock(g_ps_mutex);
+    const int dev = h->cfg.device & 63;
+    if (!g_ps_event[dev]) HIP_TRY(h, hipEventCreateWithFlags(&g_ps_event[dev], hipEventDisableTiming));
+    else HIP_TRY(h, hipStreamWaitEvent(h->stream, g_ps_event[dev], 0));
+    HIP_TRY(h, hipMemsetAsync(h->ps_comm, 0, h->ps_plan.zero_bytes, h->stream));      // every polled word, before every launch
+    HIP_TRY(h, psmf::pstep_launch(q, h->cfg.storage == PSMF_F64, h->stream));
+    HIP_TRY(h, hipEventRecord(g_ps_event[dev], h->stream));
+    ++h->ps_launches;
+    k_begin += chunk;
+    n -= chunk;
+  }
+  return PSMF_OK;
+}
+
 int set_device(psmf_handle h) {
   HIP_TRY(h, hipSetDevice(h->cfg.device));
   return PSMF_OK;
@@ -993,6 +1044,16 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
   }
   if (h->geo.sweep_lds > 48 * 1024)
     CREATE_TRY(hipFuncSetAttribute((const void*)sweep_kernel(h), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->geo.sweep_lds));
+  if (h->engine == 1 && h->sw.step_persistent && cfg->r <= 32 && !cfg->masked && !cfg->nonuniform_R && cfg->dyn_kind <= PSMF_DYN_COS_PHASE) {
+    hipDeviceProp_t prop;
+    CREATE_TRY(hipGetDeviceProperties(&prop, cfg->device));
+    if (psmf::pstep_plan(cfg->d_local, cfg->r, prop.multiProcessorCount, cfg->storage == PSMF_F64, &h->ps_plan)) {
+      CREATE_TRY(psmf::pstep_init());
+      CREATE_TRY(hipMalloc(&h->ps_comm, h->ps_plan.total_bytes));
+      CREATE_TRY(hipMemset(h->ps_comm, 0, h->ps_plan.total_bytes));
+      h->ps_ok = true;
+    }
+  }
 #undef CREATE_TRY
 
   StepParams& sp = h->sp;
@@ -1051,6 +1112,7 @@ void psmf_destroy(psmf_handle h) {
   if (h->Y) hipFree(h->Y);
   if (h->YP) hipFree(h->YP);
   if (h->partials) hipFree(h->partials);
+  if (h->ps_comm) hipFree(h->ps_comm);
   if (h->gpart) hipFree(h->gpart);
   if (h->mu_hist) hipFree(h->mu_hist);
   if (h->thbuf) hipFree(h->thbuf);
@@ -1319,6 +1381,11 @@ int psmf_run(psmf_handle h, int64_t k_begin, int64_t k_end) {
       if (to_next < seg) seg = to_next;
     }
     int64_t left = seg;
+    if (pstep_usable(h)) {      // the whole segment in ONE launch: C on chip, hand-offs through device flags (psmf_pstep.hip)
+      rc = launch_pstep(h, h->k_done, left);
+      if (rc) return rc;
+      left = 0;
+    }
     if (h->cfg.use_graph && !h->host_fn) {   // (a host-mediated all-reduce cannot be captured)
       const int want = 256;
       if (left >= want && h->chunk != want) {
@@ -1373,6 +1440,8 @@ int psmf_sync(psmf_handle h) {
              fl[0], fl[1], h->seq_next);
     return fail(h, PSMF_ERR_HIP, msg);
   }
+  if (err == -8) return fail(h, PSMF_ERR_HIP, "persistent per-step kernel: a hand-off between the hub and the row workgroups timed out "
+                                               "(PSMF_STEP_PERSISTENT=0: two launches per timestep)");
   if (err != 0) {
     char msg[128];
     snprintf(msg, sizeof(msg), "singular r x r system (I + kappa Pbar G) at step %d", err);

@@ -103,4 +103,18 @@ struct StepParams {
   double ns_far2;       // Newton-Schulz: squared residual beyond which the start is given up for the direct sweep (filter3)
 };
 
+// sum over the 64 lanes of a wave (butterfly; same value in every lane)
+__device__ __forceinline__ double wave_sum(double x) {
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
+  return x;
+}
+
+__device__ __forceinline__ double fast_rcp(double d) {
+  double x = __builtin_amdgcn_rcp(d);   // v_rcp_f64, ~1e-8 relative
+  x = x * (2.0 - d * x);
+  x = x * (2.0 - d * x);
+  return x;
+}
+
 }  // namespace psmf

@@ -45,11 +45,7 @@ __global__ void psmf_prepare_k(DevState* st, long long k) { st->k = k; st->kq = 
 // end of a run: the numeric-error flag to mapped host memory (system-scope store)
 __global__ void psmf_publish_err_k(const DevState* st, int* host_flag) { __hip_atomic_store(host_flag, st->err, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 
-__device__ __forceinline__ double wave_sum(double x) {
-#pragma unroll
-  for (int m = 32; m >= 1; m >>= 1) x += __shfl_xor(x, m, 64);
-  return x;
-}
+// (wave_sum, fast_rcp: psmf_device.h -- shared with the persistent per-step kernel's translation unit)
 
 
 // fixed-order sum of base[w * ps] for w = first, first + step, ... < n, 16 independent loads in flight.
@@ -80,13 +76,6 @@ __device__ __forceinline__ double strided_sum(const double* base, int first, int
 // line, one barrier per pivot.  A non-positive pivot raises the numeric-error flag (the
 // reference raises LinAlgError from np.linalg.inv in the same situation).
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ double fast_rcp(double d) {
-  double x = __builtin_amdgcn_rcp(d);   // v_rcp_f64, ~1e-8 relative
-  x = x * (2.0 - d * x);
-  x = x * (2.0 - d * x);
-  return x;
-}
-
 // LDS_ONLY: the barriers order LDS traffic only (s_waitcnt lgkmcnt(0); s_barrier) instead of __syncthreads(), which also
 // drains vmcnt -- for callers that keep global loads / stores in flight across the solve (psmf_impute.hip)
 template <bool LDS_ONLY>

@@ -1,0 +1,38 @@
+// Persistent per-step engine (psmf_pstep.hip): interface between its translation unit and the C-ABI host code.
+#pragma once
+#include "psmf_device.h"
+
+namespace psmf {
+
+constexpr int PSTEP_NT = 512;        // threads per workgroup (8 waves), every workgroup of the launch
+constexpr int PSTEP_NPMAX = 16;      // row passes a row workgroup can keep in registers (4 float64 per lane and pass; y_k beside them)
+constexpr int PSTEP_NPMAX_F64 = 12;  // ... with float64 storage (y_k takes two registers per pass)
+constexpr int PSTEP_PKT_MAX = 4 * RM + 1;      // granules of the hub -> rows packet
+
+struct PstepParams {
+  StepParams sp;               // the handle's parameter block
+  long long k_begin;           // series index of the first step of the launch (== st->k)
+  int n_steps;
+  int n_row_wg;                // row workgroups; grid = n_row_wg + 1 (block 0 = hub)
+  int rows_per_wg;
+  int np;                      // row passes per workgroup (<= PSTEP_NPMAX)
+  int ncol2;                   // doubles per partial row (even, >= r + 1)
+  unsigned* flags;             // rows -> hub: one epoch word per row workgroup        } one block, zeroed before every launch
+  unsigned long long* pkt;     // hub -> rows: PSTEP_PKT_MAX {tag, value} granules      }
+  double* part;                // rows -> hub: n_row_wg x ncol2 partial sums (write-through stores)
+};
+
+struct PstepPlan {
+  int n_row_wg, rows_per_wg, np, ncol2;
+  size_t zero_bytes;           // flags + packet: the block a launch zeroes (starts the allocation, multiple of 16 bytes)
+  size_t off_pkt, off_part, total_bytes;
+};
+
+// geometry of a launch for d_local rows at rank r on a device with n_cu compute units; false: the shape does not fit the kernel
+bool pstep_plan(int d_local, int r, int n_cu, bool storage_f64, PstepPlan* out);
+// one launch = n_steps timesteps (the communication block must have been zeroed on the same stream)
+hipError_t pstep_launch(const PstepParams& q, bool storage_f64, hipStream_t stream);
+// one-off per process: dynamic-LDS attribute of every instance
+hipError_t pstep_init();
+
+}  // namespace psmf

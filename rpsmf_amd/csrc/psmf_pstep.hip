@@ -1,0 +1,745 @@
+// Persistent per-step engine (gfx950): ONE launch advances a whole run of timesteps of the per-step filter
+// (pypsmf/psmf/psmf.py:104-177, rpsmf.py:116-184 in the r x r form of SURVEY App. A), instead of two launches per timestep
+// (psmf_sweep_solve + psmf_serial, psmf_kernels.hip).
+//
+//   block 0            the HUB: everything r-sized.  Waves 0-3 ("workers") keep V, P, G, Q, Lbar in registers across the
+//                      steps and do the serial stage of a step; waves 6-7 run the step's r x r inversions as wave-local tile
+//                      sweeps on the f64 matrix cores (psmf_ns.hip) while waves 0-5 collect the row workgroups' partial sums.
+//   blocks 1 .. n      ROW workgroups: each keeps its rows of C ON CHIP, as float64 in registers, for the whole launch (12.8 MB
+//                      of float32 storage at d = 1e5, r = 32 = 100 KB of float64 per CU).  Per timestep a row workgroup reads
+//                      y_k (prefetched one step ahead), forms y_hat = C mu_bar, e = y - y_hat, h += c e, C += e w^T / N, stores
+//                      y_hat, and hands (h, ee) to the hub.  HBM traffic per timestep: y and y_hat only.
+//
+// Hand-offs inside the launch (MI355X guide, Guideline 16):
+//   hub -> rows   mu_bar, w / N of the next step as 8-byte {tag = epoch, 32-bit value} granules, agent-scope relaxed atomic
+//                 stores (write-through); ONE wave per row workgroup re-reads them until every tag matches -- the data is the flag.
+//   rows -> hub   r + 1 partial sums per workgroup, agent-scope relaxed atomic stores, the storing wave's s_waitcnt vmcnt(0),
+//                 then one epoch word per workgroup; the hub polls the words, then loads the sums with agent-scope atomic loads.
+// Every polled word is zeroed by the host before each launch (epoch = step within the launch + 1); every spin is bounded by the
+// 100 MHz clock and ends the launch with the sticky error flag set.
+//
+// The float64 copy of C is rounded to the storage type ONCE per launch (the two-launch engine rounds every step), all sums keep a
+// fixed order (deterministic), and the launch starts from / leaves behind exactly the DevState the two-launch engine does, so the
+// two are interchangeable between launches.
+#include "psmf_pstep.h"
+#include "psmf_ns.hip"
+
+namespace psmf {
+
+namespace {
+
+constexpr long long PSTEP_SPIN_TICKS = 300000000LL;      // 3 s of the 100 MHz clock: a hand-off that has not come by then never will
+constexpr unsigned PSTEP_ABORT_TAG = 0xFFFFFFFFu;
+
+#define PS_DPP64(x, ctrl)                                                                                  \
+  __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(x), ctrl, 0xF, 0xF, true),                \
+                   __builtin_amdgcn_update_dpp(0, __double2loint(x), ctrl, 0xF, 0xF, true))
+
+// sum over the GS lanes (GS = 2 .. 16, aligned group) that share a row; every lane of the group gets the sum
+template <int GS>
+__device__ __forceinline__ double group_sum(double v) {
+  if (GS >= 2) v += PS_DPP64(v, 0xB1);     // quad_perm [1,0,3,2]
+  if (GS >= 4) v += PS_DPP64(v, 0x4E);     // quad_perm [2,3,0,1]
+  if (GS >= 8) v += PS_DPP64(v, 0x141);    // row_half_mirror
+  if (GS >= 16) v += PS_DPP64(v, 0x140);   // row_mirror
+  return v;
+}
+
+__device__ __forceinline__ double ps_xor16_sum(double x) {
+  const unsigned lo = __double2loint(x), hi = __double2hiint(x);
+  const auto l2 = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto h2 = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  return __hiloint2double(h2[0], l2[0]) + __hiloint2double(h2[1], l2[1]);
+}
+__device__ __forceinline__ double ps_xor32_sum(double x) {
+  const unsigned lo = __double2loint(x), hi = __double2hiint(x);
+  const auto l2 = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+  const auto h2 = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+  return __hiloint2double(h2[0], l2[0]) + __hiloint2double(h2[1], l2[1]);
+}
+
+// sum over the lanes of a wave with equal (lane % GS): rotations inside the 16-lane rows, then the row swaps; fixed order
+template <int GS>
+__device__ __forceinline__ double cross_sum(double v) {
+  if (GS <= 8) v += PS_DPP64(v, 0x128);    // row_ror:8
+  if (GS <= 4) v += PS_DPP64(v, 0x124);    // row_ror:4
+  if (GS <= 2) v += PS_DPP64(v, 0x122);    // row_ror:2
+  v = ps_xor16_sum(v);
+  return ps_xor32_sum(v);
+}
+
+// workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, and every wave here keeps global stores
+// (y_hat, the mean history, hand-off words) in flight that nothing inside the launch reads back through the cache
+__device__ __forceinline__ void ps_bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+typedef unsigned long long u64;
+__device__ __forceinline__ void gran_store(u64* g, unsigned tag, unsigned v) {
+  __hip_atomic_store(g, ((u64)tag << 32) | v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 gran_load(const u64* g) { return __hip_atomic_load(g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void wt_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double wt_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ int lds_word(const volatile int* p) { return *p; }
+
+// ------------------------------------------------------------------------------------------------------------
+// ROW workgroup
+// ------------------------------------------------------------------------------------------------------------
+template <typename T, int RPAD, int NT, int NPMAX>
+__device__ __forceinline__ void pstep_rows(const PstepParams& q, char* smem) {
+  constexpr int GS = RPAD / 4;               // lanes per row; a lane owns 4 consecutive columns
+  constexpr int RPW = NT / GS;               // rows per pass of the workgroup
+  constexpr int NW = NT / 64;
+  constexpr int NG = 4 * RPAD + 1;           // granules of a packet
+  constexpr int NGL = (NG + 63) / 64;
+  const StepParams& p = q.sp;
+  const int wg = (int)blockIdx.x - 1;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int j = tid % GS, g = tid / GS;
+  const int r = p.r, rp = p.rp, dl = p.d_local, np = q.np;
+  const int row_begin = wg * q.rows_per_wg;
+  const int row_end = min(row_begin + q.rows_per_wg, dl);
+
+  unsigned* s_pkt32 = reinterpret_cast<unsigned*>(smem);                   // NG words (8-byte aligned doubles inside)
+  double* s_red = reinterpret_cast<double*>(smem + 2048);                  // NW x (RPAD + 1)
+  int* s_ctl = reinterpret_cast<int*>(smem + 2048 + NW * (RPAD + 1) * 8);  // [0] stop
+
+  T* __restrict__ Cg = reinterpret_cast<T*>(p.C);
+  // ---- the rows of C, float64, in registers for the whole launch ----
+  double c[NPMAX][4];
+  unsigned okmask = 0;
+#pragma unroll
+  for (int ps = 0; ps < NPMAX; ++ps) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) c[ps][v] = 0.0;
+    if (ps < np) {
+      const int row = row_begin + ps * RPW + g;
+      if (row < row_end) {
+        okmask |= 1u << ps;
+        const T* src = Cg + (size_t)row * rp + 4 * j;
+        if constexpr (sizeof(T) == 4) {
+          if (4 * j < rp) {
+            const float4 x = *reinterpret_cast<const float4*>(src);
+            c[ps][0] = (double)x.x; c[ps][1] = (double)x.y; c[ps][2] = (double)x.z; c[ps][3] = (double)x.w;
+          }
+        } else {
+          if (4 * j < rp) { const double2 x = *reinterpret_cast<const double2*>(src); c[ps][0] = x.x; c[ps][1] = x.y; }
+          if (4 * j + 2 < rp) { const double2 x = *reinterpret_cast<const double2*>(src + 2); c[ps][2] = x.x; c[ps][3] = x.y; }
+        }
+      }
+    }
+  }
+  if (tid == 0) s_ctl[0] = 0;
+  const long long t_first = q.k_begin - p.series_t0;       // row of the series buffer holding the first step's y
+  const T* __restrict__ Yg = reinterpret_cast<const T*>(p.Y);
+  T* __restrict__ YPg = p.store_yp ? reinterpret_cast<T*>(p.YP) : nullptr;
+  T ycur[NPMAX];
+#pragma unroll
+  for (int ps = 0; ps < NPMAX; ++ps) {
+    ycur[ps] = (T)0;
+    if (ps < np) ycur[ps] = Yg[(size_t)t_first * dl + min(row_begin + ps * RPW + g, row_end - 1)];
+  }
+  ps_bar();
+
+  for (int s = 0; s < q.n_steps; ++s) {
+    const unsigned epoch = (unsigned)s + 1u;
+    // ---- wait for the step's packet (wave 0), spread it through LDS ----
+    if (wv == 0) {
+      unsigned val[NGL];
+      const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+      int stop = 0;
+      for (;;) {
+        bool ok = true, ab = false;
+#pragma unroll
+        for (int m = 0; m < NGL; ++m) {
+          const int k = lane + 64 * m;
+          const u64 x = gran_load(q.pkt + min(k, NG - 1));
+          val[m] = (unsigned)x;
+          const unsigned tag = (unsigned)(x >> 32);
+          ok &= (k >= NG) || tag == epoch;
+          ab |= (k == NG - 1) && tag == PSTEP_ABORT_TAG;
+        }
+        if (__any((int)ab)) { stop = 1; break; }
+        if (__all((int)ok)) break;
+        __builtin_amdgcn_s_sleep(1);
+        if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > PSTEP_SPIN_TICKS) { stop = 2; break; }
+      }
+#pragma unroll
+      for (int m = 0; m < NGL; ++m) { const int k = lane + 64 * m; if (k < NG) s_pkt32[k] = val[m]; }
+      if (lane == 0) { if (stop == 0 && s_pkt32[NG - 1] != 0u) stop = 1; }
+      if (lane == 0 && stop) s_ctl[0] = stop;
+    }
+    ps_bar();
+    if (lds_word(s_ctl) != 0) break;
+    const double* s_mub = reinterpret_cast<const double*>(s_pkt32);
+    const double* s_wn = s_mub + RPAD;
+    double mub[4], wn[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) { mub[v] = s_mub[4 * j + v]; wn[v] = s_wn[4 * j + v]; }
+    const long long t = t_first + s;
+    const bool more = s + 1 < q.n_steps;
+    const T* __restrict__ ynx = Yg + (size_t)(t + (more ? 1 : 0)) * dl;      // next step's y: loaded behind each pass's use of this step's
+    T* __restrict__ yp = YPg ? YPg + (size_t)t * dl : nullptr;
+    double hacc[4] = {0.0, 0.0, 0.0, 0.0};
+    double eacc = 0.0;
+#pragma unroll
+    for (int ps = 0; ps < NPMAX; ++ps) {
+      if (ps < np) {
+        double dot = (c[ps][0] * mub[0] + c[ps][1] * mub[1]) + (c[ps][2] * mub[2] + c[ps][3] * mub[3]);
+        dot = group_sum<GS>(dot);
+        const bool ok = (okmask >> ps) & 1u;
+        const double e = ok ? (double)ycur[ps] - dot : 0.0;
+        ycur[ps] = ynx[min(row_begin + ps * RPW + g, row_end - 1)];
+        if (yp && ok && j == 0) yp[row_begin + ps * RPW + g] = (T)dot;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+          hacc[v] = fma(c[ps][v], e, hacc[v]);
+          c[ps][v] = fma(e, wn[v], c[ps][v]);
+        }
+        eacc = fma(e, e, eacc);
+      }
+    }
+    // ---- workgroup partial of (h, ee): lanes of equal j, then the waves through LDS, fixed order ----
+#pragma unroll
+    for (int v = 0; v < 4; ++v) hacc[v] = cross_sum<GS>(hacc[v]);
+    eacc = cross_sum<GS>(eacc);
+    if (lane < GS) {
+#pragma unroll
+      for (int v = 0; v < 4; ++v) s_red[wv * (RPAD + 1) + 4 * lane + v] = hacc[v];
+      if (lane == 0) s_red[wv * (RPAD + 1) + RPAD] = eacc;
+    }
+    ps_bar();
+    if (wv == 0) {
+      // lane i: elements 2 i, 2 i + 1 of the partial row [h_0 .. h_{r-1}, ee]
+      double out[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int e = 2 * lane + u;
+        const int src = e < r ? e : RPAD;        // (e == r: the ee slot; beyond: ee again, never stored)
+        double a = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) a += s_red[w * (RPAD + 1) + min(src, RPAD)];
+        out[u] = a;
+      }
+      double* dst = q.part + (size_t)wg * q.ncol2;
+      if (2 * lane < r + 1) wt_store(dst + 2 * lane, out[0]);
+      if (2 * lane + 1 < r + 1) wt_store(dst + 2 * lane + 1, out[1]);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_store(q.flags + wg, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // (no barrier: wave 0 rewrites s_pkt32 only after every wave has passed the barrier above, behind its own reads of it;
+    //  s_red is rewritten behind the next step's first barrier, which wave 0 reaches after reading it)
+  }
+
+  // ---- C back to its storage type: one rounding per launch ----
+#pragma unroll
+  for (int ps = 0; ps < NPMAX; ++ps) {
+    if (ps < np && ((okmask >> ps) & 1u)) {
+      const int row = row_begin + ps * RPW + g;
+      T* dstp = Cg + (size_t)row * rp + 4 * j;
+      if constexpr (sizeof(T) == 4) {
+        if (4 * j < rp) *reinterpret_cast<float4*>(dstp) = make_float4((float)c[ps][0], (float)c[ps][1], (float)c[ps][2], (float)c[ps][3]);
+      } else {
+        if (4 * j < rp) *reinterpret_cast<double2*>(dstp) = make_double2(c[ps][0], c[ps][1]);
+        if (4 * j + 2 < rp) *reinterpret_cast<double2*>(dstp + 2) = make_double2(c[ps][2], c[ps][3]);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// HUB: the r x r inversions of a step on one or two waves, operands and results in LDS (row stride LS)
+//   carried (StepParams.solve_dual, Lbar = Pbar^-1 known):  role 0  P+ = (Lbar + kappa G)^-1,  role 1  W = ((Lbar + kappa G) / beta + I / q)^-1
+//   otherwise (role 0 only):  -Pbar^-1, M = Pbar^-1 + kappa G, P+ = M^-1 (and W from M when dual)
+// (the per-step engine's solve block, psmf_wave16.hip: solve_block_wave_t, with LDS in place of DevState)
+// ------------------------------------------------------------------------------------------------------------
+template <int NTL>
+__device__ __forceinline__ void hub_solve(const int role, const bool dual, const bool carried, const int r, const double kappa,
+                                          const double iq, const double ib, const double* sL, const double* sG, double* sPp,
+                                          double* sW, const int LS, int* s_bad) {
+  const int lane = threadIdx.x & 63, lk = lane >> 4, lr = lane & 15;
+  const int r2 = r + (r & 1);
+  if (role > (carried ? 1 : 0)) return;
+  Sw16K swk;
+  sw16k_init(swk, lk, lr);
+  double A[NTL][NTL][4];
+  bool bad = false;
+#define HS_FOR(body)                                                                   \
+  _Pragma("unroll") for (int ti = 0; ti < NTL; ++ti)                                   \
+    _Pragma("unroll") for (int tj = 0; tj < NTL; ++tj)                                 \
+      _Pragma("unroll") for (int qq = 0; qq < 4; ++qq) {                               \
+        const int i = 16 * ti + lk + 4 * qq, cI = 16 * tj + lr;                        \
+        const bool in = i < r && cI < r, pad = (i == cI) && i >= r;                    \
+        const int ic = in ? i : 0, cc = in ? cI : 0;                                   \
+        (void)pad; (void)ic; (void)cc;                                                 \
+        body                                                                           \
+      }
+  if (carried) {
+    HS_FOR({
+      const double mv = sL[ic * LS + cc] + kappa * sG[ic * LS + cc];
+      A[ti][tj][qq] = in ? (role == 0 ? mv : mv * ib + (i == cI ? iq : 0.0)) : (pad ? 1.0 : 0.0);
+    })
+    wave_sweep_tiles_m<NTL>(A, r2, swk, bad);
+    double* dst = role == 0 ? sPp : sW;
+    HS_FOR({ if (in) dst[i * LS + cI] = -A[ti][tj][qq]; })
+  } else {
+    HS_FOR({ A[ti][tj][qq] = in ? 0.5 * (sL[ic * LS + cc] + sL[cc * LS + ic]) : (pad ? 1.0 : 0.0); })      // sL holds Pbar here
+    wave_sweep_tiles_m<NTL>(A, r2, swk, bad);                       // -Pbar^-1
+    double Mx[NTL][NTL][4];
+    HS_FOR({ Mx[ti][tj][qq] = in ? kappa * sG[ic * LS + cc] - A[ti][tj][qq] : (pad ? 1.0 : 0.0); A[ti][tj][qq] = Mx[ti][tj][qq]; })
+    wave_sweep_tiles_m<NTL>(A, r2, swk, bad);                       // -P+
+    HS_FOR({ if (in) sPp[i * LS + cI] = -A[ti][tj][qq]; })
+    if (dual) {
+      HS_FOR({ A[ti][tj][qq] = in ? Mx[ti][tj][qq] * ib + (i == cI ? iq : 0.0) : (pad ? 1.0 : 0.0); })
+      wave_sweep_tiles_m<NTL>(A, r2, swk, bad);                     // -W
+      HS_FOR({ if (in) sW[i * LS + cI] = -A[ti][tj][qq]; })
+    }
+  }
+#undef HS_FOR
+  if (__builtin_amdgcn_readfirstlane(__any((int)bad)) && lane == 0) *s_bad = 1;
+}
+
+// column sums over the worker threads' row groups: partial of thread (ig, j) -> out[j]   (two barriers; every wave of the hub calls it)
+template <int RPAD, int NWK>
+__device__ __forceinline__ void hub_col_reduce(const bool worker, const double partial, double* s_red, double* s_out) {
+  constexpr int RG = NWK / RPAD;
+  const int tid = threadIdx.x;
+  if (worker) s_red[tid] = partial;
+  ps_bar();
+  if (tid < RPAD) {
+    double a = 0.0;
+#pragma unroll
+    for (int gI = 0; gI < RG; ++gI) a += s_red[gI * RPAD + tid];
+    s_out[tid] = a;
+  }
+  ps_bar();
+}
+
+template <int RPAD, int NT>
+__device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
+  constexpr int NWK = 256;                   // worker threads: waves 0-3
+  constexpr int NW = NT / 64;
+  constexpr int RG = NWK / RPAD;
+  constexpr int M = (RPAD * RPAD) / NWK > 0 ? (RPAD * RPAD) / NWK : 1;
+  constexpr int LS = RPAD + 1;               // row stride of the r x r LDS images
+  constexpr int NTL = RPAD > 16 ? 2 : 1;
+  constexpr int NG = 4 * RPAD + 1;
+  constexpr int NFT = (NW - 2) * 64;         // threads of the fan-in (waves 0 .. NW-3)
+  static_assert(RPAD <= 32, "the hub holds the r x r state of r <= 32");
+  const StepParams& p = q.sp;
+  DevState* st = p.st;
+  const int r = p.r, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const bool worker = tid < NWK;
+  const int j = tid % RPAD, ig = (tid % NWK) / RPAD;
+  const double dd = (double)p.d;
+  const int nwg = q.n_row_wg, ncol2 = q.ncol2, ncol = r + 1;
+
+  double* sPp = reinterpret_cast<double*>(smem);
+  double* sW = sPp + RPAD * LS;
+  double* sL = sW + RPAD * LS;               // Lbar (inversions side by side, carried) or Pbar
+  double* sG = sL + RPAD * LS;
+  double* s_seg = sG + RPAD * LS;            // fan-in: [segment][ncol2]
+  double* s_red = s_seg + 2 * NT;
+  double* s_he = s_red + NWK;                // h[0..r), ee at [r]
+  double* s_w = s_he + 2 * (RM + 1);
+  double* s_mub = s_w + RM;
+  double* s_f = s_mub + RM;
+  double* s_vec = s_f + RM;
+  double* s_wn = s_vec + RM;
+  double* s4 = s_wn + RM;                    // 8
+  double* s_sc = s4 + 8;                     // [0] kappa, [1] 1 / q, [2] 1 / beta (solve operands)
+  int* s_ctl = reinterpret_cast<int*>(s_sc + 8);      // [0] stop, [1] fan-in epoch seen by wave 0, [2] bad pivot, [3] carried
+
+  // ---------------- the state the two-launch engine left in DevState ----------------
+  const bool dual = p.solve_dual != 0;
+  const int nsv = st->ns_valid;
+  bool carried = dual && nsv == 7;
+  double Vv[M], Pv[M], Gv[M], Qv[M], Pbv[M], Wv[M];
+  bool val[M];
+  int ii[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    ii[m] = ig + m * RG;
+    val[m] = worker && (j < r) && (ii[m] < r);
+    const int idx = val[m] ? ii[m] * r + j : 0;
+    const double lv = st->V[idx], lg = st->G[idx], lq = st->Q[idx], lp = st->Pbar[idx], lpt = st->Pbar[val[m] ? j * r + ii[m] : 0], ll = st->Lbar[idx];
+    Vv[m] = val[m] ? lv : 0.0;
+    Gv[m] = val[m] ? lg : 0.0;
+    Qv[m] = val[m] ? lq : 0.0;
+    Pbv[m] = val[m] ? 0.5 * (lp + lpt) : 0.0;
+    Pv[m] = 0.0;
+    Wv[m] = 0.0;
+    if (val[m]) {
+      sG[ii[m] * LS + j] = Gv[m];
+      sL[ii[m] * LS + j] = carried ? ll : Pbv[m];
+    }
+  }
+  double rho = st->rho, lam = st->lam;
+  double N0 = st->N, kappa0 = st->kappa, s0 = st->s, eta0 = st->eta;
+  long long k0 = st->k;
+  const bool vl = tid < r;
+  const bool tl = tid < p.n_theta && p.dyn_kind == 1;
+  const int tc = tid & (RM - 1);
+  const double l_mu = st->mu[tc], l_w = st->w[tc], l_mub = st->mu_bar[tc], l_wn = st->wN[tc], l_th = p.theta[tc], l_gs = p.gradsum[tc],
+               l_am = p.adam_m[tc], l_av = p.adam_v[tc];
+  double mu_new = vl ? l_mu : 0.0;
+  double w_t = vl ? l_w : 0.0;
+  double mub_t = vl ? l_mub : 0.0;
+  double theta = tl ? l_th : 0.0;
+  double gsum = tl ? l_gs : 0.0;
+  double am = tl ? l_am : 0.0;
+  double av = tl ? l_av : 0.0;
+  double phi = 1.0, omega = 1.0, ee_last = 0.0, s_done = s0, eta_done = eta0, N_done = N0;
+  if (tid < RM) { s_w[tid] = vl ? l_w : 0.0; s_mub[tid] = vl ? l_mub : 0.0; s_wn[tid] = vl ? l_wn : 0.0; s_f[tid] = 0.0; s_vec[tid] = 0.0; }
+  if (tid < 2 * (RM + 1)) s_he[tid] = 0.0;
+  if (tid == 0) {
+    s_ctl[0] = 0; s_ctl[1] = 0; s_ctl[2] = 0;
+    s_sc[0] = kappa0;
+    s_sc[1] = 1.0 / st->Q[0];
+    s_sc[2] = p.robust ? 1.0 / p.beta : 1.0;
+  }
+  ps_bar();
+  // packet of the launch's first step
+  if (tid < NG) {
+    const int e = tid >> 1;
+    const double v = tid == NG - 1 ? 0.0 : (e < RPAD ? s_mub[e] : s_wn[e - RPAD]);
+    const unsigned half = tid == NG - 1 ? 0u : ((tid & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v));
+    gran_store(q.pkt + tid, 1u, half);
+  }
+
+  // fan-in geometry: thread t of waves 0 .. NW-3 sums elements (2 pi, 2 pi + 1) of the partial rows seg, seg + S, ...
+  const int npair = ncol2 >> 1;
+  const int S = NFT / npair;
+  const int f_pi = tid % npair, f_seg = tid / npair;
+  const bool f_on = tid < NFT && f_seg < S;
+
+  // ---- the solve waves run a loop of their own (same barriers, none of the workers' registers): the kernel's register allocation
+  //      is the larger of the two roles, not their sum ----
+  if (wv >= NW - 2) {
+    for (int s = 0; s < q.n_steps; ++s) {
+      if (p.coef_update) hub_solve<NTL>(wv - (NW - 2), dual, carried, r, s_sc[0], s_sc[1], s_sc[2], sL, sG, sPp, sW, LS, s_ctl + 2);
+      ps_bar();                                                   // end of phase A
+      if (lds_word(s_ctl) != 0 || lds_word(s_ctl + 2) != 0) break;
+      ps_bar();                                                   // phase B: the workers' barriers, one for one
+      if (p.coef_update) { ps_bar(); ps_bar(); }
+      ps_bar();
+      ps_bar(); ps_bar();
+      if (p.eta_full) ps_bar();
+      ps_bar();
+      carried = dual;
+    }
+    return;
+  }
+
+  int n_done = 0;
+  for (int s = 0; s < q.n_steps; ++s) {
+    const unsigned epoch = (unsigned)s + 1u;
+    // =========================== phase A: the fan-in (beside the solve waves' inversions) ===========================
+    {
+      if (wv == 0) {
+        const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+        int stop = 0;
+        for (;;) {
+          bool ok = true;
+          for (int b = lane; b < nwg; b += 64) ok &= __hip_atomic_load(q.flags + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= epoch;
+          if (__all((int)ok)) break;
+          __builtin_amdgcn_s_sleep(1);
+          if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > PSTEP_SPIN_TICKS) { stop = 2; break; }
+        }
+        if (lane == 0) {
+          if (stop) *reinterpret_cast<volatile int*>(s_ctl) = stop;
+          *reinterpret_cast<volatile int*>(s_ctl + 1) = (int)epoch;
+        }
+      } else {
+        while (lds_word(s_ctl + 1) < (int)epoch) __builtin_amdgcn_s_sleep(1);      // (wave 0 always sets it, bounded by its own timeout)
+      }
+      asm volatile("" ::: "memory");
+      if (f_on && lds_word(s_ctl) == 0) {
+        double a0 = 0.0, a1 = 0.0;
+        const double* base = q.part + 2 * f_pi;
+        for (int row0 = f_seg; row0 < nwg; row0 += 4 * S) {
+          double x0[4], x1[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int row = min(row0 + u * S, nwg - 1);
+            x0[u] = wt_load(base + (size_t)row * ncol2);
+            x1[u] = wt_load(base + (size_t)row * ncol2 + 1);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const bool in = row0 + u * S < nwg;
+            a0 += in ? x0[u] : 0.0;
+            a1 += in ? x1[u] : 0.0;
+          }
+        }
+        s_seg[f_seg * ncol2 + 2 * f_pi] = a0;
+        s_seg[f_seg * ncol2 + 2 * f_pi + 1] = a1;
+      }
+    }
+    ps_bar();
+    if (lds_word(s_ctl) != 0 || lds_word(s_ctl + 2) != 0) break;
+    // =========================== phase B: the serial stage of step k0 (psmf_kernels.hip: serial_body) ===========================
+    if (tid < ncol) {
+      double a = 0.0;
+      for (int sg = 0; sg < S; ++sg) a += s_seg[sg * ncol2 + tid];
+      s_he[tid] = a;
+    }
+    // P+ and W of the solve waves, symmetrised
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      if (p.coef_update) Pv[m] = val[m] ? 0.5 * (sPp[ii[m] * LS + j] + sPp[j * LS + ii[m]]) : 0.0;
+      else Pv[m] = Pbv[m];
+      Wv[m] = (dual && val[m]) ? 0.5 * (sW[ii[m] * LS + j] + sW[j * LS + ii[m]]) : 0.0;
+    }
+    ps_bar();
+    const double N = N0, kappa = kappa0;
+    const double ee = s_he[r];
+    const double wj = j < r ? s_w[j] : 0.0;
+    double quad = kappa * ee;
+    const double mu_old = mu_new;
+    if (p.coef_update) {
+      double part = 0.0;
+#pragma unroll
+      for (int m = 0; m < M; ++m) part += val[m] ? Pv[m] * s_he[min(ii[m], r - 1)] : 0.0;
+      hub_col_reduce<RPAD, NWK>(worker, part, s_red, s_vec);      // s_vec = P+ h
+      const double bPb = wave_sum(lane < r ? s_he[lane] * s_vec[lane] : 0.0);
+      quad -= kappa * kappa * bPb;
+      if (vl) mu_new = mub_t + kappa * s_vec[tid];
+    } else {
+      if (vl) mu_new = mub_t;
+    }
+    // theta gradient at the pre-update state   psmf.py:48-66,167-177; rpsmf.py:53-73
+    if (tl) {
+      const double tk = (double)(k0 + 1);
+      const double arg = 2.0 * M_PI * theta * tk + mu_old;
+      const double jt = -sin(arg) * (2.0 * M_PI * tk);
+      const double wi = w_t, hi = s_he[tid];
+      double gf;
+      if (p.robust) {
+        const double D = lam * N;
+        gf = dd * wi / N + 0.5 * (dd + lam) * (-2.0 * hi / D - 2.0 * lam * ee * wi / (D * D)) / (1.0 + ee / D);
+      } else {
+        gf = dd * wi / N - hi / N - ee * wi / (N * N);
+      }
+      gsum += jt * gf;
+    }
+    // robust scalars   rpsmf.py:133-171
+    double vscale = 1.0, pscale = 1.0, qscale = 1.0;
+    phi = 1.0; omega = 1.0;
+    const double invN = fast_rcp(N);
+    if (p.robust) {
+      const double ild = fast_rcp(lam + dd);
+      phi = (lam + ee * invN) * ild;
+      omega = (lam + quad) * ild;
+      vscale = p.alpha * phi;
+      if (p.coef_update) { pscale = p.beta * omega; qscale = omega; }
+      rho *= omega;
+      if (!p.fixed_lambda) lam += dd;
+    }
+    const double iq_old = s_sc[1];
+    double Lv[M];
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      Lv[m] = 0.0;
+      if (val[m]) {
+        const double wi = s_w[ii[m]], hi = s_he[ii[m]], hj = s_he[j];
+        Vv[m] = vscale * (Vv[m] - wi * wj * invN);
+        Pv[m] *= pscale;
+        if (p.track_g) Gv[m] += (hi * wj + wi * hj) * invN + ee * (wi * wj) * (invN * invN);
+        if (qscale != 1.0) Qv[m] *= qscale;
+        if (dual) Lv[m] = ((ii[m] == j ? iq_old : 0.0) - Wv[m] * iq_old * iq_old) / omega;      // Pbar'^-1 = (I / q - W / q^2) / omega
+      }
+    }
+    const long long knext = k0 + 1;
+    // Adam on theta inside the time loop (PSMFRecursive, psmf.py:299-304,224-242)
+    if (tl) {
+      if (p.recursive && (knext % p.update_every) == 0) {
+        const double kk = (double)knext;
+        const double lr = p.lr_steps > 0.0 ? p.lr * pow(p.lr_end / p.lr, kk / p.lr_steps) : p.lr;
+        am = p.b1 * am + (1.0 - p.b1) * gsum;
+        av = p.b2 * av + (1.0 - p.b2) * gsum * gsum;
+        const double mh = am / (1.0 - pow(p.b1, kk));
+        const double vh = av / (1.0 - pow(p.b2, kk));
+        theta = fmax(theta - lr * mh / (sqrt(vh) + 1e-8), 0.0);
+        gsum = 0.0;
+      }
+    }
+    if (vl && p.mu_hist) p.mu_hist[(size_t)(knext - p.series_t0) * r + tid] = mu_new;
+    ee_last = ee; s_done = s0; eta_done = eta0; N_done = N;
+    // ---- everything the NEXT step needs (index knext + 1) ----
+    const double qs = p.q_sched ? p.q_sched[knext + 1 - p.series_t0] : 1.0;
+    if (p.rho_sched) rho = p.rho_sched[knext + 1 - p.series_t0];
+    if (vl) {
+      double mb = mu_new, f = 1.0;
+      if (p.dyn_kind == 1) {   // cos(2 pi theta t + x)
+        const double arg = 2.0 * M_PI * theta * (double)(knext + 1) + mu_new;
+        mb = cos(arg);
+        f = -sin(arg);
+      }
+      s_mub[tid] = mb;
+      s_f[tid] = f;
+      mub_t = mb;
+    }
+    ps_bar();
+    double part = 0.0, gp = 0.0;
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      if (val[m]) {
+        const double pb = p.pbar_predict ? s_f[ii[m]] * Pv[m] * s_f[j] + qs * Qv[m] : Pv[m];
+        Pbv[m] = pb;
+        part += Vv[m] * s_mub[ii[m]];
+        gp += Gv[m] * pb;
+      }
+    }
+    hub_col_reduce<RPAD, NWK>(worker, part, s_red, s_vec);        // s_vec = V mu_bar
+    const double sN = wave_sum(lane < r ? s_mub[lane] * s_vec[lane] : 0.0);
+    double eta = rho * p.rho_mean;
+    if (p.eta_full) {
+      double x = wave_sum(worker ? gp : 0.0);
+      if (lane == 0) s4[wv] = x;
+      ps_bar();
+      eta += ((s4[0] + s4[1]) + (s4[2] + s4[3])) / dd;
+    }
+    const double Nn = sN + eta;
+    const double iNn = fast_rcp(Nn);
+    const double kap_n = fast_rcp(rho + sN);
+    if (vl) {
+      w_t = s_vec[tid];
+      s_w[tid] = w_t;
+      s_wn[tid] = w_t * iNn;
+    }
+    // operands of the next step's inversions
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      if (val[m]) {
+        sG[ii[m] * LS + j] = Gv[m];
+        sL[ii[m] * LS + j] = dual ? Lv[m] : Pbv[m];
+      }
+    }
+    if (tid == 0) {
+      s_sc[0] = kap_n;
+      s_sc[1] = 1.0 / Qv[0];
+    }
+    carried = dual;
+    N0 = Nn; kappa0 = kap_n; s0 = sN; eta0 = eta; k0 = knext;
+    n_done = s + 1;
+    ps_bar();
+    // packet of the next step
+    if (s + 1 < q.n_steps && tid < NG) {
+      const int e = tid >> 1;
+      const double v = tid == NG - 1 ? 0.0 : (e < RPAD ? s_mub[e] : s_wn[e - RPAD]);
+      const unsigned half = tid == NG - 1 ? 0u : ((tid & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v));
+      gran_store(q.pkt + tid, epoch + 1u, half);
+    }
+  }
+
+  // ---------------- end of the launch: DevState as the two-launch engine leaves it ----------------
+  const int stop = lds_word(s_ctl), badp = lds_word(s_ctl + 2);
+  if ((stop != 0 || badp != 0) && tid == 0) {
+    gran_store(q.pkt + (NG - 1), PSTEP_ABORT_TAG, 1u);        // the row workgroups leave at their next poll
+    if (st->err == 0) st->err = badp ? (int)(k0 + 1) : -8;
+  }
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    if (val[m]) {
+      const int idx = ii[m] * r + j;
+      st->V[idx] = Vv[m];
+      if (n_done > 0) st->P[idx] = Pv[m];
+      st->G[idx] = Gv[m];
+      st->Q[idx] = Qv[m];
+      st->Pbar[idx] = Pbv[m];
+      if (n_done > 0 && dual) { st->Lbar[idx] = sL[ii[m] * LS + j]; st->XpY[idx] = Wv[m]; }
+      if (n_done > 0 && p.coef_update) st->Pplus[idx] = sPp[ii[m] * LS + j];
+    }
+  }
+  if (vl) {
+    st->mu[tid] = mu_new;
+    st->mu_bar[tid] = mub_t;
+    st->w[tid] = w_t;
+    st->wN[tid] = s_wn[tid];
+  }
+  if (tl) {
+    p.theta[tid] = theta;
+    p.gradsum[tid] = gsum;
+    p.adam_m[tid] = am;
+    p.adam_v[tid] = av;
+  }
+  if (tid == 0) {
+    st->k = k0;
+    st->kq = k0;
+    if (n_done > 0) st->ns_valid = dual ? 7 : 0;
+    st->rho = rho;
+    st->lam = lam;
+    st->s = s0; st->eta = eta0; st->N = N0; st->kappa = kappa0;
+    if (n_done > 0) {
+      st->phi = phi; st->omega = omega; st->ee = ee_last;
+      st->s_done = s_done; st->eta_done = eta_done; st->N_done = N_done;
+    }
+  }
+}
+
+template <typename T, int RPAD>
+__global__ __launch_bounds__(PSTEP_NT) void psmf_pstep_k(PstepParams q) {
+  extern __shared__ __attribute__((aligned(16))) char ps_smem[];
+  if (blockIdx.x == 0) pstep_hub<RPAD, PSTEP_NT>(q, ps_smem);
+  else pstep_rows<T, RPAD, PSTEP_NT, (sizeof(T) == 4 ? PSTEP_NPMAX : PSTEP_NPMAX_F64)>(q, ps_smem);
+}
+
+// one workgroup per compute unit: the request is more than half of a CU's 160 KB
+constexpr size_t PSTEP_LDS_BYTES = 84 * 1024;
+
+typedef void (*pstep_fn_t)(PstepParams);
+pstep_fn_t pstep_kernel(int rpad, bool f64) {
+  switch (rpad) {
+    case 8: return f64 ? psmf_pstep_k<double, 8> : psmf_pstep_k<float, 8>;
+    case 16: return f64 ? psmf_pstep_k<double, 16> : psmf_pstep_k<float, 16>;
+    case 32: return f64 ? psmf_pstep_k<double, 32> : psmf_pstep_k<float, 32>;
+  }
+  return nullptr;
+}
+
+int pstep_rpad(int r) { return r <= 8 ? 8 : (r <= 16 ? 16 : (r <= 32 ? 32 : 64)); }
+
+}  // namespace
+
+bool pstep_plan(int d_local, int r, int n_cu, bool storage_f64, PstepPlan* out) {
+  if (r < 1 || r > 32 || d_local < 1 || n_cu < 2) return false;
+  const int rpad = pstep_rpad(r);
+  const int rpw = PSTEP_NT / (rpad / 4);
+  int nwg = (d_local + rpw - 1) / rpw;
+  if (nwg > n_cu - 1) nwg = n_cu - 1;
+  int rows = (d_local + nwg - 1) / nwg;
+  const int np = (rows + rpw - 1) / rpw;
+  if (np > (storage_f64 ? PSTEP_NPMAX_F64 : PSTEP_NPMAX)) return false;
+  rows = np * rpw;
+  nwg = (d_local + rows - 1) / rows;
+  out->n_row_wg = nwg;
+  out->rows_per_wg = rows;
+  out->np = np;
+  out->ncol2 = (r + 1 + 1) & ~1;
+  const size_t fl = (((size_t)nwg * sizeof(unsigned)) + 15) & ~(size_t)15;
+  const size_t pk = (((size_t)PSTEP_PKT_MAX * sizeof(unsigned long long)) + 15) & ~(size_t)15;
+  out->off_pkt = fl;
+  out->zero_bytes = fl + pk;
+  out->off_part = (out->zero_bytes + 255) & ~(size_t)255;
+  out->total_bytes = out->off_part + (size_t)nwg * out->ncol2 * sizeof(double);
+  return true;
+}
+
+hipError_t pstep_init() {
+  for (int rpad = 8; rpad <= 32; rpad *= 2)
+    for (int f = 0; f < 2; ++f) {
+      const hipError_t e = hipFuncSetAttribute((const void*)pstep_kernel(rpad, f != 0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PSTEP_LDS_BYTES);
+      if (e != hipSuccess) return e;
+    }
+  return hipSuccess;
+}
+
+hipError_t pstep_launch(const PstepParams& q, bool storage_f64, hipStream_t stream) {
+  pstep_fn_t fn = pstep_kernel(pstep_rpad(q.sp.r), storage_f64);
+  if (!fn) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(fn, dim3(q.n_row_wg + 1), dim3(PSTEP_NT), PSTEP_LDS_BYTES, stream, q);
+  return hipGetLastError();
+}
+
+}  // namespace psmf
