@@ -176,6 +176,50 @@ def cpu_baseline(args, series, st0):
     return info, st, n
 
 
+def cpu_baseline_f32(args, series, st0, budget_s=10.0):
+    """SURVEY 8(d) asks for the CPU path in float32 beside float64: the same O(d r^2) step (lowrank_step of the oracle: y_hat, e, the
+    exact Gram, h, the rank-1 update of C) with every d-sized array and product in float32 (sgemm / sgemv), the r x r algebra in
+    float64.  A timing baseline only -- nothing is checked against it."""
+    d, r = args.d, args.r
+    n_max = min(args.cpu_steps, args.T)
+    Y = np.vstack([Yc for _, Yc in series.chunks(chunk=n_max)][:1])[:n_max].astype(np.float32)
+    C = st0["C"].astype(np.float32)
+    V, P, Q, mu = st0["V"].copy(), st0["P"].copy(), st0["Q"].copy(), st0["mu"].copy()
+    rho, lam, robust = float(st0["rho"]), float(st0["lam"]), bool(args.robust)
+    n, t0 = 0, time.perf_counter()
+    while n < n_max and time.perf_counter() - t0 < budget_s:
+        P_bar = P + Q
+        mb32 = mu.astype(np.float32)
+        e = Y[n] - C @ mb32
+        w = V @ mu
+        s_ = float(mu @ w)
+        G = (C.T @ C).astype(np.float64)
+        eta = rho + float(np.sum(G * P_bar)) / d
+        N = s_ + eta
+        kap = 1.0 / (rho + s_)
+        h = (C.T @ e).astype(np.float64)
+        ee = float(e @ e)
+        P_plus = np.linalg.solve(np.eye(r) + kap * (P_bar @ G), P_bar)
+        P_plus = 0.5 * (P_plus + P_plus.T)
+        b = kap * h
+        mu = mu + P_plus @ b
+        C += np.outer(e, (w / N).astype(np.float32))
+        V = V - np.outer(w, w) / N
+        if robust:
+            om = (lam + kap * ee - float(b @ P_plus @ b)) / (lam + d)
+            V *= (lam + ee / N) / (lam + d)
+            P_plus *= om
+            Q = om * Q
+            rho *= om
+            lam += d
+        P = P_plus
+        n += 1
+    dt = time.perf_counter() - t0
+    return dict(value=n / dt, unit="timesteps/s", cores=blas_threads(), kind="port",
+                sample=f"first {n} of {args.T} timesteps of the same series (d={d}, r={r}), numpy float32 d-sized arrays and products "
+                       f"(float64 r x r algebra), the oracle's O(d r^2) step restated in bench.py, {dt:.1f} s; timing only, not a checker")
+
+
 def cpu_baseline_literal(r, seed, budget_s=12.0):
     """The reference-shaped algebra (oracle.literal_step: dense d x d R, kron, d x d inverse innovation, d x d trace --
     psmf.py:121-165 op for op) at d = 2000, the largest size at which it is still practical."""
@@ -197,12 +241,13 @@ def cpu_baseline_literal(r, seed, budget_s=12.0):
                        f"O(d^2 r) literal restatement of pypsmf/psmf/psmf.py:121-165, {dt:.1f} s")
 
 
-def run_filter_config(_capi, name, d, r, T, robust, passes=3):
-    """Configs B / C: cold pass, steady passes, parity against the oracle on the first 300 timesteps."""
+def run_filter_config(_capi, name, d, r, T, robust, passes=3, storage="f32", engine="auto", bulk_times=False):
+    """Configs B / C (and config E under another storage type / engine): cold pass, steady passes, parity against the oracle on the
+    first 300 timesteps."""
     seed = 35833 if robust else 35853
     series = Series(d, r, T, seed, 0, d, robust)
     st0 = init_state(d, r, seed)
-    f = _capi.DeviceFilter(d, r, robust=robust, storage="f32")
+    f = _capi.DeviceFilter(d, r, robust=robust, storage=storage, engine=engine)
     for a, Yc in series.chunks(chunk=1000):
         f.upload_series(Yc, t0=a, T_total=T)
     reset = lambda: f.set_state(st0["C"], st0["V"], st0["P"], st0["Q"], st0["mu"], rho=st0["rho"], lambda0=st0["lam"])
@@ -226,12 +271,15 @@ def run_filter_config(_capi, name, d, r, T, robust, passes=3):
     f.sync()
     steady = (time.perf_counter() - t0) / passes
     geo = f.geometry()
+    out = {"workload": f"{'rPSMF' if robust else 'PSMF'} full filter d={d} r={r} T={T}, {storage} storage, 1 GPU", "value": T / steady,
+           "unit": "timesteps/s", "cold_pass_steps_per_s": T / cold, "us_per_timestep": 1e6 * steady / T, "engine": geo["engine"],
+           "kernel": geo.get("filter_kernel"),
+           "parity_vs_cpu_oracle": par, "cpu_oracle_steps_per_s": n_par / dt_cpu,
+           "hbm_frac_step_at_a_time": (T / steady) * (8.0 if storage == "f32" else 16.0) * d * (r + 1) / (HBM_PEAK_GBS * 1e9)}
+    if bulk_times and geo["engine"] == "block":      # the two d-sized kernels of a block, timed alone (they run beside the filter chain)
+        out["bulk_kernels_us"] = {"cross_gram+reduce": f.time_kernel(1, 50), "apply": f.time_kernel(2, 50), "block_steps": geo["block_steps"]}
     f.close()
-    return {"workload": f"{'rPSMF' if robust else 'PSMF'} full filter d={d} r={r} T={T}, f32 storage, 1 GPU", "value": T / steady,
-            "unit": "timesteps/s", "cold_pass_steps_per_s": T / cold, "us_per_timestep": 1e6 * steady / T, "engine": geo["engine"],
-            "kernel": geo.get("filter_kernel"),
-            "parity_vs_cpu_oracle": par, "cpu_oracle_steps_per_s": n_par / dt_cpu,
-            "hbm_frac_step_at_a_time": (T / steady) * 8.0 * d * (r + 1) / (HBM_PEAK_GBS * 1e9)}
+    return out
 
 
 def run_synthetic_simplified(_capi, d=10_000, r=20, T=5_000, robust=False, passes=3):
@@ -505,10 +553,28 @@ def main():
             uid = np.zeros(_capi.UNIQUE_ID_BYTES, dtype=np.uint8)
         t = torch.from_numpy(uid)
         dist.broadcast(t, 0)
-        try:
-            f.comm_init(world, rank, t.numpy().tobytes())
-        except Exception as e:          # noqa: BLE001 -- whatever RCCL reports, every rank has to learn of it
-            rccl_error = f"rank {rank}: {e}"
+        # ncclCommInitRank is a collective: a peer that never calls it leaves every rank waiting inside RCCL, where no Python
+        # timeout reaches.  The call runs in a helper thread (ctypes releases the GIL); if it has not returned within the bound
+        # this rank says why and ends the process with a non-zero code -- a hung start must never look like a slow one.
+        import threading
+
+        init_box = {}
+
+        def _init():
+            try:
+                f.comm_init(world, rank, t.numpy().tobytes())
+            except Exception as e:      # noqa: BLE001 -- whatever RCCL reports, every rank has to learn of it
+                init_box["err"] = f"rank {rank}: {e}"
+
+        th = threading.Thread(target=_init, daemon=True)
+        th.start()
+        th.join(float(os.environ.get("PSMF_COMM_INIT_TIMEOUT", "240")))
+        if th.is_alive():
+            print(f"[bench] rank {rank}: RCCL communicator initialisation (ncclCommInitRank + warm-up all-reduces over {world} ranks) "
+                  f"did not return within {os.environ.get('PSMF_COMM_INIT_TIMEOUT', '240')} s; a peer is missing or the fabric is down. "
+                  "No number is reported.", file=sys.stderr, flush=True)
+            os._exit(3)
+        rccl_error = init_box.get("err")
         errs = [None] * world
         dist.all_gather_object(errs, rccl_error)
         if any(errs):
@@ -517,6 +583,10 @@ def main():
             rccl_error = "; ".join(e for e in errs if e)
             if rank == 0:
                 print(f"[bench] RCCL communicator failed ({rccl_error}); falling back to the host-mediated all-reduce over gloo", file=sys.stderr, flush=True)
+            try:
+                f.comm_abort()          # a communicator whose peers never joined: destroying it could wait for them
+            except Exception:           # noqa: BLE001
+                pass
             f.close()
             f = make_filter()
             f.comm_init_host(world, rank, host_allreduce)
@@ -683,6 +753,14 @@ def main():
                          "instruction stream on one CU).  frac = SURVEY 8(d) bookkeeping: step-at-a-time algorithmic bytes of the timesteps one "
                          "launch advances / its duration / 8 TB/s -- the blocked engine does not move those bytes (traffic, real_hbm_GBps, "
                          "blocked_min_bytes_per_block); the kernels that do stream the data are under bulk_kernels"}
+    elif geo.get("filter_kernel") == "psmf_pstep_k":
+        # per-step engine as ONE persistent launch per pass (psmf_pstep.hip): HIP events around a pass on the stream it runs on
+        kernel, steps_per_launch = "psmf_pstep_k", float(T)
+        kernel_us = 1e3 * min(f.run_timed(0, T) for _ in range(2))
+        extra = {"steps_per_launch": steps_per_launch, "us_per_timestep_in_kernel": kernel_us / T,
+                 "note": "C stays on chip (float64, in the row workgroups' registers) for the whole launch: the kernel moves y and y_hat only; "
+                         "frac is the SURVEY 8(d) bookkeeping ratio (step-at-a-time bytes / duration / 8 TB/s), not a bandwidth -- what bounds "
+                         "the kernel is the latency of its two hand-offs and of the r x r stage per timestep (docs/MEASUREMENTS.md)"}
     else:
         kernel, kernel_us, steps_per_launch = "psmf_sweep_solve", f.time_kernel(0, 300), 1
         extra = {"steps_per_launch": 1, "kernels_us": {"psmf_sweep_solve": kernel_us, "psmf_serial": f.time_kernel(1, 300)}}
@@ -724,6 +802,13 @@ def main():
                               "algorithmic_bytes_per_launch": alg_bytes,
                               "whole_job_frac": value * 2.0 * es * d * (r + 1) / (world * HBM_PEAK_GBS * 1e9)}, **extra),
         }
+        if world > 1:
+            # an N-GPU number carried over the host path must not be mistaken for an RCCL number
+            line["transport_fallback"] = bool(per_rank[0].get("rccl_error")) or args.comm != "rccl"
+            line["scaling_note"] = ("strong scaling at fixed d is flat BY DESIGN under the blocked engine: every rank repeats the r x r chain "
+                                    "(the critical path) on all-reduced sums and shares only the d-sized products, which are hidden behind it at "
+                                    "d <= 2.5e5 rows per GPU; whole_job_frac (value x step-at-a-time bytes / (N x 8 TB/s)) therefore falls as 1/N. "
+                                    "More GPUs buy more ROWS at the same speed (--scaling weak).")
         if cpu is not None:
             line["cpu_baseline"] = cpu
         if parity is not None:
@@ -736,7 +821,20 @@ def main():
                 line["roofline"]["hbm_peak_measured"] = {"error": repr(e)}
             if args.cpu_steps > 0:
                 line["cpu_baseline_literal"] = cpu_baseline_literal(r, seed)
+                try:
+                    line["cpu_baseline_f32"] = cpu_baseline_f32(args, series, st0)
+                except Exception as e:
+                    line["cpu_baseline_f32"] = {"error": repr(e)}
                 other = {}
+                if (d, r, args.storage, args.engine) == (100_000, 32, "f32", "auto"):
+                    try:     # the headline with float64 storage of C, y, y_hat on the same (blocked) engine: what the 1e-5 bar costs in either norm
+                        other["E_f64_storage"] = run_filter_config(_capi, "E_f64", d, r, 4_000, bool(args.robust), passes=2, storage="f64", bulk_times=True)
+                    except Exception as e:
+                        other["E_f64_storage"] = {"error": repr(e)}
+                    try:     # the step-at-a-time engine north_star describes, as one persistent launch per pass (C on chip in float64)
+                        other["E_per_step_engine"] = run_filter_config(_capi, "E_step", d, r, 4_000, bool(args.robust), passes=2, storage="f32", engine="step")
+                    except Exception as e:
+                        other["E_per_step_engine"] = {"error": repr(e)}
                 for name, rob in (("B", False), ("C", True)):
                     try:
                         other[name] = run_filter_config(_capi, name, 10_000, 20, 5_000, rob)

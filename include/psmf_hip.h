@@ -26,6 +26,7 @@ extern "C" {
 
 #define PSMF_ABI_VERSION 3
 #define PSMF_RMAX 64 /* largest supported rank r */
+#define PSMF_ROTATION_DMAX 32768 /* largest d of psmf_set_noise_rotation (the d x d eigenvector matrix stays resident) */
 
 typedef enum {
   PSMF_OK = 0,
@@ -147,7 +148,8 @@ int psmf_set_row_noise(psmf_handle h, const double* rho_rows, double rho_mean);
  * psmf_set_state / psmf_upload_series on the way in, psmf_get_state's C, psmf_download_y_pred, psmf_predict, psmf_project on the
  * way out (float64 GEMMs against the resident U on the matrix cores) -- callers see original coordinates everywhere; no d x d
  * inverse is formed and a step stays O(d r^2).  Call it before the first psmf_set_state / psmf_upload_series.  U stays resident:
- * 8 d^2 bytes. */
+ * 8 d^2 bytes, d <= PSMF_ROTATION_DMAX (PSMF_ERR_ARG beyond).  Orthonormality of U is checked over the whole matrix in O(d^2)
+ * (U^T U z = z for two sign vectors z): PSMF_ERR_ARG if it fails. */
 int psmf_set_noise_rotation(psmf_handle h, const double* U, const double* lam);
 
 /* ---- series ---------------------------------------------------------------------------- */
@@ -211,6 +213,11 @@ int psmf_download_step_scalars(psmf_handle h, double* out, int64_t t0, int64_t n
 #define PSMF_UNIQUE_ID_BYTES 128
 int psmf_comm_unique_id(void* id_out /* PSMF_UNIQUE_ID_BYTES */);
 int psmf_comm_init(psmf_handle h, int nranks, int rank, const void* unique_id);
+/* Give up the handle's RCCL communicator WITHOUT waiting for its peers (ncclCommAbort; psmf_destroy calls ncclCommDestroy, which
+ * may block when a peer never joined): for the failure path of a multi-rank start.  The handle is a single shard again afterwards.
+ * (New; the reference is single-process.) */
+int psmf_comm_abort(psmf_handle h);
+
 /* Host-mediated communicator instead of RCCL: wherever a sharded engine needs its sum-all-reduce (per-step engine: r + 1
  * float64 per timestep; blocked engine: one 64 x 64 Gram per run and one 128 x 64 cross-Gram per block) the library copies
  * the message to the host and calls fn(ctx, buf, count), which must replace buf[0..count) by its sum over all ranks -- same

@@ -74,6 +74,7 @@ SIGNATURES = {
     "psmf_time_kernel": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),
     "psmf_geometry": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "psmf_counters": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.c_int]),
+    "psmf_comm_abort": (C.c_int, [C.c_void_p]),
     "psmf_filter_kernel": (C.c_int, [C.c_void_p]),
     "psmf_filter_kernel_time": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_double), C.c_int]),
     "psmf_measure_copy_bandwidth": (C.c_int, [C.c_int, C.c_size_t, C.c_int, _dp]),
@@ -398,6 +399,10 @@ class DeviceFilter:
     def comm_init(self, nranks, rank, unique_id):
         buf = C.create_string_buffer(bytes(unique_id), UNIQUE_ID_BYTES)
         self._check(self._lib.psmf_comm_init(self._h, int(nranks), int(rank), buf))
+
+    def comm_abort(self):
+        """drop the RCCL communicator without waiting for its peers (failure path of a multi-rank start)"""
+        self._check(self._lib.psmf_comm_abort(self._h))
 
     def comm_info(self):
         """What the exchanges of this handle run on: transport ("rccl" / "host" / None), ranks, rank and device as the

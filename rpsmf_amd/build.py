@@ -29,6 +29,7 @@ HEADER = os.path.join(ROOT, "include", "psmf_hip.h")
 # copy in and out around every dependent MFMA.  With the flag they keep all 512 registers AND the short form, and what
 # does not fit the 256 VGPRs is parked in AGPRs (one instruction) instead of scratch memory.
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-Wno-unused-value", "-mllvm", "-amdgpu-mfma-vgpr-form"]
+FLAGS += os.environ.get("PSMF_CXXFLAGS", "").split()      # diagnostic builds (e.g. -DPSTEP_PROF); part of the build id
 LINK = ["-L/opt/rocm/lib", "-lrccl", "-Wl,-rpath,/opt/rocm/lib"]
 
 _PSTEP_FILES = ("psmf_pstep.hip", "psmf_pstep.h", "psmf_ns.hip", "psmf_device.h")

@@ -51,6 +51,10 @@ constexpr int kGramWG = 128;
 struct Switches {
   bool block_mfma = true, bulk2 = true, filter3 = true, filter4 = true, filter6 = true, filter7 = true, filter6_dual = true, block_dual = true, block_flags = true, block_chain = true, block_pipe = true;
   bool force_collective = false;
+  bool serial_wide = true, step_dual = true;
+  int sweep_threads = 512;
+  double ns_far4 = 0.6;            // filter4 / filter4s: residual at which a Newton-Schulz start is given up (PSMF_NS_FAR4; PSMF_NS_FAR, when set, rules both)
+  bool ns_far_set = false;
   bool step_persistent = true;      // per-step engine: one persistent launch per run (psmf_pstep.hip) where it applies; PSMF_STEP_PERSISTENT=0: two launches per timestep
   static bool off(const char* name) { const char* e = getenv(name); return e && atoi(e) == 0; }
   void read() {
@@ -58,6 +62,10 @@ struct Switches {
     block_flags = !off("PSMF_BLOCK_FLAGS"); block_chain = !off("PSMF_BLOCK_CHAIN"); block_pipe = !off("PSMF_BLOCK_PIPE");
     force_collective = getenv("PSMF_FORCE_COLLECTIVE") != nullptr;
     step_persistent = !off("PSMF_STEP_PERSISTENT");
+    serial_wide = !off("PSMF_SERIAL_WIDE"); step_dual = !off("PSMF_STEP_DUAL");
+    { const char* e = getenv("PSMF_SWEEP_THREADS"); sweep_threads = (e && atoi(e) == 256) ? 256 : 512; }
+    if (const char* e = getenv("PSMF_NS_FAR4")) ns_far4 = atof(e);
+    ns_far_set = getenv("PSMF_NS_FAR") != nullptr;
   }
 };
 
@@ -124,6 +132,8 @@ struct psmf_filter {
   psmf::PstepPlan ps_plan = {};
   bool ps_ok = false;
   void* ps_comm = nullptr;
+  long long* ps_prof = nullptr;    // PSMF_PSTEP_PROF=1 with a -DPSTEP_PROF build: per-phase clock sums of the last launch, printed at psmf_destroy
+  long long ps_prof_steps = 0;
   long long ps_launches = 0;
   bool have_state = false;
   bool need_prep = true;
@@ -220,11 +230,6 @@ sweep_fn_t sweep_for_gs(int gs) {
 
 // threads per sweep workgroup (tuning knob PSMF_SWEEP_THREADS=256|512): 512 halves the number of
 // per-workgroup partial rows the serial stage has to read at the same number of waves per CU
-int sweep_threads() {
-  static const int nt = [] { const char* e = getenv("PSMF_SWEEP_THREADS"); return (e && atoi(e) == 256) ? 256 : 512; }();
-  return nt;
-}
-
 sweep_fn_t sweep_kernel(const psmf_filter* h) {
   const int gs = h->geo.gs;
   if (h->geo.nt == 512)
@@ -232,10 +237,7 @@ sweep_fn_t sweep_kernel(const psmf_filter* h) {
   return h->cfg.storage == PSMF_F64 ? sweep_for_gs<double, 256>(gs) : sweep_for_gs<float, 256>(gs);
 }
 
-bool serial_wide(const psmf_filter* h) {
-  static const bool off = Switches::off("PSMF_SERIAL_WIDE");
-  return h->geo.rpad >= 64 && !off;
-}
+bool serial_wide(const psmf_filter* h) { return h->geo.rpad >= 64 && h->sw.serial_wide; }
 
 serial_fn_t serial_kernel(const psmf_filter* h) {
   switch (h->geo.rpad) {
@@ -397,16 +399,16 @@ FilterKernel select_filter_kernel(const psmf_filter* h) {
 void launch_blk_filter(psmf_filter* h, const psmf::BlockParams& b, hipStream_t stream = nullptr) {
   if (!stream) stream = h->stream;
   const size_t lds3 = psmf::blk_filter3_lds_bytes(), lds = psmf::blk_filter_lds_bytes();
-  switch (select_filter_kernel(h)) {
+  const FilterKernel fk = select_filter_kernel(h);
+  switch (fk) {
     case FK_FILTER5: hipLaunchKernelGGL(psmf::psmf_blk_filter5, dim3(1), dim3(psmf::F3_NT), lds3, stream, b); return;
     case FK_FILTER4:
     case FK_FILTER4S: {
       // filter4's fallback is the wave-local sweep (~5 us, five to six iterations' worth; filter3's LDS sweep: 15 us): a start
       // beyond ||R||_F = 0.6 is cheaper swept than iterated (PSMF_NS_FAR4)
-      static const double far4 = getenv("PSMF_NS_FAR4") ? atof(getenv("PSMF_NS_FAR4")) : 0.6;
       psmf::BlockParams b4 = b;
-      if (!getenv("PSMF_NS_FAR")) b4.sp.ns_far2 = far4 * far4;
-      if (select_filter_kernel(h) == FK_FILTER4) hipLaunchKernelGGL(psmf::psmf_blk_filter4, dim3(1), dim3(psmf::F3_NT), lds3, stream, b4);
+      if (!h->sw.ns_far_set) b4.sp.ns_far2 = h->sw.ns_far4 * h->sw.ns_far4;
+      if (fk == FK_FILTER4) hipLaunchKernelGGL(psmf::psmf_blk_filter4, dim3(1), dim3(psmf::F3_NT), lds3, stream, b4);
       else hipLaunchKernelGGL(psmf::psmf_blk_filter4s, dim3(1), dim3(psmf::F3_NT), lds3, stream, b4);
       return;
     }
@@ -724,12 +726,12 @@ int rot_dict(psmf_filter* h, const void* src, void* dst, bool fwd) {
   return rot_gemm(h, (const double*)h->rotU, ai, ak, (const float*)src, rp, 1LL, (float*)dst, rp, d, r, d);
 }
 
-void compute_geometry(const psmf_config& c, Geometry& g) {
+void compute_geometry(const psmf_config& c, Geometry& g, const int sweep_nt = 512) {
   g.vec = c.storage == PSMF_F64 ? 2 : 4;
   g.nv = (c.r + g.vec - 1) / g.vec;
   g.rp = g.nv * g.vec;
   g.gs = next_pow2(g.nv);
-  g.nt = c.r > 32 ? 256 : sweep_threads();      // r > 32: the solve block (3 x 3 / 4 x 4 tiles of 16 x 16 in ONE wave's registers) needs a 256-thread kernel's register budget
+  g.nt = c.r > 32 ? 256 : sweep_nt;      // r > 32: the solve block (3 x 3 / 4 x 4 tiles of 16 x 16 in ONE wave's registers) needs a 256-thread kernel's register budget
   g.rpp = g.nt / g.gs;
   g.rpad = next_pow2(c.r < 8 ? 8 : c.r);
   const size_t solve_lds = c.coef_update ? (size_t)(4 * psmf::RM + 2) * 8 : 0;
@@ -748,9 +750,8 @@ void compute_geometry(const psmf_config& c, Geometry& g) {
 // StepParams.solve_dual: can the per-step solve block run its two inversions side by side?  (random walk, Q = q I as last uploaded,
 // full filter, uniform R, wave-local solve, no Q_k schedule: q of the next step is q -- or omega q -- of this one)
 void update_solve_dual(psmf_filter* h) {
-  static const bool off = Switches::off("PSMF_STEP_DUAL");
   const psmf_config& c = h->cfg;
-  const int v = (!off && h->engine == 1 && h->q_iso && c.masked < 2 && c.dyn_kind == PSMF_DYN_RANDOM_WALK && c.coef_update && c.pbar_predict && !c.nonuniform_R &&
+  const int v = (h->sw.step_dual && h->engine == 1 && h->q_iso && c.masked < 2 && c.dyn_kind == PSMF_DYN_RANDOM_WALK && c.coef_update && c.pbar_predict && !c.nonuniform_R &&
                  !h->sp.solve_lds && !h->sp.q_sched) ? 1 : 0;
   if (v != h->sp.solve_dual) {
     h->sp.solve_dual = v;
@@ -778,6 +779,8 @@ int launch_pstep(psmf_filter* h, int64_t k_begin, int64_t n) {
     q.flags = reinterpret_cast<unsigned*>(h->ps_comm);
     q.pkt = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(h->ps_comm) + h->ps_plan.off_pkt);
     q.part = reinterpret_cast<double*>(reinterpret_cast<char*>(h->ps_comm) + h->ps_plan.off_part);
+    q.prof = h->ps_prof;
+    h->ps_prof_steps = chunk;
     std::lock_guard<std::mutex> lock(g_ps_mutex);
     const int dev = h->cfg.device & 63;
     if (!g_ps_event[dev]) HIP_TRY(h, hipEventCreateWithFlags(&g_ps_event[dev], hipEventDisableTiming));
@@ -908,7 +911,7 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
   psmf_filter* h = new psmf_filter();
   h->cfg = *cfg;
   h->sw.read();
-  compute_geometry(h->cfg, h->geo);
+  compute_geometry(h->cfg, h->geo, h->sw.sweep_threads);
   auto bail = [&](int code) { g_create_error = h->err; psmf_destroy(h); return code; };
 #define CREATE_TRY(expr)                                                                  \
   do {                                                                                    \
@@ -1051,6 +1054,7 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
       CREATE_TRY(psmf::pstep_init());
       CREATE_TRY(hipMalloc(&h->ps_comm, h->ps_plan.total_bytes));
       CREATE_TRY(hipMemset(h->ps_comm, 0, h->ps_plan.total_bytes));
+      if (getenv("PSMF_PSTEP_PROF")) { CREATE_TRY(hipMalloc((void**)&h->ps_prof, 64 * sizeof(long long))); CREATE_TRY(hipMemset(h->ps_prof, 0, 64 * sizeof(long long))); }
       h->ps_ok = true;
     }
   }
@@ -1112,6 +1116,20 @@ void psmf_destroy(psmf_handle h) {
   if (h->Y) hipFree(h->Y);
   if (h->YP) hipFree(h->YP);
   if (h->partials) hipFree(h->partials);
+  if (h->ps_prof) {
+    long long pf[64];
+    if (hipMemcpy(pf, h->ps_prof, sizeof(pf), hipMemcpyDeviceToHost) == hipSuccess && h->ps_prof_steps > 0) {
+      fprintf(stderr, "[pstep prof] cycles per timestep over the last launch (%lld steps), d_local %d r %d:\n", h->ps_prof_steps, h->cfg.d_local, h->cfg.r);
+      const char* grp[3] = {"hub workers", "solve wave ", "row wg 0   "};
+      const int base[3] = {0, 16, 24}, cnt[3] = {9, 3, 5};
+      for (int g = 0; g < 3; ++g) {
+        fprintf(stderr, "  %s:", grp[g]);
+        for (int i = 0; i < cnt[g]; ++i) fprintf(stderr, " %7.0f", (double)pf[base[g] + i] / (double)h->ps_prof_steps);
+        fprintf(stderr, "\n");
+      }
+    }
+    hipFree(h->ps_prof);
+  }
   if (h->ps_comm) hipFree(h->ps_comm);
   if (h->gpart) hipFree(h->gpart);
   if (h->mu_hist) hipFree(h->mu_hist);
@@ -1800,6 +1818,25 @@ int psmf_comm_init(psmf_handle h, int nranks, int rank, const void* unique_id) {
   return PSMF_OK;
 }
 
+int psmf_comm_abort(psmf_handle h) {
+  if (!h) return PSMF_ERR_ARG;
+  int rc = set_device(h);
+  if (rc) return rc;
+  if (h->comm) {
+    // ncclCommAbort, not ncclCommDestroy: destroy waits for outstanding work and for its peers, and the caller is here because
+    // some peer never joined (or stopped answering)
+    const ncclResult_t e = ncclCommAbort(h->comm);
+    h->comm = nullptr;
+    if (e != ncclSuccess) return fail(h, PSMF_ERR_RCCL, std::string("ncclCommAbort: ") + ncclGetErrorString(e));
+  }
+  h->nranks = 1; h->rank = 0;
+  h->use_coll = false;
+  h->sp.external_reduce = 0;
+  destroy_graph(h);
+  h->need_prep = true;
+  return PSMF_OK;
+}
+
 int psmf_set_row_noise(psmf_handle h, const double* rho_rows, double rho_mean) {
   if (!h || !rho_rows || !(rho_mean > 0.0)) return fail(h, PSMF_ERR_ARG, "psmf_set_row_noise: bad argument");
   if (!h->cfg.nonuniform_R) return fail(h, PSMF_ERR_STATE, "psmf_set_row_noise: the handle was created with nonuniform_R = 0");
@@ -1831,14 +1868,26 @@ int psmf_set_noise_rotation(psmf_handle h, const double* U, const double* lam) {
     tr += lam[i];
   }
   if (!(tr > 0.0)) return fail(h, PSMF_ERR_ARG, "psmf_set_noise_rotation: tr(R) must be positive");
-  // a cheap look at orthonormality (the full check is O(d^3)): first and last column of unit length and orthogonal
-  double n0 = 0.0, n1 = 0.0, dot = 0.0;
-  for (size_t k = 0; k < d; ++k) {
-    const double a = U[k * d], b = U[k * d + d - 1];
-    n0 += a * a; n1 += b * b; dot += a * b;
+  if (d > (size_t)PSMF_ROTATION_DMAX)
+    return fail(h, PSMF_ERR_ARG, "psmf_set_noise_rotation: a non-diagonal R is supported up to d = 32768 (the handle keeps the d x d eigenvector matrix "
+                                 "resident: 8 d^2 bytes); beyond that use a diagonal R or backend=\"numpy\"");
+  // orthonormality over ALL of U in O(d^2): U^T (U z) = z for two probe vectors z (+-1 entries from a fixed generator).  A column
+  // pair that is not orthonormal shows in (U^T U - I) z unless z lies in that matrix's null space -- two independent sign
+  // patterns do not.  (The full check U^T U = I is O(d^3); a C caller with a wrong U used to get a silently wrong filter.)
+  {
+    std::vector<double> z(d), t(d), u(d);
+    unsigned long long lcg = 0x9E3779B97F4A7C15ull;
+    for (int probe = 0; probe < 2; ++probe) {
+      for (size_t i = 0; i < d; ++i) { lcg = lcg * 6364136223846793005ull + 1442695040888963407ull; z[i] = (lcg >> 63) ? 1.0 : -1.0; }
+      for (size_t i = 0; i < d; ++i) { double a = 0.0; const double* row = U + i * d; for (size_t k = 0; k < d; ++k) a += row[k] * z[k]; t[i] = a; }
+      for (size_t k = 0; k < d; ++k) u[k] = 0.0;
+      for (size_t i = 0; i < d; ++i) { const double ti = t[i]; const double* row = U + i * d; for (size_t k = 0; k < d; ++k) u[k] += row[k] * ti; }
+      double worst = 0.0;
+      for (size_t k = 0; k < d; ++k) worst = std::fmax(worst, std::fabs(u[k] - z[k]));
+      if (!(worst <= 1e-8 * std::sqrt((double)d) + 1e-10))
+        return fail(h, PSMF_ERR_ARG, "psmf_set_noise_rotation: the columns of U are not orthonormal (U^T U z != z)");
+    }
   }
-  if (std::fabs(n0 - 1.0) > 1e-8 || std::fabs(n1 - 1.0) > 1e-8 || (d > 1 && std::fabs(dot) > 1e-8))
-    return fail(h, PSMF_ERR_ARG, "psmf_set_noise_rotation: the columns of U are not orthonormal");
   int rc = psmf_set_row_noise(h, lam, tr / (double)d);
   if (rc) return rc;
   if (!h->rotU) HIP_TRY(h, hipMalloc((void**)&h->rotU, d * d * sizeof(double)));

@@ -5,7 +5,7 @@
 namespace psmf {
 
 constexpr int PSTEP_NT = 512;        // threads per workgroup (8 waves), every workgroup of the launch
-constexpr int PSTEP_NPMAX = 16;      // row passes a row workgroup can keep in registers (4 float64 per lane and pass; y_k beside them)
+constexpr int PSTEP_NPMAX = 12;      // row passes a row workgroup can keep in registers (4 float64 per lane and pass; y_k beside them)
 constexpr int PSTEP_NPMAX_F64 = 12;  // ... with float64 storage (y_k takes two registers per pass)
 constexpr int PSTEP_PKT_MAX = 4 * RM + 1;      // granules of the hub -> rows packet
 
@@ -20,6 +20,7 @@ struct PstepParams {
   unsigned* flags;             // rows -> hub: one epoch word per row workgroup        } one block, zeroed before every launch
   unsigned long long* pkt;     // hub -> rows: PSTEP_PKT_MAX {tag, value} granules      }
   double* part;                // rows -> hub: n_row_wg x ncol2 partial sums (write-through stores)
+  long long* prof;             // diagnostic builds (-DPSTEP_PROF): per-phase shader-clock sums, [0..15] hub workers, [16..23] solve wave, [24..31] row workgroup 1
 };
 
 struct PstepPlan {

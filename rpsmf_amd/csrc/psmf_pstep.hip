@@ -68,9 +68,32 @@ __device__ __forceinline__ double cross_sum(double v) {
   return ps_xor32_sum(v);
 }
 
+// sum over the 64 lanes, float64, DPP row operations + four readlanes (a butterfly of __shfl_xor on doubles is two ds_bpermute and an LDS
+// round trip per level); fixed order, same value in every lane
+__device__ __forceinline__ double ps_wave_sum(double v) {
+  v += PS_DPP64(v, 0xB1);
+  v += PS_DPP64(v, 0x4E);
+  v += PS_DPP64(v, 0x141);
+  v += PS_DPP64(v, 0x140);
+  return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
+}
+
 // workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, and every wave here keeps global stores
 // (y_hat, the mean history, hand-off words) in flight that nothing inside the launch reads back through the cache
 __device__ __forceinline__ void ps_bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// per-phase shader-clock sums of one lane (diagnostic builds only: -DPSTEP_PROF; tools/probe_pstep.py prof)
+#ifdef PSTEP_PROF
+#define PS_PROF_DECL(n) long long pf_acc[n]; _Pragma("unroll") for (int pf_i = 0; pf_i < n; ++pf_i) pf_acc[pf_i] = 0; long long pf_prev = 0
+#define PS_PROF_START() do { __builtin_amdgcn_sched_barrier(0); pf_prev = (long long)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PS_PROF(i) do { __builtin_amdgcn_sched_barrier(0); const long long pf_t = (long long)__builtin_amdgcn_s_memtime(); pf_acc[i] += pf_t - pf_prev; pf_prev = pf_t; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define PS_PROF_OUT(base, n, cond) do { if (q.prof && (cond)) { _Pragma("unroll") for (int pf_i = 0; pf_i < n; ++pf_i) q.prof[(base) + pf_i] = pf_acc[pf_i]; } } while (0)
+#else
+#define PS_PROF_DECL(n) do { } while (0)
+#define PS_PROF_START() do { } while (0)
+#define PS_PROF(i) do { } while (0)
+#define PS_PROF_OUT(base, n, cond) do { } while (0)
+#endif
 
 typedef unsigned long long u64;
 __device__ __forceinline__ void gran_store(u64* g, unsigned tag, unsigned v) {
@@ -96,7 +119,7 @@ __device__ __forceinline__ void pstep_rows(const PstepParams& q, char* smem) {
   const int wg = (int)blockIdx.x - 1;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int j = tid % GS, g = tid / GS;
-  const int r = p.r, rp = p.rp, dl = p.d_local, np = q.np;
+  const int r = p.r, rp = p.rp, dl = p.d_local;
   const int row_begin = wg * q.rows_per_wg;
   const int row_end = min(row_begin + q.rows_per_wg, dl);
 
@@ -112,7 +135,7 @@ __device__ __forceinline__ void pstep_rows(const PstepParams& q, char* smem) {
   for (int ps = 0; ps < NPMAX; ++ps) {
 #pragma unroll
     for (int v = 0; v < 4; ++v) c[ps][v] = 0.0;
-    if (ps < np) {
+    {
       const int row = row_begin + ps * RPW + g;
       if (row < row_end) {
         okmask |= 1u << ps;
@@ -136,10 +159,11 @@ __device__ __forceinline__ void pstep_rows(const PstepParams& q, char* smem) {
   T ycur[NPMAX];
 #pragma unroll
   for (int ps = 0; ps < NPMAX; ++ps) {
-    ycur[ps] = (T)0;
-    if (ps < np) ycur[ps] = Yg[(size_t)t_first * dl + min(row_begin + ps * RPW + g, row_end - 1)];
+    ycur[ps] = Yg[(size_t)t_first * dl + min(row_begin + ps * RPW + g, row_end - 1)];
   }
   ps_bar();
+  PS_PROF_DECL(8);
+  PS_PROF_START();
 
   for (int s = 0; s < q.n_steps; ++s) {
     const unsigned epoch = (unsigned)s + 1u;
@@ -169,7 +193,9 @@ __device__ __forceinline__ void pstep_rows(const PstepParams& q, char* smem) {
       if (lane == 0) { if (stop == 0 && s_pkt32[NG - 1] != 0u) stop = 1; }
       if (lane == 0 && stop) s_ctl[0] = stop;
     }
+    PS_PROF(0);      // packet wait (wave 0) / idle (others)
     ps_bar();
+    PS_PROF(1);
     if (lds_word(s_ctl) != 0) break;
     const double* s_mub = reinterpret_cast<const double*>(s_pkt32);
     const double* s_wn = s_mub + RPAD;
@@ -184,7 +210,7 @@ __device__ __forceinline__ void pstep_rows(const PstepParams& q, char* smem) {
     double eacc = 0.0;
 #pragma unroll
     for (int ps = 0; ps < NPMAX; ++ps) {
-      if (ps < np) {
+      {
         double dot = (c[ps][0] * mub[0] + c[ps][1] * mub[1]) + (c[ps][2] * mub[2] + c[ps][3] * mub[3]);
         dot = group_sum<GS>(dot);
         const bool ok = (okmask >> ps) & 1u;
@@ -199,6 +225,7 @@ __device__ __forceinline__ void pstep_rows(const PstepParams& q, char* smem) {
         eacc = fma(e, e, eacc);
       }
     }
+    PS_PROF(2);      // row passes
     // ---- workgroup partial of (h, ee): lanes of equal j, then the waves through LDS, fixed order ----
 #pragma unroll
     for (int v = 0; v < 4; ++v) hacc[v] = cross_sum<GS>(hacc[v]);
@@ -209,6 +236,7 @@ __device__ __forceinline__ void pstep_rows(const PstepParams& q, char* smem) {
       if (lane == 0) s_red[wv * (RPAD + 1) + RPAD] = eacc;
     }
     ps_bar();
+    PS_PROF(3);      // wave sums + barrier
     if (wv == 0) {
       // lane i: elements 2 i, 2 i + 1 of the partial row [h_0 .. h_{r-1}, ee]
       double out[2];
@@ -227,14 +255,16 @@ __device__ __forceinline__ void pstep_rows(const PstepParams& q, char* smem) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (lane == 0) __hip_atomic_store(q.flags + wg, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    PS_PROF(4);      // partial row out, drained, flag
     // (no barrier: wave 0 rewrites s_pkt32 only after every wave has passed the barrier above, behind its own reads of it;
     //  s_red is rewritten behind the next step's first barrier, which wave 0 reaches after reading it)
   }
 
+  PS_PROF_OUT(24, 8, wg == 0 && tid == 0);
   // ---- C back to its storage type: one rounding per launch ----
 #pragma unroll
   for (int ps = 0; ps < NPMAX; ++ps) {
-    if (ps < np && ((okmask >> ps) & 1u)) {
+    if ((okmask >> ps) & 1u) {
       const int row = row_begin + ps * RPW + g;
       T* dstp = Cg + (size_t)row * rp + 4 * j;
       if constexpr (sizeof(T) == 4) {
@@ -322,10 +352,9 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
   constexpr int RG = NWK / RPAD;
   constexpr int M = (RPAD * RPAD) / NWK > 0 ? (RPAD * RPAD) / NWK : 1;
   constexpr int LS = RPAD + 1;               // row stride of the r x r LDS images
-  constexpr int NTL = RPAD > 16 ? 2 : 1;
   constexpr int NG = 4 * RPAD + 1;
   constexpr int NFT = (NW - 2) * 64;         // threads of the fan-in (waves 0 .. NW-3)
-  static_assert(RPAD <= 32, "the hub holds the r x r state of r <= 32");
+  constexpr int LPC = RPAD > 32 ? 4 : 8;     // lanes per column of the fan-in's second level (LPC x (r + 1) <= NFT)
   const StepParams& p = q.sp;
   DevState* st = p.st;
   const int r = p.r, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -354,7 +383,7 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
   const bool dual = p.solve_dual != 0;
   const int nsv = st->ns_valid;
   bool carried = dual && nsv == 7;
-  double Vv[M], Pv[M], Gv[M], Qv[M], Pbv[M], Wv[M];
+  double Vv[M], Pv[M], Gv[M], Qv[M], Pbv[M];
   bool val[M];
   int ii[M];
 #pragma unroll
@@ -368,7 +397,6 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
     Qv[m] = val[m] ? lq : 0.0;
     Pbv[m] = val[m] ? 0.5 * (lp + lpt) : 0.0;
     Pv[m] = 0.0;
-    Wv[m] = 0.0;
     if (val[m]) {
       sG[ii[m] * LS + j] = Gv[m];
       sL[ii[m] * LS + j] = carried ? ll : Pbv[m];
@@ -409,16 +437,26 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
 
   // fan-in geometry: thread t of waves 0 .. NW-3 sums elements (2 pi, 2 pi + 1) of the partial rows seg, seg + S, ...
   const int npair = ncol2 >> 1;
-  const int S = NFT / npair;
+  const int S = min(NFT / npair, 3 * LPC);   // segments: the second level below sums three of them per lane, LPC lanes per column
   const int f_pi = tid % npair, f_seg = tid / npair;
   const bool f_on = tid < NFT && f_seg < S;
 
   // ---- the solve waves run a loop of their own (same barriers, none of the workers' registers): the kernel's register allocation
   //      is the larger of the two roles, not their sum ----
   if (wv >= NW - 2) {
+    PS_PROF_DECL(8);
+    PS_PROF_START();
     for (int s = 0; s < q.n_steps; ++s) {
-      if (p.coef_update) hub_solve<NTL>(wv - (NW - 2), dual, carried, r, s_sc[0], s_sc[1], s_sc[2], sL, sG, sPp, sW, LS, s_ctl + 2);
+      if (p.coef_update) {
+        const int role = wv - (NW - 2);
+        if constexpr (RPAD <= 16) hub_solve<1>(role, dual, carried, r, s_sc[0], s_sc[1], s_sc[2], sL, sG, sPp, sW, LS, s_ctl + 2);
+        else if constexpr (RPAD == 32) hub_solve<2>(role, dual, carried, r, s_sc[0], s_sc[1], s_sc[2], sL, sG, sPp, sW, LS, s_ctl + 2);
+        else if (r <= 48) hub_solve<3>(role, dual, carried, r, s_sc[0], s_sc[1], s_sc[2], sL, sG, sPp, sW, LS, s_ctl + 2);
+        else hub_solve<4>(role, dual, carried, r, s_sc[0], s_sc[1], s_sc[2], sL, sG, sPp, sW, LS, s_ctl + 2);
+      }
+      PS_PROF(0);                                                 // the inversion
       ps_bar();                                                   // end of phase A
+      PS_PROF(1);                                                 // waiting for the fan-in
       if (lds_word(s_ctl) != 0 || lds_word(s_ctl + 2) != 0) break;
       ps_bar();                                                   // phase B: the workers' barriers, one for one
       if (p.coef_update) { ps_bar(); ps_bar(); }
@@ -427,11 +465,15 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
       if (p.eta_full) ps_bar();
       ps_bar();
       carried = dual;
+      PS_PROF(2);                                                 // the workers' phase B
     }
+    PS_PROF_OUT(16, 8, tid == (NW - 2) * 64);
     return;
   }
 
   int n_done = 0;
+  PS_PROF_DECL(16);
+  PS_PROF_START();
   for (int s = 0; s < q.n_steps; ++s) {
     const unsigned epoch = (unsigned)s + 1u;
     // =========================== phase A: the fan-in (beside the solve waves' inversions) ===========================
@@ -454,6 +496,7 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
         while (lds_word(s_ctl + 1) < (int)epoch) __builtin_amdgcn_s_sleep(1);      // (wave 0 always sets it, bounded by its own timeout)
       }
       asm volatile("" ::: "memory");
+      PS_PROF(0);      // flags of all row workgroups seen
       if (f_on && lds_word(s_ctl) == 0) {
         double a0 = 0.0, a1 = 0.0;
         const double* base = q.part + 2 * f_pi;
@@ -476,22 +519,30 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
         s_seg[f_seg * ncol2 + 2 * f_pi + 1] = a1;
       }
     }
+    PS_PROF(1);        // partial rows loaded, segment sums in LDS
     ps_bar();
-    if (lds_word(s_ctl) != 0 || lds_word(s_ctl + 2) != 0) break;
+    PS_PROF(2);        // (waiting for the solve waves)
+    if ((lds_word(s_ctl) | lds_word(s_ctl + 2)) != 0) break;
     // =========================== phase B: the serial stage of step k0 (psmf_kernels.hip: serial_body) ===========================
-    if (tid < ncol) {
+    if (tid < LPC * ncol) {      // column tid / LPC: lane u of its LPC sums segments u, u + LPC, u + 2 LPC, then the LPC lanes (fixed order)
+      const int col = tid / LPC, u = tid % LPC;
+      double v[3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) v[k] = s_seg[min(u + LPC * k, S - 1) * ncol2 + col];
       double a = 0.0;
-      for (int sg = 0; sg < S; ++sg) a += s_seg[sg * ncol2 + tid];
-      s_he[tid] = a;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) a += (u + LPC * k < S) ? v[k] : 0.0;
+      a = group_sum<LPC>(a);
+      if (u == 0) s_he[col] = a;
     }
     // P+ and W of the solve waves, symmetrised
 #pragma unroll
     for (int m = 0; m < M; ++m) {
       if (p.coef_update) Pv[m] = val[m] ? 0.5 * (sPp[ii[m] * LS + j] + sPp[j * LS + ii[m]]) : 0.0;
       else Pv[m] = Pbv[m];
-      Wv[m] = (dual && val[m]) ? 0.5 * (sW[ii[m] * LS + j] + sW[j * LS + ii[m]]) : 0.0;
     }
     ps_bar();
+    PS_PROF(3);        // h, ee summed; P+, W read
     const double N = N0, kappa = kappa0;
     const double ee = s_he[r];
     const double wj = j < r ? s_w[j] : 0.0;
@@ -502,12 +553,13 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
 #pragma unroll
       for (int m = 0; m < M; ++m) part += val[m] ? Pv[m] * s_he[min(ii[m], r - 1)] : 0.0;
       hub_col_reduce<RPAD, NWK>(worker, part, s_red, s_vec);      // s_vec = P+ h
-      const double bPb = wave_sum(lane < r ? s_he[lane] * s_vec[lane] : 0.0);
+      const double bPb = ps_wave_sum(lane < r ? s_he[lane] * s_vec[lane] : 0.0);
       quad -= kappa * kappa * bPb;
       if (vl) mu_new = mub_t + kappa * s_vec[tid];
     } else {
       if (vl) mu_new = mub_t;
     }
+    PS_PROF(4);        // P+ h, mu
     // theta gradient at the pre-update state   psmf.py:48-66,167-177; rpsmf.py:53-73
     if (tl) {
       const double tk = (double)(k0 + 1);
@@ -537,17 +589,21 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
       if (!p.fixed_lambda) lam += dd;
     }
     const double iq_old = s_sc[1];
-    double Lv[M];
 #pragma unroll
     for (int m = 0; m < M; ++m) {
-      Lv[m] = 0.0;
       if (val[m]) {
         const double wi = s_w[ii[m]], hi = s_he[ii[m]], hj = s_he[j];
         Vv[m] = vscale * (Vv[m] - wi * wj * invN);
         Pv[m] *= pscale;
         if (p.track_g) Gv[m] += (hi * wj + wi * hj) * invN + ee * (wi * wj) * (invN * invN);
         if (qscale != 1.0) Qv[m] *= qscale;
-        if (dual) Lv[m] = ((ii[m] == j ? iq_old : 0.0) - Wv[m] * iq_old * iq_old) / omega;      // Pbar'^-1 = (I / q - W / q^2) / omega
+        // operands of the next step's inversions (the solve waves only read them in phase A): the tracked Gram, and -- inversions side by
+        // side -- Pbar'^-1 = (I / q - W / q^2) / omega from the W the solve waves left (symmetrised)
+        sG[ii[m] * LS + j] = Gv[m];
+        if (dual) {
+          const double wsym = 0.5 * (sW[ii[m] * LS + j] + sW[j * LS + ii[m]]);
+          sL[ii[m] * LS + j] = ((ii[m] == j ? iq_old : 0.0) - wsym * iq_old * iq_old) / omega;
+        }
       }
     }
     const long long knext = k0 + 1;
@@ -581,6 +637,7 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
       mub_t = mb;
     }
     ps_bar();
+    PS_PROF(5);        // gradient, scalars, r x r updates, Adam, mu_bar
     double part = 0.0, gp = 0.0;
 #pragma unroll
     for (int m = 0; m < M; ++m) {
@@ -592,14 +649,15 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
       }
     }
     hub_col_reduce<RPAD, NWK>(worker, part, s_red, s_vec);        // s_vec = V mu_bar
-    const double sN = wave_sum(lane < r ? s_mub[lane] * s_vec[lane] : 0.0);
+    const double sN = ps_wave_sum(lane < r ? s_mub[lane] * s_vec[lane] : 0.0);
     double eta = rho * p.rho_mean;
     if (p.eta_full) {
-      double x = wave_sum(worker ? gp : 0.0);
+      double x = ps_wave_sum(worker ? gp : 0.0);
       if (lane == 0) s4[wv] = x;
       ps_bar();
       eta += ((s4[0] + s4[1]) + (s4[2] + s4[3])) / dd;
     }
+    PS_PROF(6);        // V mu_bar, s, eta
     const double Nn = sN + eta;
     const double iNn = fast_rcp(Nn);
     const double kap_n = fast_rcp(rho + sN);
@@ -608,13 +666,9 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
       s_w[tid] = w_t;
       s_wn[tid] = w_t * iNn;
     }
-    // operands of the next step's inversions
+    if (!dual) {      // inversions one after the other: the solve wave starts from Pbar
 #pragma unroll
-    for (int m = 0; m < M; ++m) {
-      if (val[m]) {
-        sG[ii[m] * LS + j] = Gv[m];
-        sL[ii[m] * LS + j] = dual ? Lv[m] : Pbv[m];
-      }
+      for (int m = 0; m < M; ++m) if (val[m]) sL[ii[m] * LS + j] = Pbv[m];
     }
     if (tid == 0) {
       s_sc[0] = kap_n;
@@ -624,6 +678,7 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
     N0 = Nn; kappa0 = kap_n; s0 = sN; eta0 = eta; k0 = knext;
     n_done = s + 1;
     ps_bar();
+    PS_PROF(7);        // w / N, solve operands, barrier
     // packet of the next step
     if (s + 1 < q.n_steps && tid < NG) {
       const int e = tid >> 1;
@@ -631,7 +686,9 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
       const unsigned half = tid == NG - 1 ? 0u : ((tid & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v));
       gran_store(q.pkt + tid, epoch + 1u, half);
     }
+    PS_PROF(8);        // packet out
   }
+  PS_PROF_OUT(0, 16, tid == 0);
 
   // ---------------- end of the launch: DevState as the two-launch engine leaves it ----------------
   const int stop = lds_word(s_ctl), badp = lds_word(s_ctl + 2);
@@ -648,7 +705,7 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
       st->G[idx] = Gv[m];
       st->Q[idx] = Qv[m];
       st->Pbar[idx] = Pbv[m];
-      if (n_done > 0 && dual) { st->Lbar[idx] = sL[ii[m] * LS + j]; st->XpY[idx] = Wv[m]; }
+      if (n_done > 0 && dual) { st->Lbar[idx] = sL[ii[m] * LS + j]; st->XpY[idx] = 0.5 * (sW[ii[m] * LS + j] + sW[j * LS + ii[m]]); }
       if (n_done > 0 && p.coef_update) st->Pplus[idx] = sPp[ii[m] * LS + j];
     }
   }
@@ -678,39 +735,48 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
   }
 }
 
-template <typename T, int RPAD>
+// NP: row passes of a row workgroup, all of them unrolled and executed (rows beyond the workgroup's share are masked): no branch
+// between the passes, so their dot products, lane sums and updates interleave
+template <typename T, int RPAD, int NP>
 __global__ __launch_bounds__(PSTEP_NT) void psmf_pstep_k(PstepParams q) {
   extern __shared__ __attribute__((aligned(16))) char ps_smem[];
   if (blockIdx.x == 0) pstep_hub<RPAD, PSTEP_NT>(q, ps_smem);
-  else pstep_rows<T, RPAD, PSTEP_NT, (sizeof(T) == 4 ? PSTEP_NPMAX : PSTEP_NPMAX_F64)>(q, ps_smem);
+  else pstep_rows<T, RPAD, PSTEP_NT, NP>(q, ps_smem);
 }
 
-// one workgroup per compute unit: the request is more than half of a CU's 160 KB
-constexpr size_t PSTEP_LDS_BYTES = 84 * 1024;
-
 typedef void (*pstep_fn_t)(PstepParams);
-pstep_fn_t pstep_kernel(int rpad, bool f64) {
+template <int RPAD>
+pstep_fn_t pstep_kernel_r(bool f64, int np) {
+  if (f64) return np <= 4 ? psmf_pstep_k<double, RPAD, 4> : (np <= 8 ? psmf_pstep_k<double, RPAD, 8> : psmf_pstep_k<double, RPAD, PSTEP_NPMAX_F64>);
+  return np <= 4 ? psmf_pstep_k<float, RPAD, 4> : (np <= 8 ? psmf_pstep_k<float, RPAD, 8> : psmf_pstep_k<float, RPAD, PSTEP_NPMAX>);
+}
+pstep_fn_t pstep_kernel(int rpad, bool f64, int np) {
   switch (rpad) {
-    case 8: return f64 ? psmf_pstep_k<double, 8> : psmf_pstep_k<float, 8>;
-    case 16: return f64 ? psmf_pstep_k<double, 16> : psmf_pstep_k<float, 16>;
-    case 32: return f64 ? psmf_pstep_k<double, 32> : psmf_pstep_k<float, 32>;
+    case 8: return pstep_kernel_r<8>(f64, np);
+    case 16: return pstep_kernel_r<16>(f64, np);
+    case 32: return pstep_kernel_r<32>(f64, np);
+    case 64: return pstep_kernel_r<64>(f64, np);
   }
   return nullptr;
 }
+// dynamic LDS of a launch: more than half of a CU's 160 KB (one workgroup per compute unit); RPAD = 64: the hub's four 64 x 65 images
+size_t pstep_lds_bytes(int rpad) { return rpad > 32 ? (size_t)148 * 1024 : (size_t)84 * 1024; }
+int pstep_np_variant(bool f64, int np) { return np <= 4 ? 4 : (np <= 8 ? 8 : (f64 ? PSTEP_NPMAX_F64 : PSTEP_NPMAX)); }
 
 int pstep_rpad(int r) { return r <= 8 ? 8 : (r <= 16 ? 16 : (r <= 32 ? 32 : 64)); }
 
 }  // namespace
 
 bool pstep_plan(int d_local, int r, int n_cu, bool storage_f64, PstepPlan* out) {
-  if (r < 1 || r > 32 || d_local < 1 || n_cu < 2) return false;
+  if (r < 1 || r > RM || d_local < 1 || n_cu < 2) return false;
   const int rpad = pstep_rpad(r);
   const int rpw = PSTEP_NT / (rpad / 4);
   int nwg = (d_local + rpw - 1) / rpw;
   if (nwg > n_cu - 1) nwg = n_cu - 1;
   int rows = (d_local + nwg - 1) / nwg;
-  const int np = (rows + rpw - 1) / rpw;
+  int np = (rows + rpw - 1) / rpw;
   if (np > (storage_f64 ? PSTEP_NPMAX_F64 : PSTEP_NPMAX)) return false;
+  np = pstep_np_variant(storage_f64, np);       // the kernel instance runs exactly this many passes: fewer, fuller workgroups
   rows = np * rpw;
   nwg = (d_local + rows - 1) / rows;
   out->n_row_wg = nwg;
@@ -727,18 +793,20 @@ bool pstep_plan(int d_local, int r, int n_cu, bool storage_f64, PstepPlan* out) 
 }
 
 hipError_t pstep_init() {
-  for (int rpad = 8; rpad <= 32; rpad *= 2)
-    for (int f = 0; f < 2; ++f) {
-      const hipError_t e = hipFuncSetAttribute((const void*)pstep_kernel(rpad, f != 0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)PSTEP_LDS_BYTES);
-      if (e != hipSuccess) return e;
-    }
+  for (int rpad = 8; rpad <= 64; rpad *= 2)
+    for (int f = 0; f < 2; ++f)
+      for (int np = 4; np <= 16; np *= 2) {      // (4, 8, 16 -> the three instances)
+        const hipError_t e = hipFuncSetAttribute((const void*)pstep_kernel(rpad, f != 0, np), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pstep_lds_bytes(rpad));
+        if (e != hipSuccess) return e;
+      }
   return hipSuccess;
 }
 
 hipError_t pstep_launch(const PstepParams& q, bool storage_f64, hipStream_t stream) {
-  pstep_fn_t fn = pstep_kernel(pstep_rpad(q.sp.r), storage_f64);
+  const int rpad = pstep_rpad(q.sp.r);
+  pstep_fn_t fn = pstep_kernel(rpad, storage_f64, q.np);
   if (!fn) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(fn, dim3(q.n_row_wg + 1), dim3(PSTEP_NT), PSTEP_LDS_BYTES, stream, q);
+  hipLaunchKernelGGL(fn, dim3(q.n_row_wg + 1), dim3(PSTEP_NT), pstep_lds_bytes(rpad), stream, q);
   return hipGetLastError();
 }
 

@@ -24,6 +24,8 @@ states the intent and involves no probing.
 Nothing here touches the GPU or the oracle; the probes are r-sized host arithmetic, run once per construction.
 """
 
+import copy
+
 import numpy as np
 
 from . import nonlinearities as NL
@@ -154,8 +156,18 @@ def _make_probe(cls, robust, pb, alpha, beta, like=None):
         Rs = {k: _rho_at(k) * np.eye(d) for k in keys}
         PSMFIter.__init__(obj, pb["theta0"], pb["C0"], pb["V0"], pb["mu0"], pb["P0"], Qs, Rs, nl, backend="numpy")
     if like is not None:
+        # COPIES of the user's attributes: hooks that keep counters, caches or dicts of their own would otherwise leave the
+        # probe's 2 x 10 steps in the live object before its real run.  (Attributes must exist when PSMFIter.__init__ runs:
+        # a subclass that sets them after super().__init__() is probed without them.)
         for name, val in vars(like).items():
             if name not in vars(obj):
+                try:
+                    val = copy.deepcopy(val)
+                except Exception:
+                    try:
+                        val = copy.copy(val)
+                    except Exception:
+                        pass              # not copyable (an open file, a lock, ...): shared, as before
                 setattr(obj, name, val)
     return obj
 
