@@ -55,13 +55,14 @@ def source_hash():
 
 
 def _units():
-    """(object name, source, files whose content decides whether the object is stale)"""
+    """(object name, source, files whose content decides whether the object is stale, extra flags)"""
     srcs = _sources()
     pstep_deps = [os.path.join(CSRC, f) for f in _PSTEP_FILES]
     capi_deps = [p for p in srcs if os.path.basename(p) not in ("psmf_pstep.hip", "psmf_buildid.cpp")] + [HEADER]
+    pstep = os.path.join(CSRC, "psmf_pstep.hip")
     return [
-        ("psmf_capi.o", os.path.join(CSRC, "psmf_capi.hip"), capi_deps),
-        ("psmf_pstep.o", os.path.join(CSRC, "psmf_pstep.hip"), pstep_deps),
+        ("psmf_capi.o", os.path.join(CSRC, "psmf_capi.hip"), capi_deps, []),
+        ("psmf_pstep.o", pstep, pstep_deps, []),          # persistent per-step kernel (+ its host entry points)
     ]
 
 
@@ -94,13 +95,13 @@ def build_library(force=False, verbose=True):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     inc = ["-I", os.path.join(ROOT, "include")]
     jobs = []
-    for obj, src, deps in _units():
+    for obj, src, deps, extra in _units():
         out = os.path.join(OBJ_DIR, obj)
         stamp = out + ".sha256"
-        dep_hash = _hash_files(deps)
+        dep_hash = _hash_files(deps, " ".join(extra))
         fresh = (not force and os.path.exists(out) and os.path.exists(stamp) and open(stamp).read().strip() == dep_hash)
         if not fresh:
-            jobs.append((out, stamp, dep_hash, [hipcc] + FLAGS + inc + ["-c", src, "-o", out]))
+            jobs.append((out, stamp, dep_hash, [hipcc] + FLAGS + extra + inc + ["-c", src, "-o", out]))
 
     def compile_one(job):
         out, stamp, dep_hash, cmd = job
@@ -114,7 +115,7 @@ def build_library(force=False, verbose=True):
         list(ex.map(compile_one, jobs))
     idobj = os.path.join(OBJ_DIR, "psmf_buildid.o")
     _run([hipcc, "-O2", "-std=c++17", "-fPIC", "-x", "c++", f'-DPSMF_BUILD_ID="{want}"'] + inc + ["-c", os.path.join(CSRC, "psmf_buildid.cpp"), "-o", idobj], verbose)
-    objs = [os.path.join(OBJ_DIR, o) for o, _, _ in _units()] + [idobj]
+    objs = [os.path.join(OBJ_DIR, u[0]) for u in _units()] + [idobj]
     _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs + LINK, verbose)
     got = library_build_id()
     if got != want:

@@ -9,10 +9,11 @@
 // float64); host model rpsmf_amd/blocked.py; C is rounded to the storage type once
 // per block instead of once per step.
 //
-//   psmf_blk_gram<T>      K partials: row chunk staged in LDS as float64, 4 x 4 register tiles   (MFMA-free fp64)
-//   psmf_blk_reduce       fixed-order sum of the partials
-//   psmf_blk_filter<RPAD> the nb steps (one workgroup)
-//   psmf_blk_apply<T>     C <- Z A_nb (rounded once), y_hat_j = Z b_j
+//   psmf_blk_gram_mfma<T>   K partials on the f64 matrix cores (row chunk staged in LDS as float64)
+//   psmf_blk_reduce         fixed-order sum of the partials
+//   psmf_blk_filter<RPAD>   the nb steps (one workgroup): the general kernel; the role-specialised ones live in psmf_blk3/4/16/32.hip
+//   psmf_blk_apply_mfma<T>  C <- Z A_nb (rounded once), y_hat_j = Z b_j
+// (round 1's MFMA-free psmf_blk_gram / psmf_blk_apply and their switch PSMF_BLOCK_MFMA were removed in round 5)
 #pragma once
 #include "psmf_kernels.hip"
 #include "psmf_ns.hip"
@@ -182,53 +183,6 @@ __global__ void psmf_flag_wait_k(long long* flags, long long v, DevState* st) {
   }
 }
 
-// ------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(WG) void psmf_blk_gram(BlockParams b) {
-  constexpr int TR = 32;
-  __shared__ double sZ[TR][RB];
-  const StepParams& p = b.sp;
-  const int tid = threadIdx.x, ta = tid >> 4, tb = tid & 15;
-  const int r = p.r, rp = p.rp, dl = p.d_local;
-  const T* __restrict__ C = reinterpret_cast<const T*>(p.C);
-  const T* __restrict__ Y = reinterpret_cast<const T*>(p.Y) + (size_t)(b.k0 - p.series_t0) * dl;
-  double acc[4][4];
-#pragma unroll
-  for (int x = 0; x < 4; ++x)
-#pragma unroll
-    for (int y = 0; y < 4; ++y) acc[x][y] = 0.0;
-  const int row_begin = blockIdx.x * b.gram_rows;
-  const int row_end = min(row_begin + b.gram_rows, dl);
-  for (int base = row_begin; base < row_end; base += TR) {
-    __syncthreads();
-    // stage TR rows of Z as float64: columns [0, r) from C, [r, r + nb) from the series block, 0 beyond
-    for (int idx = tid; idx < TR * RB; idx += WG) {
-      const int col = idx / TR, rr = idx - col * TR;       // consecutive threads -> consecutive rows (Y is time-major)
-      const int row = min(base + rr, row_end - 1);
-      double v;
-      if (col < r) v = (double)C[(size_t)row * rp + col];
-      else if (col < r + b.nb) v = (double)Y[(size_t)(col - r) * dl + row];
-      else v = 0.0;
-      sZ[rr][col] = (base + rr < row_end) ? v : 0.0;
-    }
-    __syncthreads();
-#pragma unroll 4
-    for (int rr = 0; rr < TR; ++rr) {
-      double za[4], zb[4];
-#pragma unroll
-      for (int x = 0; x < 4; ++x) { za[x] = sZ[rr][4 * ta + x]; zb[x] = sZ[rr][4 * tb + x]; }
-#pragma unroll
-      for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int y = 0; y < 4; ++y) acc[x][y] += za[x] * zb[y];
-    }
-  }
-  double* out = b.Kpart + (size_t)blockIdx.x * RB * RB;
-#pragma unroll
-  for (int x = 0; x < 4; ++x)
-#pragma unroll
-    for (int y = 0; y < 4; ++y) out[(4 * ta + x) * RB + 4 * tb + y] = acc[x][y];
-}
 
 // ---- f64-MFMA versions of the two d-sized products of a block -------------------------------
 // K = Z^T Z with v_mfma_f64_16x16x4_f64: a tile of 32 rows of Z is staged in LDS as float64 (row
@@ -1231,55 +1185,5 @@ inline size_t blk_filter_lds_bytes() {
   return (doubles * 8 + 15) & ~(size_t)15;
 }
 
-// ------------------------------------------------------------------------------------------
-// C <- Z A_nb (one rounding to the storage type per block), y_hat_{k0+j} = Z b_j.  Thread per row,
-// the row of Z in registers (float64), the coefficient matrices broadcast from LDS.
-// ------------------------------------------------------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(WG) void psmf_blk_apply(BlockParams b) {
-  constexpr int RH = RM / 2;               // r <= 32
-  __shared__ double sA[RB * RH];           // RB x r
-  __shared__ double sB[RB * RB];           // nb x RB, stored [j][m]
-  const StepParams& p = b.sp;
-  const int r = p.r, rp = p.rp, dl = p.d_local, tid = threadIdx.x, nb = b.nb;
-  for (int idx = tid; idx < RB * r; idx += WG) sA[idx] = b.Acoef[idx];
-  for (int idx = tid; idx < nb * RB; idx += WG) sB[idx] = b.Bcoef[idx];
-  __syncthreads();
-  T* __restrict__ C = reinterpret_cast<T*>(p.C);
-  const T* __restrict__ Y = reinterpret_cast<const T*>(p.Y) + (size_t)(b.k0 - p.series_t0) * dl;
-  T* __restrict__ YP = p.store_yp ? reinterpret_cast<T*>(p.YP) + (size_t)(b.k0 - p.series_t0) * dl : nullptr;
-  for (int row = blockIdx.x * WG + tid; row < dl; row += gridDim.x * WG) {
-    // this row of Z in registers: zc = the C part (coefficients 0..r), zy = the series part (r..r+nb)
-    double zc[RH], zy[RB];
-#pragma unroll
-    for (int m = 0; m < RH; ++m) {
-      const double v = (double)C[(size_t)row * rp + min(m, r - 1)];     // unconditional load, masked
-      zc[m] = m < r ? v : 0.0;
-    }
-#pragma unroll
-    for (int q = 0; q < RB; ++q) {
-      const double v = (double)Y[(size_t)min(q, nb - 1) * dl + row];
-      zy[q] = q < nb ? v : 0.0;
-    }
-    for (int c = 0; c < r; ++c) {
-      double acc = 0.0;
-#pragma unroll
-      for (int m = 0; m < RH; ++m) acc += zc[m] * sA[min(m, r - 1) * r + c];          // zc[m >= r] = 0
-#pragma unroll
-      for (int q = 0; q < RB; ++q) acc += zy[q] * sA[min(r + q, RB - 1) * r + c];     // zy[q >= nb] = 0
-      C[(size_t)row * rp + c] = (T)acc;
-    }
-    if (YP) {
-      for (int jb = 0; jb < nb; ++jb) {
-        double acc = 0.0;
-#pragma unroll
-        for (int m = 0; m < RH; ++m) acc += zc[m] * sB[jb * RB + min(m, r - 1)];
-#pragma unroll
-        for (int q = 0; q < RB; ++q) acc += zy[q] * sB[jb * RB + min(r + q, RB - 1)];
-        YP[(size_t)jb * dl + row] = (T)acc;
-      }
-    }
-  }
-}
 
 }  // namespace psmf

@@ -49,8 +49,9 @@ constexpr int kGramWG = 128;
 // Environment switches ("Switches"): read ONCE per handle, at psmf_create -- tests flip them between
 // handles of one process; nothing on the per-block host path calls getenv.
 struct Switches {
-  bool block_mfma = true, bulk2 = true, filter3 = true, filter4 = true, filter6 = true, filter7 = true, filter6_dual = true, block_dual = true, block_flags = true, block_chain = true, block_pipe = true;
+  bool bulk2 = true, filter3 = true, filter4 = true, filter6 = true, filter7 = true, filter6_dual = true, block_dual = true, block_flags = true, block_chain = true, block_pipe = true;
   bool force_collective = false;
+  bool host_comm_flags = false;     // PSMF_HOST_COMM_FLAGS=1: device-flag hand-off (and chained filter launches) under a host-mediated communicator too
   bool serial_wide = true, step_dual = true;
   int sweep_threads = 512;
   double ns_far4 = 0.6;            // filter4 / filter4s: residual at which a Newton-Schulz start is given up (PSMF_NS_FAR4; PSMF_NS_FAR, when set, rules both)
@@ -58,9 +59,10 @@ struct Switches {
   bool step_persistent = true;      // per-step engine: one persistent launch per run (psmf_pstep.hip) where it applies; PSMF_STEP_PERSISTENT=0: two launches per timestep
   static bool off(const char* name) { const char* e = getenv(name); return e && atoi(e) == 0; }
   void read() {
-    block_mfma = !off("PSMF_BLOCK_MFMA"); bulk2 = !off("PSMF_BULK2"); filter3 = !off("PSMF_FILTER3"); filter4 = !off("PSMF_FILTER4"); filter6 = !off("PSMF_FILTER6"); filter7 = !off("PSMF_FILTER7"); filter6_dual = !off("PSMF_FILTER6_DUAL"); block_dual = !off("PSMF_BLOCK_DUAL");
+    bulk2 = !off("PSMF_BULK2"); filter3 = !off("PSMF_FILTER3"); filter4 = !off("PSMF_FILTER4"); filter6 = !off("PSMF_FILTER6"); filter7 = !off("PSMF_FILTER7"); filter6_dual = !off("PSMF_FILTER6_DUAL"); block_dual = !off("PSMF_BLOCK_DUAL");
     block_flags = !off("PSMF_BLOCK_FLAGS"); block_chain = !off("PSMF_BLOCK_CHAIN"); block_pipe = !off("PSMF_BLOCK_PIPE");
     force_collective = getenv("PSMF_FORCE_COLLECTIVE") != nullptr;
+    { const char* e = getenv("PSMF_HOST_COMM_FLAGS"); host_comm_flags = e && atoi(e) != 0; }
     step_persistent = !off("PSMF_STEP_PERSISTENT");
     serial_wide = !off("PSMF_SERIAL_WIDE"); step_dual = !off("PSMF_STEP_DUAL");
     { const char* e = getenv("PSMF_SWEEP_THREADS"); sweep_threads = (e && atoi(e) == 256) ? 256 : 512; }
@@ -291,26 +293,18 @@ void fill_block_params(psmf_filter* h, psmf::BlockParams& b, int64_t k0, int nb,
   b.gram_rows = (h->cfg.d_local + psmf::BLK_GRAM_WG - 1) / psmf::BLK_GRAM_WG;
 }
 
-bool blk_use_mfma(const psmf_filter* h) { return h->sw.block_mfma; }
-
 void launch_blk_gram(psmf_filter* h, const psmf::BlockParams& b, hipStream_t stream = nullptr) {
   if (!stream) stream = h->stream;
-  if (blk_use_mfma(h)) {
-    if (h->cfg.storage == PSMF_F64)
-      hipLaunchKernelGGL(psmf::psmf_blk_gram_mfma<double>, dim3(psmf::BLK_GRAM_WG), dim3(psmf::WG), 0, stream, b);
-    else
-      hipLaunchKernelGGL(psmf::psmf_blk_gram_mfma<float>, dim3(psmf::BLK_GRAM_WG), dim3(psmf::WG), 0, stream, b);
-  } else if (h->cfg.storage == PSMF_F64) {
-    hipLaunchKernelGGL(psmf::psmf_blk_gram<double>, dim3(psmf::BLK_GRAM_WG), dim3(psmf::WG), 0, stream, b);
-  } else {
-    hipLaunchKernelGGL(psmf::psmf_blk_gram<float>, dim3(psmf::BLK_GRAM_WG), dim3(psmf::WG), 0, stream, b);
-  }
+  if (h->cfg.storage == PSMF_F64)
+    hipLaunchKernelGGL(psmf::psmf_blk_gram_mfma<double>, dim3(psmf::BLK_GRAM_WG), dim3(psmf::WG), 0, stream, b);
+  else
+    hipLaunchKernelGGL(psmf::psmf_blk_gram_mfma<float>, dim3(psmf::BLK_GRAM_WG), dim3(psmf::WG), 0, stream, b);
   hipLaunchKernelGGL(psmf::psmf_blk_reduce, dim3(psmf::RB * psmf::RB / 128), dim3(128), 0, stream, b, (int)psmf::BLK_GRAM_WG);
 }
 
 // streaming bulk kernels (psmf_bulk.hip): float32 storage, d_local a multiple of 4, 16 <= r <= 32
 bool blk_bulk2_ok(const psmf_filter* h) {
-  return h->sw.bulk2 && blk_use_mfma(h) && h->cfg.storage == PSMF_F32 && (h->cfg.d_local % 4) == 0 && h->cfg.r <= 32 && (h->geo.rp % 4) == 0;
+  return h->sw.bulk2 && h->cfg.storage == PSMF_F32 && (h->cfg.d_local % 4) == 0 && h->cfg.r <= 32 && (h->geo.rp % 4) == 0;
 }
 
 void launch_blk_xgram(psmf_filter* h, const psmf::BlockParams& x, double* xg, hipStream_t stream) {
@@ -376,10 +370,12 @@ bool blk_simpl_ok(const psmf_filter* h) {
 enum FilterKernel { FK_STEP = 0, FK_GENERAL = 1, FK_FILTER2 = 2, FK_FILTER3 = 3, FK_FILTER3S = 4, FK_FILTER4 = 5, FK_FILTER4S = 6,
                     FK_FILTER5 = 7, FK_FILTER6 = 8, FK_FILTER6D = 9, FK_FILTER7 = 10, FK_PSTEP = 11 };
 
-// Can the handle's next run go through the persistent per-step kernel?  (one rank, uniform diagonal R, no mask, random walk or
-// cos-phase dynamics, r <= 32, rows that fit the row workgroups' registers; everything else keeps the two launches per timestep)
+// Can the handle's next run go through the persistent per-step kernel?  (one rank, uniform diagonal R, random walk or cos-phase
+// dynamics, r <= 32, rows that fit the row workgroups' registers, unmasked or the masked PSMF / rPSMF filter; everything else keeps
+// the two -- masked: three -- launches per timestep)
 bool pstep_usable(const psmf_filter* h) {
-  return h->engine == 1 && h->ps_ok && h->sw.step_persistent && !h->use_coll && !h->host_fn && !h->sp.rho_rows && !h->cfg.masked &&
+  return h->engine == 1 && h->ps_ok && h->sw.step_persistent && !h->use_coll && !h->host_fn && !h->sp.rho_rows &&
+         (h->cfg.masked == 0 || (h->cfg.masked == 1 && h->have_mask)) &&        // masked PSMF / rPSMF; MLE-SMF and TMF keep the two launches
          !h->cfg.nonuniform_R && h->cfg.dyn_kind <= PSMF_DYN_COS_PHASE && !h->sp.solve_lds;
 }
 
@@ -452,23 +448,14 @@ void launch_blk_apply(psmf_filter* h, const psmf::BlockParams& b, hipStream_t st
     else hipLaunchKernelGGL(psmf::psmf_blk_apply2<3>, dim3(h->bulk_wgs), dim3(psmf::BK_NT), lds, stream, b);
     return;
   }
-  if (blk_use_mfma(h)) {
-    const int nslab = (h->cfg.d_local + 15) / 16;
-    int g = (nslab + 3) / 4;
-    if (g > 1024) g = 1024;
-    const size_t lds = psmf::blk_apply_lds_bytes();
-    if (h->cfg.storage == PSMF_F64)
-      hipLaunchKernelGGL(psmf::psmf_blk_apply_mfma<double>, dim3(g), dim3(psmf::WG), lds, stream, b);
-    else
-      hipLaunchKernelGGL(psmf::psmf_blk_apply_mfma<float>, dim3(g), dim3(psmf::WG), lds, stream, b);
-    return;
-  }
-  int grid = (h->cfg.d_local + psmf::WG - 1) / psmf::WG;
-  if (grid > 1024) grid = 1024;
+  const int nslab = (h->cfg.d_local + 15) / 16;
+  int g = (nslab + 3) / 4;
+  if (g > 1024) g = 1024;
+  const size_t lds = psmf::blk_apply_lds_bytes();
   if (h->cfg.storage == PSMF_F64)
-    hipLaunchKernelGGL(psmf::psmf_blk_apply<double>, dim3(grid), dim3(psmf::WG), 0, stream, b);
+    hipLaunchKernelGGL(psmf::psmf_blk_apply_mfma<double>, dim3(g), dim3(psmf::WG), lds, stream, b);
   else
-    hipLaunchKernelGGL(psmf::psmf_blk_apply<float>, dim3(grid), dim3(psmf::WG), 0, stream, b);
+    hipLaunchKernelGGL(psmf::psmf_blk_apply_mfma<float>, dim3(g), dim3(psmf::WG), lds, stream, b);
 }
 
 int enqueue_block(psmf_filter* h, int64_t k0, int nb) {
@@ -511,8 +498,9 @@ int enqueue_blocks_pipelined(psmf_filter* h, int64_t k_begin, int64_t k_end) {
   const bool flags_off = !h->sw.block_flags;
   // (a tool that serialises dispatches: events.  A host-mediated communicator synchronises the bulk stream at every exchange
   //  anyway, and several such handles usually share one process and one GPU -- shards of a test -- where kernels that spin on
-  //  flags could end up behind each other in a shared hardware queue: events there, too)
-  const bool use_flags = h->fstream != nullptr && h->flags != nullptr && !flags_off && h->streams_concurrent && !h->host_fn;
+  //  flags could end up behind each other in a shared hardware queue: events there, too -- unless PSMF_HOST_COMM_FLAGS=1 asks for the
+  //  flags, which is how tests/test_hip_multishard.py runs the flag hand-off and the chained launch with more than one shard)
+  const bool use_flags = h->fstream != nullptr && h->flags != nullptr && !flags_off && h->streams_concurrent && (!h->host_fn || h->sw.host_comm_flags);
   const long long s0 = h->seq_next;
   h->seq_next += nblk;
   // chain: the filter kernels of the whole run as ONE launch (psmf_blk_filter3; the bulk stream is driven as before)
@@ -779,6 +767,18 @@ int launch_pstep(psmf_filter* h, int64_t k_begin, int64_t n) {
     q.flags = reinterpret_cast<unsigned*>(h->ps_comm);
     q.pkt = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(h->ps_comm) + h->ps_plan.off_pkt);
     q.part = reinterpret_cast<double*>(reinterpret_cast<char*>(h->ps_comm) + h->ps_plan.off_part);
+    if (h->cfg.masked) {
+      char* base = reinterpret_cast<char*>(h->ps_comm);
+      q.masked = 1;
+      q.nge = h->ps_plan.nge;
+      q.slice_len = h->ps_plan.slice_len;
+      q.gflags = reinterpret_cast<unsigned*>(base + h->ps_plan.off_gflags);
+      q.sflags = reinterpret_cast<unsigned*>(base + h->ps_plan.off_sflags);
+      q.gpart = reinterpret_cast<double*>(base + h->ps_plan.off_gpart);
+      q.gslice = reinterpret_cast<double*>(base + h->ps_plan.off_gslice);
+      q.mg_out = h->mg;
+      q.mg_ntr = h->sp.mg_ntr;
+    }
     q.prof = h->ps_prof;
     h->ps_prof_steps = chunk;
     std::lock_guard<std::mutex> lock(g_ps_mutex);
@@ -969,7 +969,12 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
       CREATE_TRY(hipGetDeviceProperties(&prop, cfg->device));
       const int ncu = prop.multiProcessorCount;
       const int words = (ncu + 31) / 32;
-      if (nres > 0 && nres < ncu / 2 && words <= 16) {
+      // The split below is written for the unpartitioned MI355X: 256 CUs = 8 XCDs x 4 shader engines x 8 CUs, mask bit =
+      // 32 cu + 8 se + xcc (tools/xcc_probe.hip).  On any other device (a CPX / NPS partition, another part) the bit layout and the
+      // engine count are not known here: no CU masks, plain streams -- the filter chain then shares CUs with the bulk kernels
+      // (10-17 % slower, measured), which is a speed matter only.
+      const bool known_layout = ncu == 256;
+      if (known_layout && nres > 0 && nres < ncu / 2 && words <= 16) {
         uint32_t mf[16] = {0}, mb[16] = {0};
         for (int i = 0; i < ncu; ++i) (i < nres ? mf : mb)[i >> 5] |= 1u << (i & 31);
         hipStream_t fs = nullptr, bs = nullptr;
@@ -1009,6 +1014,7 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
       // the device-flag hand-off and the chained filter launches need the two streams to run concurrently: probe it (a waiter on the filter stream, then the
       // setter on the bulk stream; the waiter gives up after 50 ms)
       int* dres = nullptr;
+      struct FreeOnExit { int** p; ~FreeOnExit() { if (*p) { hipFree(*p); *p = nullptr; } } } dres_guard{&dres};      // also on the CREATE_TRY failure paths below
       CREATE_TRY(hipMalloc((void**)&dres, sizeof(int)));
       CREATE_TRY(hipMemset(dres, 0, sizeof(int)));
       CREATE_TRY(hipDeviceSynchronize());      // hipMemset is asynchronous on the null stream, the probe's streams are non-blocking: the zeroes (of dres and of h->flags above) first
@@ -1018,7 +1024,6 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
       CREATE_TRY(hipStreamSynchronize(h->bulk));
       int res = 0;
       CREATE_TRY(hipMemcpy(&res, dres, sizeof(int), hipMemcpyDeviceToHost));
-      hipFree(dres);
       h->streams_concurrent = res == 1;
     }
     const size_t flds = psmf::blk_filter_lds_bytes();
@@ -1047,10 +1052,10 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
   }
   if (h->geo.sweep_lds > 48 * 1024)
     CREATE_TRY(hipFuncSetAttribute((const void*)sweep_kernel(h), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->geo.sweep_lds));
-  if (h->engine == 1 && h->sw.step_persistent && cfg->r <= 32 && !cfg->masked && !cfg->nonuniform_R && cfg->dyn_kind <= PSMF_DYN_COS_PHASE) {
+  if (h->engine == 1 && h->sw.step_persistent && cfg->r <= 32 && cfg->masked <= 1 && !cfg->nonuniform_R && cfg->dyn_kind <= PSMF_DYN_COS_PHASE) {
     hipDeviceProp_t prop;
     CREATE_TRY(hipGetDeviceProperties(&prop, cfg->device));
-    if (psmf::pstep_plan(cfg->d_local, cfg->r, prop.multiProcessorCount, cfg->storage == PSMF_F64, &h->ps_plan)) {
+    if (psmf::pstep_plan(cfg->d_local, cfg->r, prop.multiProcessorCount, cfg->storage == PSMF_F64, cfg->masked == 1, &h->ps_plan)) {
       CREATE_TRY(psmf::pstep_init());
       CREATE_TRY(hipMalloc(&h->ps_comm, h->ps_plan.total_bytes));
       CREATE_TRY(hipMemset(h->ps_comm, 0, h->ps_plan.total_bytes));

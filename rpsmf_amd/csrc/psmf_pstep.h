@@ -4,10 +4,10 @@
 
 namespace psmf {
 
-constexpr int PSTEP_NT = 512;        // threads per workgroup (8 waves), every workgroup of the launch
 constexpr int PSTEP_NPMAX = 12;      // row passes a row workgroup can keep in registers (4 float64 per lane and pass; y_k beside them)
-constexpr int PSTEP_NPMAX_F64 = 12;  // ... with float64 storage (y_k takes two registers per pass)
+constexpr int PSTEP_NPMAX_BIG = 32;  // ... of the 256-thread instances (r > 32: 16 rows per pass, 512 registers per wave)
 constexpr int PSTEP_PKT_MAX = 4 * RM + 1;      // granules of the hub -> rows packet
+constexpr int PSTEP_FANIN_ROWS = 12;           // partial rows one thread of the hub's fan-in sums (all its loads in flight at once)
 
 struct PstepParams {
   StepParams sp;               // the handle's parameter block
@@ -20,6 +20,16 @@ struct PstepParams {
   unsigned* flags;             // rows -> hub: one epoch word per row workgroup        } one block, zeroed before every launch
   unsigned long long* pkt;     // hub -> rows: PSTEP_PKT_MAX {tag, value} granules      }
   double* part;                // rows -> hub: n_row_wg x ncol2 partial sums (write-through stores)
+  // masked handles (cfg.masked = 1, PSMF / rPSMF): the masked Gram of the NEXT step travels rows -> rows -> hub every timestep
+  int masked;                  // 1: sp.mask is the observation mask; G_m = sum_i m_i c_i c_i^T is formed per step from the on-chip C
+  int nge;                     // elements of a Gram partial: upper 16 x 16 tiles in the MFMA layout (256 each) + the observed count
+  int slice_len;               // elements of the reduced Gram one row workgroup sums over all partials (ceil(nge / n_row_wg))
+  unsigned* gflags;            // rows -> rows: partial Gram of the epoch published       } in the zeroed block
+  unsigned* sflags;            // rows -> hub: slice of the reduced Gram published        }
+  double* gpart;               // n_row_wg x nge
+  double* gslice;              // n_row_wg x slice_len (>= nge, contiguous: element e at gslice[e])
+  double* mg_out;              // the handle's reduced-Gram buffer (r*r + 1 | trace shares): what a launch leaves for the next one
+  int mg_ntr;
   long long* prof;             // diagnostic builds (-DPSTEP_PROF): per-phase shader-clock sums, [0..15] hub workers, [16..23] solve wave, [24..31] row workgroup 1
 };
 
@@ -27,10 +37,12 @@ struct PstepPlan {
   int n_row_wg, rows_per_wg, np, ncol2;
   size_t zero_bytes;           // flags + packet: the block a launch zeroes (starts the allocation, multiple of 16 bytes)
   size_t off_pkt, off_part, total_bytes;
+  int nge, slice_len;          // masked handles (0 otherwise)
+  size_t off_gflags, off_sflags, off_gpart, off_gslice;
 };
 
 // geometry of a launch for d_local rows at rank r on a device with n_cu compute units; false: the shape does not fit the kernel
-bool pstep_plan(int d_local, int r, int n_cu, bool storage_f64, PstepPlan* out);
+bool pstep_plan(int d_local, int r, int n_cu, bool storage_f64, bool masked, PstepPlan* out);
 // one launch = n_steps timesteps (the communication block must have been zeroed on the same stream)
 hipError_t pstep_launch(const PstepParams& q, bool storage_f64, hipStream_t stream);
 // one-off per process: dynamic-LDS attribute of every instance

@@ -37,7 +37,7 @@ constexpr unsigned PSTEP_ABORT_TAG = 0xFFFFFFFFu;
 
 // sum over the GS lanes (GS = 2 .. 16, aligned group) that share a row; every lane of the group gets the sum
 template <int GS>
-__device__ __forceinline__ double group_sum(double v) {
+__device__ __forceinline__ double group_sum(double v) {      // (GS = 1: nothing to add)
   if (GS >= 2) v += PS_DPP64(v, 0xB1);     // quad_perm [1,0,3,2]
   if (GS >= 4) v += PS_DPP64(v, 0x4E);     // quad_perm [2,3,0,1]
   if (GS >= 8) v += PS_DPP64(v, 0x141);    // row_half_mirror
@@ -103,12 +103,27 @@ __device__ __forceinline__ u64 gran_load(const u64* g) { return __hip_atomic_loa
 __device__ __forceinline__ void wt_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ double wt_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
+// 16-byte write-through-coherent load (buffer_load_dwordx4 ... sc1 through a raw buffer resource: aux bit 4 = sc1): the hub reads
+// the row workgroups' partial sums two doubles at a time (8-byte sc1 accesses run at 0.54-0.70 x the 16-byte rate).  The builtin, not
+// inline asm: the compiler tracks the load's wait count, so a spill of the destination registers lands behind the data.  (An inline
+// asm global_load is invisible to that tracking -- with 256 registers in use hipcc spilled the destinations BEFORE the hand-written
+// wait, and the fan-in summed stale scratch: found on the masked r = 32 instances.)
+typedef unsigned ps_u32x4 __attribute__((ext_vector_type(4)));
+struct ps_f64pair { double x, y; };
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t wt_rsrc(const void* base, const unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ ps_f64pair wt_load2(const __amdgpu_buffer_rsrc_t rs, const int byte_off) {
+  const ps_u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, byte_off, 0, 16);
+  return ps_f64pair{__hiloint2double((int)v[1], (int)v[0]), __hiloint2double((int)v[3], (int)v[2])};
+}
+
 __device__ __forceinline__ int lds_word(const volatile int* p) { return *p; }
 
 // ------------------------------------------------------------------------------------------------------------
 // ROW workgroup
 // ------------------------------------------------------------------------------------------------------------
-template <typename T, int RPAD, int NT, int NPMAX>
+template <typename T, int RPAD, int NT, int NPMAX, bool MASKED>
 __device__ __forceinline__ void pstep_rows(const PstepParams& q, char* smem) {
   constexpr int GS = RPAD / 4;               // lanes per row; a lane owns 4 consecutive columns
   constexpr int RPW = NT / GS;               // rows per pass of the workgroup
@@ -161,6 +176,30 @@ __device__ __forceinline__ void pstep_rows(const PstepParams& q, char* smem) {
   for (int ps = 0; ps < NPMAX; ++ps) {
     ycur[ps] = Yg[(size_t)t_first * dl + min(row_begin + ps * RPW + g, row_end - 1)];
   }
+  // masked handles: the observation mask of the current step (e) and of the next (its Gram is formed one step ahead), one bit per pass
+  constexpr int NTG = RPAD > 16 ? 2 : 1;                 // 16-column tiles of the masked Gram
+  constexpr int NTT = NTG * (NTG + 1) / 2;               // ... upper tiles
+  constexpr int SG = NTG == 1 ? 16 : 48;                 // row stride of a wave's slab (16 mod 32: conflict-free operand reads)
+  constexpr int RW = 64 / GS;                            // rows of a pass held by one wave
+  constexpr int NSLAB = NPMAX * RW / 16;                 // 16-row slabs of a wave
+  double* s_slab = reinterpret_cast<double*>(smem + 8192);                       // NW x 16 x SG  | later NW x NTT x 256 (wave sums)
+  double* s_rs = reinterpret_cast<double*>(smem + 8192 + NW * NTT * 256 * 8);    // reduce-scatter staging: [element][source] (<= nge + n_row_wg)
+  double* s_cnt = s_rs + 1280;
+  const uint8_t* __restrict__ Mg = p.mask;
+  auto mask_bits = [&](long long trow) -> unsigned {
+    unsigned b = 0;
+    if constexpr (MASKED) {
+      if (trow > (long long)p.mask_rows - 1) trow = (long long)p.mask_rows - 1;      // (the step after the last: formed, never used)
+      const uint8_t* mk = Mg + (size_t)trow * dl;
+#pragma unroll
+      for (int ps = 0; ps < NPMAX; ++ps) b |= (mk[min(row_begin + ps * RPW + g, row_end - 1)] != 0 ? 1u : 0u) << ps;
+    }
+    return b;
+  };
+  unsigned mcur = mask_bits(t_first), mnext = mask_bits(t_first + 1);
+  if constexpr (MASKED) {
+    for (int idx = tid; idx < NW * 16 * SG; idx += NT) s_slab[idx] = 0.0;      // columns beyond 4 GS of a slab stay zero
+  }
   ps_bar();
   PS_PROF_DECL(8);
   PS_PROF_START();
@@ -204,7 +243,7 @@ __device__ __forceinline__ void pstep_rows(const PstepParams& q, char* smem) {
     for (int v = 0; v < 4; ++v) { mub[v] = s_mub[4 * j + v]; wn[v] = s_wn[4 * j + v]; }
     const long long t = t_first + s;
     const bool more = s + 1 < q.n_steps;
-    const T* __restrict__ ynx = Yg + (size_t)(t + (more ? 1 : 0)) * dl;      // next step's y: loaded behind each pass's use of this step's
+    const T* __restrict__ ynx = Yg + (size_t)(t + (more ? 1 : 0)) * dl;      // next step's y
     T* __restrict__ yp = YPg ? YPg + (size_t)t * dl : nullptr;
     double hacc[4] = {0.0, 0.0, 0.0, 0.0};
     double eacc = 0.0;
@@ -214,9 +253,9 @@ __device__ __forceinline__ void pstep_rows(const PstepParams& q, char* smem) {
         double dot = (c[ps][0] * mub[0] + c[ps][1] * mub[1]) + (c[ps][2] * mub[2] + c[ps][3] * mub[3]);
         dot = group_sum<GS>(dot);
         const bool ok = (okmask >> ps) & 1u;
-        const double e = ok ? (double)ycur[ps] - dot : 0.0;
-        ycur[ps] = ynx[min(row_begin + ps * RPW + g, row_end - 1)];
-        if (yp && ok && j == 0) yp[row_begin + ps * RPW + g] = (T)dot;
+        const bool obs = ok && (!MASKED || ((mcur >> ps) & 1u));       // rows with m_i = 0: no residual, no update (y_hat stored all the same)
+        const double e = obs ? (double)ycur[ps] - dot : 0.0;
+        ycur[ps] = (T)dot;       // y_hat of the row: stored behind the hand-off below (no global memory traffic inside the passes)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
           hacc[v] = fma(c[ps][v], e, hacc[v]);
@@ -256,6 +295,130 @@ __device__ __forceinline__ void pstep_rows(const PstepParams& q, char* smem) {
       if (lane == 0) __hip_atomic_store(q.flags + wg, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     PS_PROF(4);      // partial row out, drained, flag
+    if constexpr (MASKED) {
+      // ---------- masked Gram of the NEXT step from the updated rows: G_m = sum_i m_i c_i c_i^T (m of step k + 1) ----------
+      // every wave by itself: 16-row slabs of its own rows (zeros where m_i = 0) in a wave-private LDS image, the upper 16 x 16 tiles
+      // on the f64 matrix cores (psmf_masked.hip: mgram_body, with the rows coming from registers instead of HBM)
+      f64x4 acc[NTT];
+#pragma unroll
+      for (int t_ = 0; t_ < NTT; ++t_) acc[t_] = f64x4{0.0, 0.0, 0.0, 0.0};
+      double* slab = s_slab + wv * 16 * SG;
+      const int gl = lane / GS, lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+      for (int sb = 0; sb < NSLAB; ++sb) {
+#pragma unroll
+        for (int ps = 0; ps < NPMAX; ++ps) {
+          if ((ps * RW) / 16 <= sb && sb <= (ps * RW + RW - 1) / 16) {      // (compile time) pass ps has rows in slab sb
+            const int rr = ps * RW + gl;
+            if (rr / 16 == sb) {
+              const bool on = ((mnext & okmask) >> ps) & 1u;
+              double* dstl = slab + (rr & 15) * SG + 4 * j;
+              *reinterpret_cast<double2*>(dstl) = make_double2(on ? c[ps][0] : 0.0, on ? c[ps][1] : 0.0);
+              *reinterpret_cast<double2*>(dstl + 2) = make_double2(on ? c[ps][2] : 0.0, on ? c[ps][3] : 0.0);
+            }
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) {
+          double a[NTG];
+#pragma unroll
+          for (int t_ = 0; t_ < NTG; ++t_) a[t_] = slab[(4 * qq + lk) * SG + 16 * t_ + lr];
+          int tt = 0;
+#pragma unroll
+          for (int ta = 0; ta < NTG; ++ta)
+#pragma unroll
+            for (int tb = ta; tb < NTG; ++tb, ++tt) acc[tt] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ta], a[tb], acc[tt], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();        // every lane has read the image before the next slab overwrites it
+      }
+      double cnt = j == 0 ? (double)__builtin_popcount(mnext & okmask) : 0.0;
+      cnt = cross_sum<GS>(cnt);
+      ps_bar();                                  // the slabs are done: their memory takes the waves' tiles
+#pragma unroll
+      for (int tt = 0; tt < NTT; ++tt)
+#pragma unroll
+        for (int qq = 0; qq < 4; ++qq) s_slab[(wv * NTT + tt) * 256 + qq * 64 + lane] = acc[tt][qq];
+      if (lane == 0) s_cnt[wv] = cnt;
+      ps_bar();
+      {
+        double* gdst = q.gpart + (size_t)wg * q.nge;
+        for (int idx = tid; idx < NTT * 256; idx += NT) {
+          double a = 0.0;
+#pragma unroll
+          for (int w = 0; w < NW; ++w) a += s_slab[w * NTT * 256 + idx];      // fixed order
+          wt_store(gdst + idx, a);
+        }
+        if (tid == 0) {
+          double a = 0.0;
+#pragma unroll
+          for (int w = 0; w < NW; ++w) a += s_cnt[w];
+          wt_store(gdst + NTT * 256, a);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // EVERY storing wave, then the barrier, then one flag
+      ps_bar();
+      if (tid == 0) __hip_atomic_store(q.gflags + wg, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // ---------- reduce-scatter: this workgroup sums ITS elements of the Gram over all workgroups' partials (fixed order) ----------
+      const int nwg = q.n_row_wg, SL = q.slice_len, e0 = wg * SL;
+      const int nmine = max(0, min(SL, q.nge - e0));
+      if (wv == 0) {
+        const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+        int stop = 0;
+        for (;;) {
+          bool ok = true;
+          for (int b = lane; b < nwg; b += 64) ok &= __hip_atomic_load(q.gflags + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= epoch;
+          if (__all((int)ok)) break;
+          __builtin_amdgcn_s_sleep(1);
+          if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > PSTEP_SPIN_TICKS) { stop = 2; break; }
+        }
+        if (lane == 0 && stop) s_ctl[0] = stop;
+      }
+      ps_bar();
+      if (lds_word(s_ctl) != 0) break;
+      for (int item = tid; item < nwg * nmine; item += NT) {
+        const int src = item / nmine, el = item - src * nmine;
+        s_rs[el * nwg + src] = wt_load(q.gpart + (size_t)src * q.nge + e0 + el);
+      }
+      ps_bar();
+      if (8 * nmine <= NT) {       // eight lanes per element, then the eight
+        const int el = tid >> 3, u = tid & 7;
+        double a = 0.0;
+        if (el < nmine) {
+          const double* rowp = s_rs + el * nwg;
+          for (int s0 = u; s0 < nwg; s0 += 32) {
+            double v4[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v4[k] = rowp[min(s0 + 8 * k, nwg - 1)];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) a += (s0 + 8 * k < nwg) ? v4[k] : 0.0;
+          }
+        }
+        a = group_sum<8>(a);
+        if (el < nmine && u == 0) wt_store(q.gslice + e0 + el, a);
+      } else {                     // few workgroups, long slices: one lane per element
+        for (int el = tid; el < nmine; el += NT) {
+          double a = 0.0;
+          for (int src = 0; src < nwg; ++src) a += s_rs[el * nwg + src];
+          wt_store(q.gslice + e0 + el, a);
+        }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      ps_bar();
+      if (tid == 0) __hip_atomic_store(q.sflags + wg, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      mcur = mnext;
+      mnext = mask_bits(t + 2);
+    }
+    // y_hat out and the next step's y in, BEHIND the hand-off: the drain above waits for every vector-memory operation of wave 0, and
+    // a y load from HBM issued inside the passes would have been the longest of them
+#pragma unroll
+    for (int ps = 0; ps < NPMAX; ++ps) {
+      const int row = row_begin + ps * RPW + g;
+      if (yp && ((okmask >> ps) & 1u) && j == 0) yp[row] = ycur[ps];
+      ycur[ps] = ynx[min(row, row_end - 1)];
+    }
     // (no barrier: wave 0 rewrites s_pkt32 only after every wave has passed the barrier above, behind its own reads of it;
     //  s_red is rewritten behind the next step's first barrier, which wave 0 reaches after reading it)
   }
@@ -345,8 +508,9 @@ __device__ __forceinline__ void hub_col_reduce(const bool worker, const double p
   ps_bar();
 }
 
-template <int RPAD, int NT>
+template <int RPAD, int NT, bool MASKED>
 __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
+  constexpr bool SHARED = NT == 256;         // r > 32: 256-thread workgroups (a wave may hold 512 registers); all four waves are workers, the last two ALSO run the inversions
   constexpr int NWK = 256;                   // worker threads: waves 0-3
   constexpr int NW = NT / 64;
   constexpr int RG = NWK / RPAD;
@@ -354,7 +518,8 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
   constexpr int LS = RPAD + 1;               // row stride of the r x r LDS images
   constexpr int NG = 4 * RPAD + 1;
   constexpr int NFT = (NW - 2) * 64;         // threads of the fan-in (waves 0 .. NW-3)
-  constexpr int LPC = RPAD > 32 ? 4 : 8;     // lanes per column of the fan-in's second level (LPC x (r + 1) <= NFT)
+  constexpr int NLT = SHARED ? NT : NT - 128; // threads that run the worker loop (the two solve waves have a loop of their own)
+  constexpr int LPC = NT >= 512 ? 8 : 1;     // lanes per column of the fan-in's second level (LPC x (r + 1) <= NFT)
   const StepParams& p = q.sp;
   DevState* st = p.st;
   const int r = p.r, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -378,6 +543,16 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
   double* s4 = s_wn + RM;                    // 8
   double* s_sc = s4 + 8;                     // [0] kappa, [1] 1 / q, [2] 1 / beta (solve operands)
   int* s_ctl = reinterpret_cast<int*>(s_sc + 8);      // [0] stop, [1] fan-in epoch seen by wave 0, [2] bad pivot, [3] carried
+  double* s_gm = s_sc + 16;                  // masked handles: the reduced Gram of the next step, upper tiles in the MFMA layout | observed count
+  constexpr int NTG = RPAD > 16 ? 2 : 1;
+  constexpr int NTT = NTG * (NTG + 1) / 2;
+  // element (i, c) of the symmetric Gram in s_gm (tiles (ta, tb), ta <= tb; lane = 16 (row & 3) + column, register = (row & 15) >> 2)
+  auto gm_index = [](int i, int cI) -> int {
+    if ((i >> 4) > (cI >> 4)) { const int t_ = i; i = cI; cI = t_; }
+    const int tt = NTG == 1 ? 0 : ((i >> 4) == 0 ? (cI >> 4) : 2);
+    const int i16 = i & 15, c16 = cI & 15;
+    return tt * 256 + (i16 >> 2) * 64 + (i16 & 3) * 16 + c16;
+  };
 
   // ---------------- the state the two-launch engine left in DevState ----------------
   const bool dual = p.solve_dual != 0;
@@ -405,6 +580,24 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
   double rho = st->rho, lam = st->lam;
   double N0 = st->N, kappa0 = st->kappa, s0 = st->s, eta0 = st->eta;
   long long k0 = st->k;
+  double nobs = 0.0;
+  if constexpr (MASKED) {
+    // masked handle: G is the masked Gram of the CURRENT step, reduced by the previous launch (psmf_mgram_reduce or this kernel) into
+    // the handle's buffer with the shares of <G_m, Pbar>; eta, N, kappa of the step are formed from it (ExperimentImpute/PSMF.py:77-78)
+    const double* mgp = q.mg_out;
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const double a = mgp[val[m] ? ii[m] * r + j : 0], b = mgp[val[m] ? j * r + ii[m] : 0];
+      Gv[m] = val[m] ? 0.5 * (a + b) : 0.0;
+      if (val[m]) sG[ii[m] * LS + j] = Gv[m];
+    }
+    nobs = mgp[r * r];
+    double tr = 0.0;
+    for (int w = 0; w < q.mg_ntr; ++w) tr += mgp[r * r + 2 + w];
+    eta0 = (rho * nobs + tr) / dd;
+    N0 = s0 + eta0;
+    kappa0 = fast_rcp(rho + s0);
+  }
   const bool vl = tid < r;
   const bool tl = tid < p.n_theta && p.dyn_kind == 1;
   const int tc = tid & (RM - 1);
@@ -418,7 +611,8 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
   double am = tl ? l_am : 0.0;
   double av = tl ? l_av : 0.0;
   double phi = 1.0, omega = 1.0, ee_last = 0.0, s_done = s0, eta_done = eta0, N_done = N0;
-  if (tid < RM) { s_w[tid] = vl ? l_w : 0.0; s_mub[tid] = vl ? l_mub : 0.0; s_wn[tid] = vl ? l_wn : 0.0; s_f[tid] = 0.0; s_vec[tid] = 0.0; }
+  if (tid < RM) { s_w[tid] = vl ? l_w : 0.0; s_mub[tid] = vl ? l_mub : 0.0; s_wn[tid] = vl ? (MASKED ? l_w * fast_rcp(N0) : l_wn) : 0.0; s_f[tid] = 0.0; s_vec[tid] = 0.0; }
+  if (MASKED && tid == 0 && p.sc_hist) { p.sc_hist[2 * (k0 - p.series_t0)] = s0; p.sc_hist[2 * (k0 - p.series_t0) + 1] = eta0; }
   if (tid < 2 * (RM + 1)) s_he[tid] = 0.0;
   if (tid == 0) {
     s_ctl[0] = 0; s_ctl[1] = 0; s_ctl[2] = 0;
@@ -428,11 +622,11 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
   }
   ps_bar();
   // packet of the launch's first step
-  if (tid < NG) {
-    const int e = tid >> 1;
-    const double v = tid == NG - 1 ? 0.0 : (e < RPAD ? s_mub[e] : s_wn[e - RPAD]);
-    const unsigned half = tid == NG - 1 ? 0u : ((tid & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v));
-    gran_store(q.pkt + tid, 1u, half);
+  for (int gI = tid; gI < NG; gI += NT) {
+    const int e = gI >> 1;
+    const double v = gI == NG - 1 ? 0.0 : (e < RPAD ? s_mub[e] : s_wn[e - RPAD]);
+    const unsigned half = gI == NG - 1 ? 0u : ((gI & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v));
+    gran_store(q.pkt + gI, 1u, half);
   }
 
   // fan-in geometry: thread t of waves 0 .. NW-3 sums elements (2 pi, 2 pi + 1) of the partial rows seg, seg + S, ...
@@ -443,7 +637,7 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
 
   // ---- the solve waves run a loop of their own (same barriers, none of the workers' registers): the kernel's register allocation
   //      is the larger of the two roles, not their sum ----
-  if (wv >= NW - 2) {
+  if (!SHARED && wv >= NW - 2) {
     PS_PROF_DECL(8);
     PS_PROF_START();
     for (int s = 0; s < q.n_steps; ++s) {
@@ -462,7 +656,13 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
       if (p.coef_update) { ps_bar(); ps_bar(); }
       ps_bar();
       ps_bar(); ps_bar();
-      if (p.eta_full) ps_bar();
+      if constexpr (MASKED) {                                     // the Gram hand-off of the next step: three barriers, one exit
+        ps_bar();
+        if (lds_word(s_ctl) != 0) break;
+        ps_bar(); ps_bar();
+      } else {
+        if (p.eta_full) ps_bar();
+      }
       ps_bar();
       carried = dual;
       PS_PROF(2);                                                 // the workers' phase B
@@ -477,7 +677,15 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
   for (int s = 0; s < q.n_steps; ++s) {
     const unsigned epoch = (unsigned)s + 1u;
     // =========================== phase A: the fan-in (beside the solve waves' inversions) ===========================
-    {
+    if (SHARED && wv >= NW - 2) {
+      if (p.coef_update) {      // (r > 32: these waves are workers too and run the inversions of the step here)
+        const int role = wv - (NW - 2);
+        if constexpr (RPAD <= 16) hub_solve<1>(role, dual, carried, r, s_sc[0], s_sc[1], s_sc[2], sL, sG, sPp, sW, LS, s_ctl + 2);
+        else if constexpr (RPAD == 32) hub_solve<2>(role, dual, carried, r, s_sc[0], s_sc[1], s_sc[2], sL, sG, sPp, sW, LS, s_ctl + 2);
+        else if (r <= 48) hub_solve<3>(role, dual, carried, r, s_sc[0], s_sc[1], s_sc[2], sL, sG, sPp, sW, LS, s_ctl + 2);
+        else hub_solve<4>(role, dual, carried, r, s_sc[0], s_sc[1], s_sc[2], sL, sG, sPp, sW, LS, s_ctl + 2);
+      }
+    } else {
       if (wv == 0) {
         const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
         int stop = 0;
@@ -499,21 +707,17 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
       PS_PROF(0);      // flags of all row workgroups seen
       if (f_on && lds_word(s_ctl) == 0) {
         double a0 = 0.0, a1 = 0.0;
-        const double* base = q.part + 2 * f_pi;
-        for (int row0 = f_seg; row0 < nwg; row0 += 4 * S) {
-          double x0[4], x1[4];
+        // every load of the thread in flight at once: ONE memory round trip (rows f_seg, f_seg + S, ...: at most PSTEP_FANIN_ROWS of them,
+        // which pstep_plan guarantees), summed in fixed order
+        ps_f64pair x[PSTEP_FANIN_ROWS];
+        const __amdgpu_buffer_rsrc_t rs = wt_rsrc(q.part, (unsigned)nwg * (unsigned)ncol2 * 8u);
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int row = min(row0 + u * S, nwg - 1);
-            x0[u] = wt_load(base + (size_t)row * ncol2);
-            x1[u] = wt_load(base + (size_t)row * ncol2 + 1);
-          }
+        for (int u = 0; u < PSTEP_FANIN_ROWS; ++u) x[u] = wt_load2(rs, (min(f_seg + u * S, nwg - 1) * ncol2 + 2 * f_pi) * 8);
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const bool in = row0 + u * S < nwg;
-            a0 += in ? x0[u] : 0.0;
-            a1 += in ? x1[u] : 0.0;
-          }
+        for (int u = 0; u < PSTEP_FANIN_ROWS; ++u) {
+          const bool in = f_seg + u * S < nwg;
+          a0 += in ? x[u].x : 0.0;
+          a1 += in ? x[u].y : 0.0;
         }
         s_seg[f_seg * ncol2 + 2 * f_pi] = a0;
         s_seg[f_seg * ncol2 + 2 * f_pi + 1] = a1;
@@ -645,13 +849,49 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
         const double pb = p.pbar_predict ? s_f[ii[m]] * Pv[m] * s_f[j] + qs * Qv[m] : Pv[m];
         Pbv[m] = pb;
         part += Vv[m] * s_mub[ii[m]];
-        gp += Gv[m] * pb;
+        if (!MASKED) gp += Gv[m] * pb;
       }
     }
     hub_col_reduce<RPAD, NWK>(worker, part, s_red, s_vec);        // s_vec = V mu_bar
     const double sN = ps_wave_sum(lane < r ? s_mub[lane] * s_vec[lane] : 0.0);
     double eta = rho * p.rho_mean;
-    if (p.eta_full) {
+    if constexpr (MASKED) {
+      // ---- phase C: the masked Gram of the NEXT step, summed by the row workgroups slice by slice (psmf_pstep.hip: pstep_rows) ----
+      if (wv == 0) {
+        const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
+        int stop = 0;
+        for (;;) {
+          bool ok = true;
+          for (int b = lane; b < nwg; b += 64) ok &= __hip_atomic_load(q.sflags + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= epoch;
+          if (__all((int)ok)) break;
+          __builtin_amdgcn_s_sleep(1);
+          if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > PSTEP_SPIN_TICKS) { stop = 2; break; }
+        }
+        if (lane == 0 && stop) *reinterpret_cast<volatile int*>(s_ctl) = stop;
+      }
+      ps_bar();
+      if (lds_word(s_ctl) != 0) break;
+      for (int e = tid; e < q.nge; e += NLT) s_gm[e] = wt_load(q.gslice + e);
+      ps_bar();
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        if (val[m]) {
+          Gv[m] = s_gm[gm_index(ii[m], j)];
+          gp += Gv[m] * Pbv[m];
+          sG[ii[m] * LS + j] = Gv[m];
+        }
+      }
+      nobs = s_gm[NTT * 256];
+      double x = ps_wave_sum(worker ? gp : 0.0);
+      if (lane == 0) s4[wv] = x;
+      ps_bar();
+      eta = (rho * nobs + ((s4[0] + s4[1]) + (s4[2] + s4[3]))) / dd;      // divided by d, not by the observed count (PSMF.py:77)
+      if (tid == 0 && p.sc_hist) {
+        long long tr_ = knext - p.series_t0;
+        if (tr_ > (long long)p.mask_rows - 1) tr_ = (long long)p.mask_rows - 1;      // (the step after the last of the series: never run)
+        if (knext - p.series_t0 <= (long long)p.mask_rows - 1) { p.sc_hist[2 * tr_] = sN; p.sc_hist[2 * tr_ + 1] = eta; }
+      }
+    } else if (p.eta_full) {
       double x = ps_wave_sum(worker ? gp : 0.0);
       if (lane == 0) s4[wv] = x;
       ps_bar();
@@ -680,11 +920,13 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
     ps_bar();
     PS_PROF(7);        // w / N, solve operands, barrier
     // packet of the next step
-    if (s + 1 < q.n_steps && tid < NG) {
-      const int e = tid >> 1;
-      const double v = tid == NG - 1 ? 0.0 : (e < RPAD ? s_mub[e] : s_wn[e - RPAD]);
-      const unsigned half = tid == NG - 1 ? 0u : ((tid & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v));
-      gran_store(q.pkt + tid, epoch + 1u, half);
+    if (s + 1 < q.n_steps) {
+      for (int gI = tid; gI < NG; gI += NLT) {
+        const int e = gI >> 1;
+        const double v = gI == NG - 1 ? 0.0 : (e < RPAD ? s_mub[e] : s_wn[e - RPAD]);
+        const unsigned half = gI == NG - 1 ? 0u : ((gI & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v));
+        gran_store(q.pkt + gI, epoch + 1u, half);
+      }
     }
     PS_PROF(8);        // packet out
   }
@@ -702,7 +944,8 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
       const int idx = ii[m] * r + j;
       st->V[idx] = Vv[m];
       if (n_done > 0) st->P[idx] = Pv[m];
-      st->G[idx] = Gv[m];
+      if (!MASKED) st->G[idx] = Gv[m];
+      else if (n_done > 0) { q.mg_out[idx] = Gv[m]; st->GR[idx] = Gv[m]; }      // the reduced masked Gram of the next step, where the next launch looks for it (GR: debug copy)
       st->Q[idx] = Qv[m];
       st->Pbar[idx] = Pbv[m];
       if (n_done > 0 && dual) { st->Lbar[idx] = sL[ii[m] * LS + j]; st->XpY[idx] = 0.5 * (sW[ii[m] * LS + j] + sW[j * LS + ii[m]]); }
@@ -721,6 +964,11 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
     p.adam_m[tid] = am;
     p.adam_v[tid] = av;
   }
+  if (MASKED && tid == 0 && n_done > 0) {
+    q.mg_out[r * r] = nobs;
+    q.mg_out[r * r + 2] = eta0 * dd - rho * nobs;          // <G_m, Pbar> as ONE share (the consumer sums mg_ntr of them in order)
+    for (int w = 1; w < q.mg_ntr; ++w) q.mg_out[r * r + 2 + w] = 0.0;
+  }
   if (tid == 0) {
     st->k = k0;
     st->kq = k0;
@@ -736,67 +984,96 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
 }
 
 // NP: row passes of a row workgroup, all of them unrolled and executed (rows beyond the workgroup's share are masked): no branch
-// between the passes, so their dot products, lane sums and updates interleave
-template <typename T, int RPAD, int NP>
-__global__ __launch_bounds__(PSTEP_NT) void psmf_pstep_k(PstepParams q) {
+// between the passes, so their dot products, lane sums and updates interleave.  NT: threads per workgroup -- 512 for r <= 32; 256 for
+// r > 32, where the solve waves keep 3 x 3 / 4 x 4 tiles of 16 x 16 in registers and the workers 32 elements of five 64 x 64 matrices
+// each (a wave of a 256-thread workgroup may hold 512 registers).
+template <typename T, int RPAD, int NP, int NT, bool MASKED>
+__global__ __launch_bounds__(NT) void psmf_pstep_k(PstepParams q) {
   extern __shared__ __attribute__((aligned(16))) char ps_smem[];
-  if (blockIdx.x == 0) pstep_hub<RPAD, PSTEP_NT>(q, ps_smem);
-  else pstep_rows<T, RPAD, PSTEP_NT, NP>(q, ps_smem);
+  if (blockIdx.x == 0) pstep_hub<RPAD, NT, MASKED>(q, ps_smem);
+  else pstep_rows<T, RPAD, NT, NP, MASKED>(q, ps_smem);
 }
 
 typedef void (*pstep_fn_t)(PstepParams);
-template <int RPAD>
+constexpr int pstep_nt(int rpad) { return rpad > 32 ? 256 : 512; }
+int pstep_np_variant(int rpad, int np) { return rpad > 32 ? (np <= 8 ? 8 : PSTEP_NPMAX_BIG) : (np <= 4 ? 4 : (np <= 8 ? 8 : PSTEP_NPMAX)); }
+
+template <int RPAD, bool MASKED>
 pstep_fn_t pstep_kernel_r(bool f64, int np) {
-  if (f64) return np <= 4 ? psmf_pstep_k<double, RPAD, 4> : (np <= 8 ? psmf_pstep_k<double, RPAD, 8> : psmf_pstep_k<double, RPAD, PSTEP_NPMAX_F64>);
-  return np <= 4 ? psmf_pstep_k<float, RPAD, 4> : (np <= 8 ? psmf_pstep_k<float, RPAD, 8> : psmf_pstep_k<float, RPAD, PSTEP_NPMAX>);
+  constexpr int NT = pstep_nt(RPAD);
+  if (f64) return np <= 4 ? psmf_pstep_k<double, RPAD, 4, NT, MASKED> : (np <= 8 ? psmf_pstep_k<double, RPAD, 8, NT, MASKED> : psmf_pstep_k<double, RPAD, PSTEP_NPMAX, NT, MASKED>);
+  return np <= 4 ? psmf_pstep_k<float, RPAD, 4, NT, MASKED> : (np <= 8 ? psmf_pstep_k<float, RPAD, 8, NT, MASKED> : psmf_pstep_k<float, RPAD, PSTEP_NPMAX, NT, MASKED>);
 }
-pstep_fn_t pstep_kernel(int rpad, bool f64, int np) {
+pstep_fn_t pstep_kernel(int rpad, bool f64, int np, bool masked) {
   switch (rpad) {
-    case 8: return pstep_kernel_r<8>(f64, np);
-    case 16: return pstep_kernel_r<16>(f64, np);
-    case 32: return pstep_kernel_r<32>(f64, np);
-    case 64: return pstep_kernel_r<64>(f64, np);
+    case 8: return masked ? pstep_kernel_r<8, true>(f64, np) : pstep_kernel_r<8, false>(f64, np);
+    case 16: return masked ? pstep_kernel_r<16, true>(f64, np) : pstep_kernel_r<16, false>(f64, np);
+    case 32: return masked ? pstep_kernel_r<32, true>(f64, np) : pstep_kernel_r<32, false>(f64, np);
   }
   return nullptr;
 }
 // dynamic LDS of a launch: more than half of a CU's 160 KB (one workgroup per compute unit); RPAD = 64: the hub's four 64 x 65 images
 size_t pstep_lds_bytes(int rpad) { return rpad > 32 ? (size_t)148 * 1024 : (size_t)84 * 1024; }
-int pstep_np_variant(bool f64, int np) { return np <= 4 ? 4 : (np <= 8 ? 8 : (f64 ? PSTEP_NPMAX_F64 : PSTEP_NPMAX)); }
 
 int pstep_rpad(int r) { return r <= 8 ? 8 : (r <= 16 ? 16 : (r <= 32 ? 32 : 64)); }
 
 }  // namespace
 
-bool pstep_plan(int d_local, int r, int n_cu, bool storage_f64, PstepPlan* out) {
-  if (r < 1 || r > RM || d_local < 1 || n_cu < 2) return false;
+// r > 32 is NOT instantiated: with 16 elements of five 64 x 64 matrices per worker thread beside the 3 x 3 / 4 x 4 tile sweeps the hub needs
+// more than the 512 registers a wave of a 256-thread workgroup may hold (hipcc: 2.7 KB of scratch per lane, measured before it was
+// dropped) -- those ranks keep the two launches per timestep (psmf_kernels.hip), whose serial stage spreads the state over 512 workers.
+static pstep_fn_t pstep_kernel_any(int rpad, bool f64, int np, bool masked) { return rpad > 32 ? nullptr : pstep_kernel(rpad, f64, np, masked); }
+
+bool pstep_plan(int d_local, int r, int n_cu, bool storage_f64, bool masked, PstepPlan* out) {
+  if (r < 1 || r > 32 || d_local < 1 || n_cu < 2) return false;
   const int rpad = pstep_rpad(r);
-  const int rpw = PSTEP_NT / (rpad / 4);
+  const int rpw = pstep_nt(rpad) / (rpad / 4);
   int nwg = (d_local + rpw - 1) / rpw;
   if (nwg > n_cu - 1) nwg = n_cu - 1;
   int rows = (d_local + nwg - 1) / nwg;
   int np = (rows + rpw - 1) / rpw;
-  if (np > (storage_f64 ? PSTEP_NPMAX_F64 : PSTEP_NPMAX)) return false;
-  np = pstep_np_variant(storage_f64, np);       // the kernel instance runs exactly this many passes: fewer, fuller workgroups
+  if (np > (rpad > 32 ? PSTEP_NPMAX_BIG : PSTEP_NPMAX)) return false;
+  (void)storage_f64;
+  np = pstep_np_variant(rpad, np);       // the kernel instance runs exactly this many passes: fewer, fuller workgroups
   rows = np * rpw;
   nwg = (d_local + rows - 1) / rows;
+  {      // the hub's fan-in: (threads of its six fan-in waves / pairs of columns, at most 24) segments x PSTEP_FANIN_ROWS rows each
+    const int npair = ((r + 1 + 1) & ~1) / 2;
+    int S = (6 * 64) / npair;
+    if (S > 24) S = 24;
+    if (nwg > S * PSTEP_FANIN_ROWS) return false;
+  }
   out->n_row_wg = nwg;
   out->rows_per_wg = rows;
   out->np = np;
   out->ncol2 = (r + 1 + 1) & ~1;
   const size_t fl = (((size_t)nwg * sizeof(unsigned)) + 15) & ~(size_t)15;
   const size_t pk = (((size_t)PSTEP_PKT_MAX * sizeof(unsigned long long)) + 15) & ~(size_t)15;
-  out->off_pkt = fl;
-  out->zero_bytes = fl + pk;
+  // the zeroed block: | flags of the (h, ee) hand-off | flags of the Gram partials | flags of the Gram slices | packet |
+  out->off_gflags = fl;
+  out->off_sflags = 2 * fl;
+  out->off_pkt = 3 * fl;
+  out->zero_bytes = 3 * fl + pk;
   out->off_part = (out->zero_bytes + 255) & ~(size_t)255;
-  out->total_bytes = out->off_part + (size_t)nwg * out->ncol2 * sizeof(double);
+  size_t end = out->off_part + (size_t)nwg * out->ncol2 * sizeof(double);
+  out->nge = 0; out->slice_len = 0; out->off_gpart = 0; out->off_gslice = 0;
+  if (masked) {
+    const int ntg = rpad > 16 ? 2 : 1;
+    out->nge = ntg * (ntg + 1) / 2 * 256 + 1;
+    out->slice_len = (out->nge + nwg - 1) / nwg;
+    out->off_gpart = (end + 255) & ~(size_t)255;
+    out->off_gslice = (out->off_gpart + (size_t)nwg * out->nge * sizeof(double) + 255) & ~(size_t)255;
+    end = out->off_gslice + (size_t)nwg * out->slice_len * sizeof(double);
+  }
+  out->total_bytes = end;
   return true;
 }
 
 hipError_t pstep_init() {
-  for (int rpad = 8; rpad <= 64; rpad *= 2)
-    for (int f = 0; f < 2; ++f)
-      for (int np = 4; np <= 16; np *= 2) {      // (4, 8, 16 -> the three instances)
-        const hipError_t e = hipFuncSetAttribute((const void*)pstep_kernel(rpad, f != 0, np), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pstep_lds_bytes(rpad));
+  for (int rpad = 8; rpad <= 32; rpad *= 2)
+    for (int f = 0; f < 4; ++f)
+      for (int np = 4; np <= 16; np *= 2) {      // (every instance is reached by one of these)
+        const hipError_t e = hipFuncSetAttribute((const void*)pstep_kernel_any(rpad, (f & 1) != 0, np, (f & 2) != 0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pstep_lds_bytes(rpad));
         if (e != hipSuccess) return e;
       }
   return hipSuccess;
@@ -804,9 +1081,9 @@ hipError_t pstep_init() {
 
 hipError_t pstep_launch(const PstepParams& q, bool storage_f64, hipStream_t stream) {
   const int rpad = pstep_rpad(q.sp.r);
-  pstep_fn_t fn = pstep_kernel(rpad, storage_f64, q.np);
+  pstep_fn_t fn = pstep_kernel_any(rpad, storage_f64, q.np, q.masked != 0);
   if (!fn) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(fn, dim3(q.n_row_wg + 1), dim3(PSTEP_NT), pstep_lds_bytes(rpad), stream, q);
+  hipLaunchKernelGGL(fn, dim3(q.n_row_wg + 1), dim3(pstep_nt(rpad)), pstep_lds_bytes(rpad), stream, q);
   return hipGetLastError();
 }
 

@@ -43,12 +43,64 @@ def kernel_name(d, r):
     return {1: "psmf_impute_kernel", 2: "psmf_impute_kernel2", 4: "masked per-step engine"}.get(code, f"error {code}")
 
 
+def replica_slices(batch, parts):
+    """Contiguous, near-equal slices of `batch` replicas for `parts` devices / ranks (the repeats of ExperimentImpute are
+    independent filters -- "replicas only", no exchange): [(start, stop), ...], empty slices when parts > batch."""
+    base, extra = divmod(int(batch), int(parts))
+    out, a = [], 0
+    for i in range(int(parts)):
+        b = a + base + (1 if i < extra else 0)
+        out.append((a, b))
+        a = b
+    return out
+
+
+def _impute_batch_devices(devices, YorgInt, M, Mmiss, C0, X0, *args, **kw):
+    """impute_batch with the replicas dealt over several devices of THIS process: one host thread per device (psmf_impute_run is
+    synchronous and releases the GIL), results merged in replica order.  One process per GPU works the same way with
+    replica_slices(batch, world)[rank] and device=LOCAL_RANK."""
+    import threading
+
+    M, Mmiss, C0, X0 = (np.asarray(a) for a in (M, Mmiss, C0, X0))
+    B = M.shape[0]
+    sl = [(dev, a, b) for dev, (a, b) in zip(devices, replica_slices(B, len(devices))) if b > a]
+    res, errs = [None] * len(sl), []
+
+    def work(i, dev, a, b):
+        try:
+            res[i] = impute_batch(YorgInt, M[a:b], Mmiss[a:b], C0[a:b], X0[a:b], *args, device=int(dev), **kw)
+        except BaseException as e:      # noqa: BLE001 -- re-raised by the caller's thread
+            errs.append(e)
+
+    ths = [threading.Thread(target=work, args=(i, dev, a, b)) for i, (dev, a, b) in enumerate(sl)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    if errs:
+        raise errs[0]
+    out = {}
+    for k in res[0]:
+        if isinstance(res[0][k], np.ndarray):
+            out[k] = np.concatenate([r_[k] for r_ in res], axis=0)
+    out["elapsed_ms"] = max(r_["elapsed_ms"] for r_ in res)      # the slices ran side by side
+    out["kernel"] = res[0]["kernel"]
+    out["devices"] = [(int(dev), a, b) for dev, a, b in sl]
+    return out
+
+
 def impute_batch(YorgInt, M, Mmiss, C0, X0, V, Q, R, P, sig, Iter, robust=False, lambda0=0.0, device=0,
                  want_bands=False, method=None):
     """Run `batch` replicas.  Reference layouts: YorgInt (d, n); M, Mmiss (batch, d, n);
     C0 (batch, d, r); X0 (batch, r, n).  Returns a dict with Epred, Efull (batch, Iter),
     inside (batch,), C (batch, d, r), X (batch, r, n), elapsed_ms and, if requested,
-    Yrec / YrecL / YrecH (batch, d, n)."""
+    Yrec / YrecL / YrecH (batch, d, n).  `device`: a HIP device ordinal, or a sequence of them -- the replicas are then dealt
+    over those devices in contiguous slices (replica_slices) and run side by side."""
+    if not np.isscalar(device):
+        if np.asarray(M).ndim == 2:
+            raise ValueError("a device list needs a batch of replicas")
+        return _impute_batch_devices(list(device), YorgInt, M, Mmiss, C0, X0, V, Q, R, P, sig, Iter, robust=robust, lambda0=lambda0,
+                                     want_bands=want_bands, method=method)
     lib = _capi.load_library()
     meth = METHODS[method] if method is not None else int(bool(robust))     # "mle_smf" / "tmf": the baseline filters
     YorgInt = np.asarray(YorgInt, dtype=np.float64)

@@ -50,6 +50,32 @@ def test_bench_two_ranks_one_gpu(engine, d, r):
         assert ex["messages"]["per_timestep_bytes"] == (r + 1) * 8
 
 
+def test_bench_four_ranks_one_gpu_uneven_rows():
+    """Four ranks (the most a one-GPU box lets share its card is six processes) with a row count that does not divide: every rank's
+    shard, the exchange description with four entries, the N > 1 fields of the line (transport_fallback, scaling_note,
+    whole_job_frac) and the sharded parity."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    d, r = 10_002, 32
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2", "--warmup", "1", "--rows", str(d),
+           "--latent-rank", str(r), "--timesteps", "400", "--cpu-steps", "150", "--no-extras", "--comm", "gloo", "--one-device"]
+    pr = subprocess.run(cmd, capture_output=True, text=True, timeout=280, env=dict(os.environ, OMP_NUM_THREADS="2"), cwd=ROOT)
+    assert pr.returncode == 0, pr.stdout[-2000:] + pr.stderr[-3000:]
+    lines = [ln for ln in pr.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, pr.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 4 and out["value"] > 0
+    ex = out["config"]["exchange"]
+    assert ex["world_size"] == 4 and ex["ranks"] == [4, 4, 4, 4] and [p["rank"] for p in ex["rank_devices"]] == [0, 1, 2, 3]
+    assert out["transport_fallback"] is True and "flat BY DESIGN" in out["scaling_note"]        # gloo, not RCCL: the line says so at top level
+    assert 0.0 < out["roofline"]["whole_job_frac"] < 1.0
+    assert len(out["roofline"]["gap_between_blocks_us_per_rank"]) == 4
+    par = out["parity_vs_cpu_oracle"]
+    assert par["ranks"] == 4 and max(par["C"], par["V"], par["mu"], par["P"]) < 1e-5 and par["replicated_state_bit_identical"] is True
+
+
 def test_bench_falls_back_to_gloo_when_rccl_does_not_come_up():
     """The driver's N > 1 run asks for RCCL (the default).  If the communicator cannot be built on every rank the bench must still
     deliver its line -- over the host-mediated transport, saying so with RCCL's own message -- instead of losing the measurement.
@@ -68,6 +94,7 @@ def test_bench_falls_back_to_gloo_when_rccl_does_not_come_up():
     out = json.loads(lines[0])
     ex = out["config"]["exchange"]
     assert ex["rccl_init_error"] and ex["transport"].startswith("host-mediated") and ex["rccl_ranks"] is None and ex["ranks"] == [2, 2]
+    assert out["transport_fallback"] is True
     par = out["parity_vs_cpu_oracle"]
     assert par["ranks"] == 2 and max(par["C"], par["V"], par["mu"], par["P"]) < 1e-5 and par["replicated_state_bit_identical"] is True
 

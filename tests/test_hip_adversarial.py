@@ -69,3 +69,46 @@ def test_adversarial_series_vs_oracle(name, r, robust):
     assert tail["sweep_steps"] <= 0.2 * (T - cs["checkpoints"][-2]), tail        # ... and the filter goes back to iterating
     print(name, "rPSMF" if robust else "PSMF", f"worst rel-err {worst:.1e}, y_pred {e:.1e}",
           {k: (c["ns_steps"], c["sweep_steps"], c["ns_iterations"], c["ns_failed"]) for k, c in counters.items()})
+
+
+# ---- the same cases on psmf_blk_filter4 (round 5): its Newton-Schulz starts are given up only beyond a residual of 0.6
+# (PSMF_NS_FAR4; filter3: 0.3) because its fallback is the cheap wave-local sweep -- a threshold no adversarial series had run under.
+# A random walk with R_k / Q_k schedules is kept off filter3 (blk_dual_ok) and runs the full filter, Q = q I, at 17 <= r <= 32 on
+# filter4; constant schedules (all ones) leave the oracle's arithmetic exactly the unscheduled one.  Not chaotic (unlike the full
+# cos-phase filter, tools/probe_f4g.py), so the horizon can be long.
+F4_COMBOS = [("tiny_Q", 24, False), ("tiny_P0", 24, False), ("outlier_block", 32, False), ("tiny_Q", 32, False), ("level_shift", 20, False)]
+
+
+@pytest.mark.parametrize("name,r,robust", F4_COMBOS, ids=[f"f4-{n}-{'rPSMF' if rb else 'PSMF'}_r{r}" for n, r, rb in F4_COMBOS])
+def test_adversarial_series_on_filter4(name, r, robust):
+    from rpsmf_amd import _capi
+
+    d, T = 6_000, 600
+    cs = make_case(name, d, r, T, robust)
+    st = O.State(C=cs["C0"].copy(), V=cs["V0"], mu=np.zeros(r), P=cs["P0"], Q=cs["Q"], rho=1.0, lam=1.8)
+    cps = tuple(k for k in cs["checkpoints"] if k <= T)
+    st, Yp, trace = O.run_epoch(st, cs["Y"].astype(np.float64), O.Mode(robust=robust), O.RandomWalkDyn(), keep=cps, want_grad=False)
+    f = _capi.DeviceFilter(d, r, robust=robust, storage="f32")
+    f.set_schedules(np.ones(T + 1), np.ones(T + 1))
+    f.upload_series(cs["Y"])
+    f.set_state(cs["C0"], cs["V0"], cs["P0"], cs["Q"], np.zeros(r), rho=1.0, lambda0=1.8)
+    assert f.geometry()["filter_kernel"] == "psmf_blk_filter4", f.geometry()
+    k_prev, worst, tot = 0, 0.0, dict(ns_steps=0, sweep_steps=0, ns_failed=0)
+    for k in cps:
+        f.counters(reset=True)
+        f.run(k_prev, k)
+        s = f.get_state()
+        c = f.counters()
+        for key in tot:
+            tot[key] += c[key]
+        ref = trace[k][0]
+        for n in ("C", "V", "mu", "P"):
+            e = relerr(s[n], getattr(ref, n))
+            worst = max(worst, e)
+            assert e < TOL, (name, n, k, e, c)
+        k_prev = k
+    e = relerr(f.y_pred(0, T), Yp)
+    f.close()
+    assert e < TOL, (name, "y_pred", e)
+    assert tot["ns_steps"] + tot["sweep_steps"] == T, tot
+    print("filter4", name, f"r={r} worst rel-err {worst:.1e}, y_pred {e:.1e}", tot)

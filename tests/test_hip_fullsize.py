@@ -17,6 +17,12 @@ from oracle.impute_oracle import impute_filter
 pytestmark = pytest.mark.gpu
 
 TOL = 1e-5
+# Entry-by-entry bound (entries >= 1e-3 of the largest), as a multiple of the tolerance of the normalised norm.  With float32 storage
+# of C, y, y_hat the worst entry-by-entry errors measured over configs B, C, E (two epochs of 10 000 timesteps, PSMF and rPSMF) are
+# 6.9e-4 (y_hat of the tracked series), 3.5e-4 (C), 1.5e-4 (V), 5.4e-5 (P) -- profiles/r4_parity_fullsize.txt; with float64 storage
+# 3.4e-9 on C (BENCH r5, other_configs.E_f64_storage).  150 x tol = 1.5e-3 leaves a factor 2 over the worst measured value, so a
+# regression by a small factor fails here (the bound was 1000 x tol until round 5).
+ELEMENTWISE_FACTOR = 150.0
 
 
 def _capi():
@@ -56,12 +62,12 @@ def _checkpointed_parity(d, r, T, robust, checkpoints, engine="auto", storage="f
             e = relerr(s[name], getattr(ref, name))
             worst[name] = max(worst.get(name, 0.0), e)
             assert e < tol, (name, k, e)
-            # the same comparison entry by entry (entries >= 1e-3 of the largest): reported, and bounded at 1000 x the tolerance
-            # of the normalised norm -- an entry a thousand times smaller than the largest may carry the same absolute error
+            # the same comparison entry by entry (entries >= 1e-3 of the largest): reported, and bounded at ELEMENTWISE_FACTOR x the
+            # tolerance of the normalised norm -- an entry a thousand times smaller than the largest may carry the same absolute error
             ee, share = relerr_elementwise(s[name], getattr(ref, name))
             worst[name + "_elementwise"] = max(worst.get(name + "_elementwise", 0.0), ee)
             worst[name + "_elementwise_share"] = share
-            assert ee < 1e3 * tol, (name, k, ee)
+            assert ee < ELEMENTWISE_FACTOR * tol, (name, k, ee)
         if robust:
             assert relerr(s["rho"], ref.rho) < tol and relerr(s["lam"], ref.lam) < 1e-12
     e = relerr(f.y_pred(0, T), Yp)
@@ -119,7 +125,7 @@ def test_config_E_full_horizon_two_epochs_vs_oracle_fixture(which):
         if np.ndim(ref) >= 1 and np.size(ref) > 1:          # entry by entry as well (entries >= 1e-3 of the largest): reported
             ee, _ = relerr_elementwise(got, ref)
             worst[name + "_elementwise"] = max(worst.get(name + "_elementwise", 0.0), ee)
-            assert ee < 1e3 * tol, (which, name, k, ee)
+            assert ee < ELEMENTWISE_FACTOR * tol, (which, name, k, ee)
 
     epochs = int(g["epochs"])
     cps = [int(k) for k in g["checkpoints"]]

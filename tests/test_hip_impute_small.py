@@ -39,16 +39,26 @@ def _err(a, b):
     return relerr(np.nan_to_num(a), np.nan_to_num(b))
 
 
-def _v2(fn):
-    old = os.environ.get("PSMF_IMPUTE_V3")
-    os.environ["PSMF_IMPUTE_V3"] = "0"
+def _with_env(name, value, fn):
+    old = os.environ.get(name)
+    os.environ[name] = value
     try:
         return fn()
     finally:
         if old is None:
-            os.environ.pop("PSMF_IMPUTE_V3", None)
+            os.environ.pop(name, None)
         else:
-            os.environ["PSMF_IMPUTE_V3"] = old
+            os.environ[name] = old
+
+
+def _v2(fn):
+    return _with_env("PSMF_IMPUTE_V3", "0", fn)
+
+
+def _sequential(fn):
+    """PSMF_IMPUTE_PAR=0: the two r x r inversions of a column one after the other on one wave (the Q = q I case takes them side by
+    side on two by default)"""
+    return _with_env("PSMF_IMPUTE_PAR", "0", fn)
 
 
 SHAPES = [(19, 10), (19, 9), (7, 3), (12, 5), (16, 14), (20, 13), (21, 2), (32, 14), (25, 7), (2, 1),
@@ -66,6 +76,7 @@ def test_small_shapes_vs_oracle_and_version_2(d, r, robust):
     run = lambda: impute.impute_batch(Yorig, np.stack([M] * 3), np.stack([Mmiss] * 3), np.stack([C0] * 3), np.stack([X0] * 3),
                                       V, Q, 10.0, P, 2, 2, robust=robust, lambda0=1.8, want_bands=True)
     res, res2 = run(), _v2(run)
+    res3 = _sequential(run) if (d, r) in ((19, 10), (7, 3), (33, 5), (75, 10)) else None
     tol = 1e-8 if robust else 1e-10
     for rep in (0, 2):
         assert relerr(res["Epred"][rep], ep[0, 1:]) < 1e-9 and relerr(res["Efull"][rep], ef[0, 1:]) < 1e-9
@@ -76,6 +87,8 @@ def test_small_shapes_vs_oracle_and_version_2(d, r, robust):
     assert np.array_equal(res["X"][0], res["X"][2])            # replicas of one problem: the same bits
     for k in ("C", "X", "Yrec", "YrecL", "YrecH"):
         assert _err(res[k], res2[k]) < tol, k
+        if res3 is not None:
+            assert _err(res[k], res3[k]) < tol, ("PSMF_IMPUTE_PAR=0", k)
 
 
 @pytest.mark.parametrize("robust", [False, True], ids=["PSMF", "rPSMF"])
@@ -137,3 +150,21 @@ def test_small_shapes_drawn_at_random(seed):
         tol = 1e-8
     assert _err(res["C"][0], st["C"]) < tol and _err(res["X"][0], st["X"]) < tol, (d, r, n, method)
     assert _err(res["Epred"][0], ep[0, 1:]) < 1e-8 and _err(res["Efull"][0], ef[0, 1:]) < 1e-8
+
+
+def test_replicas_dealt_over_a_device_list_are_the_same_filters():
+    """impute_batch(device=[...]): contiguous slices of the replicas on the listed devices, one host thread each (config
+    D's seeds over the GPUs of a node).  On a one-GPU box the list names device 0 three times: same bits as the single call."""
+    d, n, r, B = 19, 120, 10, 7
+    Yorig, M, Mmiss, C0, X0 = _problem(d, n, r, 321)
+    rng = np.random.default_rng(5)
+    Ms = np.stack([(rng.random((d, n)) > 0.3).astype(float) for _ in range(B)])
+    Mm = 1.0 - Ms
+    Cs = np.stack([rng.random((d, r)) for _ in range(B)])
+    Xs = np.stack([rng.random((r, n)) for _ in range(B)])
+    V, Q, P = 2 * np.eye(r), 0.1 * np.eye(r), np.eye(r)
+    one = impute.impute_batch(Yorig, Ms, Mm, Cs, Xs, V, Q, 10.0, P, 2, 2, robust=True, lambda0=1.8, want_bands=True)
+    three = impute.impute_batch(Yorig, Ms, Mm, Cs, Xs, V, Q, 10.0, P, 2, 2, robust=True, lambda0=1.8, want_bands=True, device=[0, 0, 0])
+    assert three["devices"] == [(0, 0, 3), (0, 3, 5), (0, 5, 7)]
+    for k in ("Epred", "Efull", "inside", "C", "X", "Yrec", "YrecL", "YrecH", "status"):
+        assert np.array_equal(one[k], three[k], equal_nan=True), k

@@ -123,6 +123,15 @@ CASES = [
     ("block", "f64", 2000, 32, 140, 2, {"PSMF_FILTER3": "0"}),       # two-halves filter kernel (psmf_blk_filter2)
     ("step", "f64", 1001, 9, 60, 2, None),                          # per-step engine: r + 1 doubles per timestep
     ("step", "f64", 900, 40, 40, 3, None),                          # r > 32
+    # round 5 (SURVEY section 4 asks for 1 / 2 / 4 / 8 shards): four and eight shards, uneven row counts
+    ("block", "f32", 4100, 32, 200, 4, None),
+    ("block", "f64", 3001, 32, 150, 8, None),
+    ("block", "f64", 2002, 12, 130, 4, None),
+    ("step", "f64", 1001, 9, 60, 4, None),
+    ("step", "f64", 1203, 20, 40, 8, None),
+    # the device-flag hand-off and the chained filter launch (what an RCCL run uses) under the host communicator
+    ("block", "f32", 4096, 32, 200, 2, {"PSMF_HOST_COMM_FLAGS": "1"}),
+    ("block", "f64", 3001, 20, 180, 4, {"PSMF_HOST_COMM_FLAGS": "1"}),
 ]
 
 

@@ -26,10 +26,10 @@ int main(int argc, char** argv) {
   hipMemcpy(dV, V.data(), r * r * 8, hipMemcpyHostToDevice); hipMemcpy(dP, P.data(), r * r * 8, hipMemcpyHostToDevice); hipMemcpy(dQ, Q.data(), r * r * 8, hipMemcpyHostToDevice);
   hipMemcpy(dM, M.data(), M.size(), hipMemcpyHostToDevice); hipMemcpy(dMm, Mm.data(), Mm.size(), hipMemcpyHostToDevice);
   p.Yorg = dY; p.M = dM; p.Mmiss = dMm; p.C = dC; p.X = dX; p.V0 = dV; p.P0 = dP; p.Q0 = dQ; p.Epred = dE; p.Efull = dF; p.inside = dI; p.err = dErr; p.prof = prof; p.q_iso = argc > 5 ? atoi(argv[5]) : 1;
-  const size_t lds = ver == 1 ? impute_lds_bytes(d, r) : (ver == 3 ? impute3_lds_bytes(d, r) : impute2_lds_bytes(d, r));
+  const size_t lds = ver == 3 ? impute3_lds_bytes(d, r) : impute2_lds_bytes(d, r);      // (version 1, round 1's loop, was removed in round 5)
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipEventRecord(e0);
-  if (ver == 1) psmf_impute_kernel<<<B, WG, lds>>>(p); else if (ver == 3) { void* args[] = {&p}; hipLaunchKernel(impute3_kernel(d), dim3(B), dim3(WG), args, lds, 0); } else psmf_impute_kernel2<<<B, WG, lds>>>(p);
+  if (ver == 3) { void* args[] = {&p}; hipLaunchKernel(impute3_kernel(d), dim3(B), dim3(WG), args, lds, 0); } else psmf_impute_kernel2<<<B, WG, lds>>>(p);
   hipEventRecord(e1); hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
   std::vector<unsigned long long> h((size_t)B * 4 * 8); hipMemcpy(h.data(), prof, h.size() * 8, hipMemcpyDeviceToHost);
