@@ -241,7 +241,7 @@ def cpu_baseline_literal(r, seed, budget_s=12.0):
                        f"O(d^2 r) literal restatement of pypsmf/psmf/psmf.py:121-165, {dt:.1f} s")
 
 
-def run_filter_config(_capi, name, d, r, T, robust, passes=3, storage="f32", engine="auto", bulk_times=False):
+def run_filter_config(_capi, name, d, r, T, robust, passes=3, storage="f32", engine="auto", bulk_times=False, oracle=None):
     """Configs B / C (and config E under another storage type / engine): cold pass, steady passes, parity against the oracle on the
     first 300 timesteps."""
     seed = 35833 if robust else 35853
@@ -252,7 +252,10 @@ def run_filter_config(_capi, name, d, r, T, robust, passes=3, storage="f32", eng
         f.upload_series(Yc, t0=a, T_total=T)
     reset = lambda: f.set_state(st0["C"], st0["V"], st0["P"], st0["Q"], st0["mu"], rho=st0["rho"], lambda0=st0["lam"])
     n_par = 300
-    st_cpu, dt_cpu = oracle_prefix(series, st0, n_par, robust)
+    if oracle is not None:      # (state after n steps, n, seconds): the headline's own oracle prefix -- same seed, same series generator
+        st_cpu, n_par, dt_cpu = oracle
+    else:
+        st_cpu, dt_cpu = oracle_prefix(series, st0, n_par, robust)
     reset()
     f.run(0, n_par)
     par = parity_of(f, st_cpu, n_par)
@@ -280,6 +283,46 @@ def run_filter_config(_capi, name, d, r, T, robust, passes=3, storage="f32", eng
         out["bulk_kernels_us"] = {"cross_gram+reduce": f.time_kernel(1, 50), "apply": f.time_kernel(2, 50), "block_steps": geo["block_steps"]}
     f.close()
     return out
+
+
+def run_masked_config(_capi, d=100_000, r=32, T=1_000, missing=0.4, n_par=40, passes=3):
+    """The masked filter north_star describes ("masked innovation-covariance assembly over the observed-index set") at config E's shape:
+    40 % of the entries missing at random, the large-d masked handle (cfg.masked = 1) -- one persistent launch per pass, the masked Gram
+    of every timestep formed from the on-chip C -- with parity against the oracle's masked step on the first timesteps."""
+    from oracle import psmf_oracle as O
+
+    seed = 35871
+    series = Series(d, r, T, seed, 0, d, False)
+    st0 = init_state(d, r, seed)
+    Y = np.vstack([Yc for _, Yc in series.chunks(chunk=T)])[:T].astype(np.float64)
+    rng = np.random.default_rng(seed)
+    M = (rng.random((T, d)) >= missing).astype(np.uint8)
+    Y *= M
+    f = _capi.DeviceFilter(d, r, storage="f64", engine="step", masked=True)
+    f.upload_series(Y)
+    f.upload_mask(M)
+    reset = lambda: f.set_state(st0["C"], st0["V"], st0["P"], st0["Q"], st0["mu"], rho=st0["rho"], lambda0=st0["lam"])
+    st = O.State(C=st0["C"].copy(), V=st0["V"].copy(), mu=st0["mu"].copy(), P=st0["P"].copy(), Q=st0["Q"].copy(), rho=st0["rho"], lam=st0["lam"])
+    t0 = time.perf_counter()
+    for k in range(n_par):
+        st, _ = O.lowrank_step(st, Y[k], k + 1, O.Mode(), O.RandomWalkDyn(), mask=M[k].astype(float), want_grad=False)
+    dt_cpu = time.perf_counter() - t0
+    reset()
+    f.run(0, n_par)
+    par = parity_of(f, st, n_par)
+    reset()
+    f.run(0, T)
+    f.sync()
+    t0 = time.perf_counter()
+    for _ in range(passes):
+        f.run(0, T, sync=False)
+    f.sync()
+    steady = (time.perf_counter() - t0) / passes
+    geo = f.geometry()
+    f.close()
+    return {"workload": f"masked PSMF (ExperimentImpute/PSMF.py:59-84 semantics), d={d} r={r} T={T}, {int(100 * missing)} % missing, f64 storage, 1 GPU",
+            "value": T / steady, "unit": "masked timesteps/s", "us_per_timestep": 1e6 * steady / T, "kernel": geo.get("filter_kernel"),
+            "parity_vs_cpu_oracle": par, "cpu_oracle_steps_per_s": n_par / dt_cpu}
 
 
 def run_synthetic_simplified(_capi, d=10_000, r=20, T=5_000, robust=False, passes=3):
@@ -826,15 +869,20 @@ def main():
                 except Exception as e:
                     line["cpu_baseline_f32"] = {"error": repr(e)}
                 other = {}
+                e_oracle = (st_cpu, n_cpu, n_cpu / cpu["value"]) if cpu is not None else None
                 if (d, r, args.storage, args.engine) == (100_000, 32, "f32", "auto"):
                     try:     # the headline with float64 storage of C, y, y_hat on the same (blocked) engine: what the 1e-5 bar costs in either norm
-                        other["E_f64_storage"] = run_filter_config(_capi, "E_f64", d, r, 4_000, bool(args.robust), passes=2, storage="f64", bulk_times=True)
+                        other["E_f64_storage"] = run_filter_config(_capi, "E_f64", d, r, 4_000, bool(args.robust), passes=2, storage="f64", bulk_times=True, oracle=e_oracle)
                     except Exception as e:
                         other["E_f64_storage"] = {"error": repr(e)}
                     try:     # the step-at-a-time engine north_star describes, as one persistent launch per pass (C on chip in float64)
-                        other["E_per_step_engine"] = run_filter_config(_capi, "E_step", d, r, 4_000, bool(args.robust), passes=2, storage="f32", engine="step")
+                        other["E_per_step_engine"] = run_filter_config(_capi, "E_step", d, r, 4_000, bool(args.robust), passes=2, storage="f32", engine="step", oracle=e_oracle)
                     except Exception as e:
                         other["E_per_step_engine"] = {"error": repr(e)}
+                    try:     # ... and its masked form at the same shape
+                        other["E_masked_per_step_engine"] = run_masked_config(_capi, d, r)
+                    except Exception as e:
+                        other["E_masked_per_step_engine"] = {"error": repr(e)}
                 for name, rob in (("B", False), ("C", True)):
                     try:
                         other[name] = run_filter_config(_capi, name, 10_000, 20, 5_000, rob)
