@@ -1126,7 +1126,7 @@ void psmf_destroy(psmf_handle h) {
     if (hipMemcpy(pf, h->ps_prof, sizeof(pf), hipMemcpyDeviceToHost) == hipSuccess && h->ps_prof_steps > 0) {
       fprintf(stderr, "[pstep prof] cycles per timestep over the last launch (%lld steps), d_local %d r %d:\n", h->ps_prof_steps, h->cfg.d_local, h->cfg.r);
       const char* grp[3] = {"hub workers", "solve wave ", "row wg 0   "};
-      const int base[3] = {0, 16, 24}, cnt[3] = {9, 3, 5};
+      const int base[3] = {0, 16, 24}, cnt[3] = {11, 3, 8};
       for (int g = 0; g < 3; ++g) {
         fprintf(stderr, "  %s:", grp[g]);
         for (int i = 0; i < cnt[g]; ++i) fprintf(stderr, " %7.0f", (double)pf[base[g] + i] / (double)h->ps_prof_steps);

@@ -7,7 +7,7 @@ namespace psmf {
 constexpr int PSTEP_NPMAX = 12;      // row passes a row workgroup can keep in registers (4 float64 per lane and pass; y_k beside them)
 constexpr int PSTEP_NPMAX_BIG = 32;  // ... of the 256-thread instances (r > 32: 16 rows per pass, 512 registers per wave)
 constexpr int PSTEP_PKT_MAX = 4 * RM + 1;      // granules of the hub -> rows packet
-constexpr int PSTEP_FANIN_ROWS = 12;           // partial rows one thread of the hub's fan-in sums (all its loads in flight at once)
+constexpr int PSTEP_FANIN_ROWS = 17;           // partial rows one thread of the hub's fan-in sums (all its loads in flight at once)
 
 struct PstepParams {
   StepParams sp;               // the handle's parameter block
@@ -25,9 +25,9 @@ struct PstepParams {
   int nge;                     // elements of a Gram partial: upper 16 x 16 tiles in the MFMA layout (256 each) + the observed count
   int slice_len;               // elements of the reduced Gram one row workgroup sums over all partials (ceil(nge / n_row_wg))
   unsigned* gflags;            // rows -> rows: partial Gram of the epoch published       } in the zeroed block
-  unsigned* sflags;            // rows -> hub: slice of the reduced Gram published        }
+  unsigned* sflags;            // (spare)                                                 }
   double* gpart;               // n_row_wg x nge
-  double* gslice;              // n_row_wg x slice_len (>= nge, contiguous: element e at gslice[e])
+  double* gslice;              // rows -> hub: the reduced Gram as 2 nge {tag, half} granules (element e at granules 2 e, 2 e + 1); in the zeroed block
   double* mg_out;              // the handle's reduced-Gram buffer (r*r + 1 | trace shares): what a launch leaves for the next one
   int mg_ntr;
   long long* prof;             // diagnostic builds (-DPSTEP_PROF): per-phase shader-clock sums, [0..15] hub workers, [16..23] solve wave, [24..31] row workgroup 1

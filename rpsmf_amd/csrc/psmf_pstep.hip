@@ -82,18 +82,22 @@ __device__ __forceinline__ double ps_wave_sum(double v) {
 // (y_hat, the mean history, hand-off words) in flight that nothing inside the launch reads back through the cache
 __device__ __forceinline__ void ps_bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// per-phase shader-clock sums of one lane (diagnostic builds only: -DPSTEP_PROF; tools/probe_pstep.py prof)
+// per-phase shader-clock sums of one lane (diagnostic builds only: -DPSTEP_PROF; tools/probe_pstep_time.py).  Stamps only in the
+// UNMASKED instances: with stamps in them the masked instances die in hipcc 7.2's back end ("Illegal instruction detected: Operand has
+// incorrect register class"; the error count changes with every stamp removed) -- the masked per-phase numbers of docs/MEASUREMENTS.md
+// come from the build before the Gram slices became tagged granules, which still compiled.
 #ifdef PSTEP_PROF
 #define PS_PROF_DECL(n) long long pf_acc[n]; _Pragma("unroll") for (int pf_i = 0; pf_i < n; ++pf_i) pf_acc[pf_i] = 0; long long pf_prev = 0
-#define PS_PROF_START() do { __builtin_amdgcn_sched_barrier(0); pf_prev = (long long)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } while (0)
-#define PS_PROF(i) do { __builtin_amdgcn_sched_barrier(0); const long long pf_t = (long long)__builtin_amdgcn_s_memtime(); pf_acc[i] += pf_t - pf_prev; pf_prev = pf_t; __builtin_amdgcn_sched_barrier(0); } while (0)
-#define PS_PROF_OUT(base, n, cond) do { if (q.prof && (cond)) { _Pragma("unroll") for (int pf_i = 0; pf_i < n; ++pf_i) q.prof[(base) + pf_i] = pf_acc[pf_i]; } } while (0)
+#define PS_PROF_START() do { if constexpr (!MASKED) { __builtin_amdgcn_sched_barrier(0); pf_prev = (long long)__builtin_amdgcn_s_memtime(); __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define PS_PROF(i) do { if constexpr (!MASKED) { __builtin_amdgcn_sched_barrier(0); const long long pf_t = (long long)__builtin_amdgcn_s_memtime(); pf_acc[i] += pf_t - pf_prev; pf_prev = pf_t; __builtin_amdgcn_sched_barrier(0); } } while (0)
+#define PS_PROF_OUT(base, n, cond) do { if constexpr (!MASKED) { if (q.prof && (cond)) { _Pragma("unroll") for (int pf_i = 0; pf_i < n; ++pf_i) q.prof[(base) + pf_i] = pf_acc[pf_i]; } } } while (0)
 #else
 #define PS_PROF_DECL(n) do { } while (0)
 #define PS_PROF_START() do { } while (0)
 #define PS_PROF(i) do { } while (0)
 #define PS_PROF_OUT(base, n, cond) do { } while (0)
 #endif
+#define PS_PROFM(i) do { } while (0)
 
 typedef unsigned long long u64;
 __device__ __forceinline__ void gran_store(u64* g, unsigned tag, unsigned v) {
@@ -291,6 +295,8 @@ __device__ __forceinline__ void pstep_rows(const PstepParams& q, char* smem) {
       double* dst = q.part + (size_t)wg * q.ncol2;
       if (2 * lane < r + 1) wt_store(dst + 2 * lane, out[0]);
       if (2 * lane + 1 < r + 1) wt_store(dst + 2 * lane + 1, out[1]);
+      // (masked handles too: (h, ee) goes out NOW, before the Gram of the next step -- measured the other way round, with one drain and
+      //  one flag for both, the hub's serial stage waited for h behind the Gram: 17.1 -> 21.8 us per masked timestep)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       if (lane == 0) __hip_atomic_store(q.flags + wg, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -361,6 +367,7 @@ __device__ __forceinline__ void pstep_rows(const PstepParams& q, char* smem) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // EVERY storing wave, then the barrier, then one flag
       ps_bar();
       if (tid == 0) __hip_atomic_store(q.gflags + wg, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      PS_PROFM(5);    // masked Gram of the next step: slabs, matrix cores, wave sums, partial out, drained, flag
       // ---------- reduce-scatter: this workgroup sums ITS elements of the Gram over all workgroups' partials (fixed order) ----------
       const int nwg = q.n_row_wg, SL = q.slice_len, e0 = wg * SL;
       const int nmine = max(0, min(SL, q.nge - e0));
@@ -378,6 +385,15 @@ __device__ __forceinline__ void pstep_rows(const PstepParams& q, char* smem) {
       }
       ps_bar();
       if (lds_word(s_ctl) != 0) break;
+      // the slice leaves as 8-byte {tag = epoch, 32-bit half} granules (the data is the flag: no drain, no barrier, no flag word)
+      u64* gsl = reinterpret_cast<u64*>(q.gslice);
+      auto slice_out = [&](const int e, const double a) {
+        const u64 bits = (u64)__double_as_longlong(a), tg = (u64)epoch << 32;
+        __hip_atomic_store(gsl + 2 * e, tg | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(gsl + 2 * e + 1, tg | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      };
+      // (the sources go through LDS, two loads per thread: with eight lanes per element loading 32 partials each straight into registers
+      //  the one active wave issued 1 024 scattered requests by itself and the phase took 6.7 us instead of 2.2)
       for (int item = tid; item < nwg * nmine; item += NT) {
         const int src = item / nmine, el = item - src * nmine;
         s_rs[el * nwg + src] = wt_load(q.gpart + (size_t)src * q.nge + e0 + el);
@@ -397,17 +413,17 @@ __device__ __forceinline__ void pstep_rows(const PstepParams& q, char* smem) {
           }
         }
         a = group_sum<8>(a);
-        if (el < nmine && u == 0) wt_store(q.gslice + e0 + el, a);
+        if (el < nmine && u == 0) slice_out(e0 + el, a);
       } else {                     // few workgroups, long slices: one lane per element
         for (int el = tid; el < nmine; el += NT) {
           double a = 0.0;
           for (int src = 0; src < nwg; ++src) a += s_rs[el * nwg + src];
-          wt_store(q.gslice + e0 + el, a);
+          slice_out(e0 + el, a);
         }
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      ps_bar();
-      if (tid == 0) __hip_atomic_store(q.sflags + wg, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      ps_bar();                    // (s_rs is free again)
+      PS_PROFM(6);    // partials of every workgroup seen, own slice summed and out (one stamp: with two in this region hipcc 7.2 fails with
+                     // "Illegal instruction detected: Operand has incorrect register class" in the diagnostic build)
       mcur = mnext;
       mnext = mask_bits(t + 2);
     }
@@ -517,7 +533,9 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
   constexpr int M = (RPAD * RPAD) / NWK > 0 ? (RPAD * RPAD) / NWK : 1;
   constexpr int LS = RPAD + 1;               // row stride of the r x r LDS images
   constexpr int NG = 4 * RPAD + 1;
-  constexpr int NFT = (NW - 2) * 64;         // threads of the fan-in (waves 0 .. NW-3)
+  // threads of the fan-in.  512-thread hub: waves 0, 1, 4, 5 -- the SIMDs (wave id mod 4) of the two solve waves, 6 and 7, are shared
+  // with waves 2 and 3, which therefore spend phase A asleep in the workgroup barrier instead of polling LDS beside the tile sweeps
+  constexpr int NFT = SHARED ? (NW - 2) * 64 : 256;
   constexpr int NLT = SHARED ? NT : NT - 128; // threads that run the worker loop (the two solve waves have a loop of their own)
   constexpr int LPC = NT >= 512 ? 8 : 1;     // lanes per column of the fan-in's second level (LPC x (r + 1) <= NFT)
   const StepParams& p = q.sp;
@@ -632,8 +650,10 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
   // fan-in geometry: thread t of waves 0 .. NW-3 sums elements (2 pi, 2 pi + 1) of the partial rows seg, seg + S, ...
   const int npair = ncol2 >> 1;
   const int S = min(NFT / npair, 3 * LPC);   // segments: the second level below sums three of them per lane, LPC lanes per column
-  const int f_pi = tid % npair, f_seg = tid / npair;
-  const bool f_on = tid < NFT && f_seg < S;
+  const int f_tid = SHARED ? tid : (wv < 2 ? tid : (wv >= 4 && wv < 6 ? tid - 128 : NFT));      // index among the fan-in threads
+  const bool f_wave = f_tid < NFT;
+  const int f_pi = f_tid % npair, f_seg = f_tid / npair;
+  const bool f_on = f_wave && f_seg < S;
 
   // ---- the solve waves run a loop of their own (same barriers, none of the workers' registers): the kernel's register allocation
   //      is the larger of the two roles, not their sum ----
@@ -656,12 +676,10 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
       if (p.coef_update) { ps_bar(); ps_bar(); }
       ps_bar();
       ps_bar(); ps_bar();
-      if constexpr (MASKED) {                                     // the Gram hand-off of the next step: three barriers, one exit
+      if constexpr (MASKED) {                                     // the Gram hand-off of the next step: two barriers, one exit
         ps_bar();
         if (lds_word(s_ctl) != 0) break;
-        ps_bar(); ps_bar();
-      } else {
-        if (p.eta_full) ps_bar();
+        ps_bar();
       }
       ps_bar();
       carried = dual;
@@ -700,7 +718,7 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
           if (stop) *reinterpret_cast<volatile int*>(s_ctl) = stop;
           *reinterpret_cast<volatile int*>(s_ctl + 1) = (int)epoch;
         }
-      } else {
+      } else if (f_wave) {
         while (lds_word(s_ctl + 1) < (int)epoch) __builtin_amdgcn_s_sleep(1);      // (wave 0 always sets it, bounded by its own timeout)
       }
       asm volatile("" ::: "memory");
@@ -852,27 +870,45 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
         if (!MASKED) gp += Gv[m] * pb;
       }
     }
+    if (!MASKED && p.eta_full) {      // <G, Pbar>: the waves' shares go out with the column reduction's own barriers
+      const double x = ps_wave_sum(worker ? gp : 0.0);
+      if (lane == 0) s4[wv] = x;
+    }
     hub_col_reduce<RPAD, NWK>(worker, part, s_red, s_vec);        // s_vec = V mu_bar
     const double sN = ps_wave_sum(lane < r ? s_mub[lane] * s_vec[lane] : 0.0);
     double eta = rho * p.rho_mean;
     if constexpr (MASKED) {
-      // ---- phase C: the masked Gram of the NEXT step, summed by the row workgroups slice by slice (psmf_pstep.hip: pstep_rows) ----
-      if (wv == 0) {
+      // ---- phase C: the masked Gram of the NEXT step, summed by the row workgroups slice by slice (pstep_rows); it arrives as
+      //      tagged granules: every wave of the loop re-reads its elements until their tags carry the epoch ----
+      {
+        const u64* gsl = reinterpret_cast<const u64*>(q.gslice);
+        constexpr int NEL = (NTT * 256 + 1 + NLT - 1) / NLT;      // elements per thread
         const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
         int stop = 0;
         for (;;) {
           bool ok = true;
-          for (int b = lane; b < nwg; b += 64) ok &= __hip_atomic_load(q.sflags + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= epoch;
+          u64 lo[NEL], hi[NEL];
+#pragma unroll
+          for (int k = 0; k < NEL; ++k) {
+            const int e = min(tid + k * NLT, q.nge - 1);
+            lo[k] = gran_load(gsl + 2 * e);
+            hi[k] = gran_load(gsl + 2 * e + 1);
+          }
+#pragma unroll
+          for (int k = 0; k < NEL; ++k) {
+            ok &= (unsigned)(lo[k] >> 32) == epoch && (unsigned)(hi[k] >> 32) == epoch;
+            const int e = tid + k * NLT;
+            if (e < q.nge) s_gm[e] = __hiloint2double((int)(unsigned)hi[k], (int)(unsigned)lo[k]);
+          }
           if (__all((int)ok)) break;
-          __builtin_amdgcn_s_sleep(1);
+          __builtin_amdgcn_s_sleep(2);
           if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > PSTEP_SPIN_TICKS) { stop = 2; break; }
         }
-        if (lane == 0 && stop) *reinterpret_cast<volatile int*>(s_ctl) = stop;
+        if (stop && lane == 0) *reinterpret_cast<volatile int*>(s_ctl) = stop;
       }
       ps_bar();
+      PS_PROFM(9);      // masked: the reduced Gram of the next step is in LDS
       if (lds_word(s_ctl) != 0) break;
-      for (int e = tid; e < q.nge; e += NLT) s_gm[e] = wt_load(q.gslice + e);
-      ps_bar();
 #pragma unroll
       for (int m = 0; m < M; ++m) {
         if (val[m]) {
@@ -886,15 +922,13 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
       if (lane == 0) s4[wv] = x;
       ps_bar();
       eta = (rho * nobs + ((s4[0] + s4[1]) + (s4[2] + s4[3]))) / dd;      // divided by d, not by the observed count (PSMF.py:77)
+      PS_PROFM(10);     // masked: reduced Gram gathered, eta
       if (tid == 0 && p.sc_hist) {
         long long tr_ = knext - p.series_t0;
         if (tr_ > (long long)p.mask_rows - 1) tr_ = (long long)p.mask_rows - 1;      // (the step after the last of the series: never run)
         if (knext - p.series_t0 <= (long long)p.mask_rows - 1) { p.sc_hist[2 * tr_] = sN; p.sc_hist[2 * tr_ + 1] = eta; }
       }
     } else if (p.eta_full) {
-      double x = ps_wave_sum(worker ? gp : 0.0);
-      if (lane == 0) s4[wv] = x;
-      ps_bar();
       eta += ((s4[0] + s4[1]) + (s4[2] + s4[3])) / dd;
     }
     PS_PROF(6);        // V mu_bar, s, eta
@@ -905,6 +939,21 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
       w_t = s_vec[tid];
       s_w[tid] = w_t;
       s_wn[tid] = w_t * iNn;
+    }
+    // packet of the next step, by wave 0 alone and at once: mu_bar and w / N were written by this wave (r <= 32 < 64: LDS operations
+    // of one wave complete in order), so nothing on the way to the row workgroups waits for a workgroup barrier
+    if (wv == 0 && s + 1 < q.n_steps) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int gm_ = 0; gm_ < (NG + 63) / 64; ++gm_) {
+        const int gI = lane + 64 * gm_;
+        if (gI < NG) {
+          const int e = gI >> 1;
+          const double v = gI == NG - 1 ? 0.0 : (e < RPAD ? s_mub[e] : s_wn[e - RPAD]);
+          const unsigned half = gI == NG - 1 ? 0u : ((gI & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v));
+          gran_store(q.pkt + gI, epoch + 1u, half);
+        }
+      }
     }
     if (!dual) {      // inversions one after the other: the solve wave starts from Pbar
 #pragma unroll
@@ -919,15 +968,6 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
     n_done = s + 1;
     ps_bar();
     PS_PROF(7);        // w / N, solve operands, barrier
-    // packet of the next step
-    if (s + 1 < q.n_steps) {
-      for (int gI = tid; gI < NG; gI += NLT) {
-        const int e = gI >> 1;
-        const double v = gI == NG - 1 ? 0.0 : (e < RPAD ? s_mub[e] : s_wn[e - RPAD]);
-        const unsigned half = gI == NG - 1 ? 0u : ((gI & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v));
-        gran_store(q.pkt + gI, epoch + 1u, half);
-      }
-    }
     PS_PROF(8);        // packet out
   }
   PS_PROF_OUT(0, 16, tid == 0);
@@ -1037,9 +1077,9 @@ bool pstep_plan(int d_local, int r, int n_cu, bool storage_f64, bool masked, Pst
   np = pstep_np_variant(rpad, np);       // the kernel instance runs exactly this many passes: fewer, fuller workgroups
   rows = np * rpw;
   nwg = (d_local + rows - 1) / rows;
-  {      // the hub's fan-in: (threads of its six fan-in waves / pairs of columns, at most 24) segments x PSTEP_FANIN_ROWS rows each
+  {      // the hub's fan-in: (threads of its four fan-in waves / pairs of columns, at most 24) segments x PSTEP_FANIN_ROWS rows each
     const int npair = ((r + 1 + 1) & ~1) / 2;
-    int S = (6 * 64) / npair;
+    int S = (4 * 64) / npair;
     if (S > 24) S = 24;
     if (nwg > S * PSTEP_FANIN_ROWS) return false;
   }
@@ -1049,21 +1089,22 @@ bool pstep_plan(int d_local, int r, int n_cu, bool storage_f64, bool masked, Pst
   out->ncol2 = (r + 1 + 1) & ~1;
   const size_t fl = (((size_t)nwg * sizeof(unsigned)) + 15) & ~(size_t)15;
   const size_t pk = (((size_t)PSTEP_PKT_MAX * sizeof(unsigned long long)) + 15) & ~(size_t)15;
-  // the zeroed block: | flags of the (h, ee) hand-off | flags of the Gram partials | flags of the Gram slices | packet |
+  // the zeroed block: | flags of the (h, ee) hand-off | flags of the Gram partials | (spare) | packet | granules of the reduced Gram |
+  const int ntg = rpad > 16 ? 2 : 1;
+  const int nge = masked ? ntg * (ntg + 1) / 2 * 256 + 1 : 0;
+  const size_t gs = ((size_t)2 * nge * sizeof(unsigned long long) + 15) & ~(size_t)15;
   out->off_gflags = fl;
   out->off_sflags = 2 * fl;
   out->off_pkt = 3 * fl;
-  out->zero_bytes = 3 * fl + pk;
+  out->off_gslice = 3 * fl + pk;
+  out->zero_bytes = 3 * fl + pk + gs;
   out->off_part = (out->zero_bytes + 255) & ~(size_t)255;
   size_t end = out->off_part + (size_t)nwg * out->ncol2 * sizeof(double);
-  out->nge = 0; out->slice_len = 0; out->off_gpart = 0; out->off_gslice = 0;
+  out->nge = nge; out->slice_len = 0; out->off_gpart = 0;
   if (masked) {
-    const int ntg = rpad > 16 ? 2 : 1;
-    out->nge = ntg * (ntg + 1) / 2 * 256 + 1;
-    out->slice_len = (out->nge + nwg - 1) / nwg;
+    out->slice_len = (nge + nwg - 1) / nwg;
     out->off_gpart = (end + 255) & ~(size_t)255;
-    out->off_gslice = (out->off_gpart + (size_t)nwg * out->nge * sizeof(double) + 255) & ~(size_t)255;
-    end = out->off_gslice + (size_t)nwg * out->slice_len * sizeof(double);
+    end = out->off_gpart + (size_t)nwg * nge * sizeof(double);
   }
   out->total_bytes = end;
   return true;

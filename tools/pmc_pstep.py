@@ -4,7 +4,19 @@ persistent per-step kernel (gfx950 correction: FETCH_SIZE x 2 for wide coalesced
     python tools/pmc_pstep.py out.json <fetch_dir> <write_dir> d r T storage_bytes
 """
 import json, sys
-from pmc_summary import summarise
+import collections, csv, glob, os
+
+
+def summarise(d, counter):
+    """per kernel: launches, mean / min / max of the counter (KB).  (pmc_summary.summarise cuts kernel names at the first "(", which
+    is inside "(anonymous namespace)" for this kernel: own parser.)"""
+    acc = collections.defaultdict(list)
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row.get("Counter_Name") == counter:
+                acc[row["Kernel_Name"]].append(float(row["Counter_Value"]))
+    return {k: dict(launches=len(v), mean_KB=sum(v) / len(v), min_KB=min(v), max_KB=max(v)) for k, v in acc.items()}
+
 
 out, fdir, wdir = sys.argv[1:4]
 d, r, T, es = (int(x) for x in sys.argv[4:8])
