@@ -76,7 +76,8 @@ typedef struct {
   int32_t storage;       /* psmf_dtype of C, y, y_pred in HBM (arithmetic on r x r is f64)    */
   int32_t store_y_pred;  /* keep y_hat_k = C_{k-1} mu_bar_k for every step (psmf.py:93)       */
   int32_t recursive;     /* 1: PSMFRecursive -- Adam step on theta inside the time loop every
-                            `update_every` steps (psmf.py:287-304)                            */
+                            `update_every` steps (psmf.py:287-304); 2: the same with plain SGD
+                            (psmf.py:244-248; learning rate = adam_lr / its schedule)           */
   int32_t update_every;
   int32_t gram_refresh;  /* recompute G = C^T C exactly every this many steps (0 = only at
                             set_state); between refreshes G is updated algebraically           */

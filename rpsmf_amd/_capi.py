@@ -165,7 +165,7 @@ class DeviceFilter:
             robust=int(robust), coef_update=int(coef_update), eta_full=int(eta_full),
             pbar_predict=int(pbar_predict), fixed_lambda=int(fixed_lambda), dyn_kind=int(dyn_kind),
             n_theta=self.n_theta, storage=self.storage, store_y_pred=int(store_y_pred),
-            recursive=int(recursive), update_every=int(update_every), gram_refresh=int(gram_refresh),
+            recursive=int(recursive), update_every=int(update_every), gram_refresh=int(gram_refresh),      # recursive: 1 / True in-loop Adam, 2 in-loop SGD
             device=int(device), use_graph=int(use_graph), n_workgroups=int(n_workgroups),
             engine={"auto": 0, "step": 1, "block": 2}.get(engine, engine), dyn_flags=int(dyn_flags), dyn_terms=int(dyn_terms), nonuniform_R=int(bool(nonuniform_R)), masked=int(masked),
             alpha=float(alpha), beta=float(beta), adam_lr=float(adam_lr), adam_lr_end=float(adam_lr_end),

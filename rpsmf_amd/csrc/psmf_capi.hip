@@ -353,7 +353,7 @@ bool blk_seq_ok(const psmf_filter* h) {
   const int kd = h->cfg.dyn_kind;
   const bool diag_dyn = kd == PSMF_DYN_RANDOM_WALK || kd == PSMF_DYN_COS_PHASE || (kd == PSMF_DYN_SINUSOID && !(h->cfg.dyn_flags & 1));
   return h->sw.filter4 && h->sw.filter3 && h->sw.block_dual && h->q_iso && h->cfg.coef_update && h->cfg.pbar_predict && h->cfg.eta_full && diag_dyn &&
-         h->cfg.r <= 32;
+         h->cfg.r <= 32 && h->cfg.recursive != 2;      // (in-loop SGD: the kernels with dyn_adam_step carry it, filter4 / filter5 have an Adam step of their own)
 }
 
 // filter5: the simplified hook configuration (no coefficient update, eta = tr(R) / d, P_bar = P) with diagonal-Jacobian dynamics
@@ -361,7 +361,7 @@ bool blk_simpl_ok(const psmf_filter* h) {
   const int kd = h->cfg.dyn_kind;
   const bool diag_dyn = kd == PSMF_DYN_RANDOM_WALK || kd == PSMF_DYN_COS_PHASE || (kd == PSMF_DYN_SINUSOID && !(h->cfg.dyn_flags & 1));
   return h->sw.filter4 && h->sw.filter3 && !h->cfg.coef_update && !h->cfg.eta_full && !h->cfg.pbar_predict && diag_dyn && h->cfg.r <= 32 &&
-         !h->sp.q_sched;
+         !h->sp.q_sched && h->cfg.recursive != 2;
 }
 
 // The ONE place that decides which kernel advances the coefficient-space state of a block: launch_blk_filter switches on it
@@ -893,6 +893,7 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
     return fail(nullptr, PSMF_ERR_ARG, "psmf_create: n_theta does not match dyn_kind / dyn_flags / dyn_terms (see psmf_dyn_kind)");
   if (cfg->dyn_kind == PSMF_DYN_HOST && cfg->recursive) return fail(nullptr, PSMF_ERR_ARG, "psmf_create: host-stepped dynamics keep theta (and its optimiser) on the host");
   if (cfg->recursive && cfg->update_every < 1) return fail(nullptr, PSMF_ERR_ARG, "psmf_create: update_every must be >= 1");
+  if (cfg->recursive < 0 || cfg->recursive > 2) return fail(nullptr, PSMF_ERR_ARG, "psmf_create: recursive must be 0, 1 (in-loop Adam) or 2 (in-loop SGD)");
   if (cfg->masked < 0 || cfg->masked > 3) return fail(nullptr, PSMF_ERR_ARG, "psmf_create: masked must be 0 .. 3");
   if (cfg->masked >= 2 && (cfg->robust || cfg->dyn_kind != PSMF_DYN_RANDOM_WALK))
     return fail(nullptr, PSMF_ERR_ARG, "psmf_create: masked = 2 (MLE-SMF) / 3 (TMF) are random-walk, non-robust filters");

@@ -223,13 +223,22 @@ __device__ __forceinline__ void dyn_backward(const StepParams& p, const double t
   __syncthreads();
 }
 
-// Adam step on theta inside the time loop (PSMFRecursive, psmf.py:224-242,299-304): bias correction with the step index,
+// Optimiser step on theta inside the time loop (PSMFRecursive, psmf.py:224-248,299-304; StepParams.recursive = 1 Adam, 2 SGD): bias correction with the step index,
 // projection theta >= 0, gradient sum restarted.  All NTH threads; ends with a barrier.
 template <int NTH>
 __device__ __forceinline__ void dyn_adam_step(const StepParams& p, const long long knext, const int tid) {
   const double kk = (double)knext;
   const double lr = p.lr_steps > 0.0 ? p.lr * pow(p.lr_end / p.lr, kk / p.lr_steps) : p.lr;
   const double c1 = 1.0 / (1.0 - pow(p.b1, kk)), c2 = 1.0 / (1.0 - pow(p.b2, kk));
+  if (p.recursive == 2) {      // plain SGD (psmf.py:244-248): theta <- max(theta - lr g, 0)
+    for (int idx = tid; idx < p.n_theta; idx += NTH) {
+      p.theta[idx] = fmax(p.theta[idx] - lr * p.gradsum[idx], 0.0);
+      p.gradsum[idx] = 0.0;
+    }
+    __threadfence_block();
+    __syncthreads();
+    return;
+  }
   for (int idx = tid; idx < p.n_theta; idx += NTH) {
     const double gs = p.gradsum[idx];
     const double am = p.b1 * p.adam_m[idx] + (1.0 - p.b1) * gs;

@@ -721,13 +721,17 @@ __device__ __forceinline__ void serial_body(const StepParams& p, const int first
       if (p.recursive && (knext % p.update_every) == 0) {
         const double kk = (double)knext;
         const double lr = p.lr_steps > 0.0 ? p.lr * pow(p.lr_end / p.lr, kk / p.lr_steps) : p.lr;
-        am = p.b1 * am + (1.0 - p.b1) * gsum;
-        av = p.b2 * av + (1.0 - p.b2) * gsum * gsum;
-        p.adam_m[tid] = am;
-        p.adam_v[tid] = av;
-        const double mh = am / (1.0 - pow(p.b1, kk));
-        const double vh = av / (1.0 - pow(p.b2, kk));
-        theta = fmax(theta - lr * mh / (sqrt(vh) + 1e-8), 0.0);
+        if (p.recursive == 2) {           // plain SGD (psmf.py:244-248)
+          theta = fmax(theta - lr * gsum, 0.0);
+        } else {
+          am = p.b1 * am + (1.0 - p.b1) * gsum;
+          av = p.b2 * av + (1.0 - p.b2) * gsum * gsum;
+          p.adam_m[tid] = am;
+          p.adam_v[tid] = av;
+          const double mh = am / (1.0 - pow(p.b1, kk));
+          const double vh = av / (1.0 - pow(p.b2, kk));
+          theta = fmax(theta - lr * mh / (sqrt(vh) + 1e-8), 0.0);
+        }
         p.theta[tid] = theta;
         gsum = 0.0;
       }

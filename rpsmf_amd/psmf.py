@@ -722,24 +722,27 @@ class PSMFIter:
 
 
 def _device_optimiser(obj):
-    """Keyword arguments of the in-loop optimiser the device implements -- Adam (psmf.py:224-242) with a constant or an
-    exponentially decaying learning rate (learning_rate.py:13-27) -- or None: SGD (psmf.py:244-248) and custom
-    learning-rate schedules keep theta and its optimiser on the host (host-stepped device loop)."""
-    if obj.optim != "adam":
+    """Keyword arguments of the in-loop optimiser the device implements -- Adam (psmf.py:224-242) or plain SGD (psmf.py:244-248),
+    each with a constant or an exponentially decaying learning rate (learning_rate.py:13-27) -- or None: custom learning-rate
+    schedules keep theta and its optimiser on the host (host-stepped device loop)."""
+    if obj.optim == "adam":
+        gam, kind = getattr(obj, "adam_gam", ConstantLearningRate(1e-3)), 1
+    elif obj.optim == "sgd":
+        gam, kind = getattr(obj, "sgd_gam", ConstantLearningRate(1e-3)), 2
+    else:
         return None
-    gam = getattr(obj, "adam_gam", ConstantLearningRate(1e-3))
     if isinstance(gam, ConstantLearningRate):
-        return dict(adam_lr=gam.lr)
+        return dict(recursive=kind, adam_lr=gam.lr)
     if hasattr(gam, "lr_start") and hasattr(gam, "lr_end") and hasattr(gam, "steps"):
-        return dict(adam_lr=gam.lr_start, adam_lr_end=gam.lr_end, adam_lr_steps=gam.steps)
+        return dict(recursive=kind, adam_lr=gam.lr_start, adam_lr_end=gam.lr_end, adam_lr_steps=gam.steps)
     return None
 
 
 def _recursive_kwargs(obj, kw):
-    """Adds the in-loop Adam configuration (psmf.py:224-242,299-304) to the device options."""
+    """Adds the in-loop optimiser's configuration (psmf.py:224-248,299-304) to the device options: recursive = 1 Adam, 2 SGD."""
     if kw.get("dyn_kind") == _capi.DYN_HOST:
-        return kw               # host-stepped: theta and its optimiser (Adam or SGD, any schedule) stay on the host
-    kw.update(recursive=True, update_every=getattr(obj, "_update_every", 1),
+        return kw               # host-stepped: theta and its optimiser (any schedule) stay on the host
+    kw.update(update_every=getattr(obj, "_update_every", 1),
               adam_b1=getattr(obj, "adam_b1", 0.9), adam_b2=getattr(obj, "adam_b2", 0.999), **_device_optimiser(obj))
     return kw
 
@@ -810,7 +813,7 @@ class PSMFRecursive(PSMFIter):
             self._mu_pred[k] = self._nl(last_theta, self._mu_pred[k - 1], k)
             self._y_pred[k] = self._C[T] @ self._mu_pred[k]
 
-    # device: Adam runs inside the time loop of either engine; SGD / custom schedules: host-stepped
+    # device: Adam and plain SGD run inside the time loop of either engine; custom learning-rate schedules: host-stepped
     def _host_stepped(self):
         return _recursive_host_stepped(self, super()._host_stepped())
 
@@ -826,7 +829,8 @@ class PSMFRecursive(PSMFIter):
         if self._host_stepped():
             return self._after_device_epoch(self._run_host_stepped(1, T, recursive=True), T)
         self._dev.zero_gradsum()
-        self._dev.set_adam(self.adam_m.reshape(-1), self.adam_v.reshape(-1))
+        if self.optim == "adam":
+            self._dev.set_adam(self.adam_m.reshape(-1), self.adam_v.reshape(-1))
         self._dev.run(0, T)
         s = self._pull_state(T)
         self._theta[T] = s["theta"].reshape(np.asarray(self.theta0).shape)

@@ -341,16 +341,18 @@ def test_tracking_error_norms_on_device():
     assert f._tracking_on_device == 2 and len(f._logs) == 2
 
 
+@pytest.mark.parametrize("engine", ["step", "block"])
 @pytest.mark.parametrize("robust", [False, True], ids=["PSMF", "rPSMF"])
-def test_recursive_sgd_runs_host_stepped(robust):
-    """SGD inside the recursive loop (psmf.py:244-248,299-304) is not an optimiser the device kernels carry: theta and the
-    optimiser stay on the host, the device advances one step at a time -- same numbers as the numpy back end."""
+def test_recursive_sgd_in_the_device_loop(robust, engine):
+    """SGD inside the recursive loop (psmf.py:244-248,299-304) runs in the device loops since round 5 (psmf_config.recursive = 2:
+    the persistent per-step kernel, the launched serial stage and the blocked kernels that share dyn_adam_step) -- same numbers as the
+    numpy back end, which executes the reference's hook sequence."""
     g = load_golden("rpsmf_recursive" if robust else "psmf_recursive")
     T, n_pred, ue = int(g["T"]), int(g["n_pred"]), int(g["update_every"])
     d, r = g["C0"].shape
     theta0, mu0 = g["theta0"].reshape(-1, 1), g["mu0"].reshape(-1, 1)
     out = []
-    for kw in (dict(storage="f64"), dict(backend="numpy")):
+    for kw in (dict(storage="f64", engine=engine), dict(backend="numpy")):
         nl = psmf.CosPhase(r)
         if robust:
             f = psmf.rPSMFRecursive(theta0, g["C0"], g["V0"], mu0, g["P0"], g["Q"], np.eye(d), 1.8, nl, optim="sgd", **kw)
@@ -362,6 +364,35 @@ def test_recursive_sgd_runs_host_stepped(robust):
         f.step(ydict(g["Y"]), T)
         f.predict(T, n_pred)
         out.append((f._theta[T].reshape(-1), f._C[T], np.array([f._y_pred[k].reshape(-1) for k in range(1, T + n_pred + 1)])))
+        if "storage" in kw:
+            assert f._dev.dyn_kind == _capi().DYN_COS_PHASE          # evaluated on the device, theta stepped there
+            kern = f._dev.geometry()["filter_kernel"]
+            assert kern == ("psmf_pstep_k" if engine == "step" else kern) and kern not in ("psmf_blk_filter4", "psmf_blk_filter4s", "psmf_blk_filter5")
+    for a, b in zip(*out):
+        assert relerr(a, b) < 1e-9
+
+
+def test_recursive_custom_learning_rate_schedule_stays_host_stepped():
+    """An in-loop optimiser with a learning-rate schedule the device does not implement (here: a step function of k) keeps theta and the
+    optimiser on the host, the device advances one step at a time -- same numbers as the numpy back end."""
+    from rpsmf_amd.learning_rate import BaseLearningRate
+
+    class Steps(BaseLearningRate):
+        def get(self, t):
+            return 1e-7 if t < 20 else 5e-8
+
+    g = load_golden("psmf_recursive")
+    T, n_pred, ue = int(g["T"]), int(g["n_pred"]), int(g["update_every"])
+    d, r = g["C0"].shape
+    theta0, mu0 = g["theta0"].reshape(-1, 1), g["mu0"].reshape(-1, 1)
+    out = []
+    for kw in (dict(storage="f64"), dict(backend="numpy")):
+        f = psmf.PSMFRecursive(theta0, g["C0"], g["V0"], mu0, g["P0"], {k: g["Q"] for k in range(T + 1)},
+                               {k: np.eye(d) for k in range(T + 1)}, psmf.CosPhase(r), optim="sgd", **kw)
+        f._update_every = ue
+        f.optim_init(gam=Steps())
+        f.step(ydict(g["Y"]), T)
+        out.append((f._theta[T].reshape(-1), f._C[T]))
         if "storage" in kw:
             assert f._dev.dyn_kind == _capi().DYN_HOST
     for a, b in zip(*out):
