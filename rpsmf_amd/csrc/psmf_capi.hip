@@ -114,6 +114,8 @@ struct psmf_filter {
   int engine = 1;              // 1 per-step, 2 blocked
   int block_steps = 0;         // B = RB - r
   bool q_iso = false;          // Q = q I with q > 0 as last uploaded (two-group block filter applies)
+  double q_last = 0.0, p_diag_max = 0.0;      // Q[0][0] and max_i P[i][i] as last uploaded: the give-up policy of the Newton-Schulz starts (update_ns_policy)
+  bool ns_far_env = false, ns_skip_env = false;
   double* Kpart = nullptr;
   double* Kmat = nullptr;
   double* Acoef = nullptr;     // 2 x RB x RM   (ping-pong across pipelined blocks)
@@ -795,6 +797,18 @@ int launch_pstep(psmf_filter* h, int64_t k_begin, int64_t n) {
   return PSMF_OK;
 }
 
+// Give-up policy of filter3's Newton-Schulz starts (docs/MEASUREMENTS.md round 5).  A start whose residual exceeds
+// `far` is abandoned for the pivot-exact LDS sweep (15 us) and the next `skip` steps sweep unasked.  Where Lbar' = (I / q - W / q^2) / omega
+// cancels -- eigenvalues of Pbar far above q: the adversarial Q = 1e-8 -- every early step that iterates instead of sweeping costs
+// accuracy, so the conservative 0.3 / 3 stays; everywhere else (max diag P / q <= 1e3: at most three digits cancel) 0.9 / 1 takes
+// config E's cold pass from 36.5 to 35.5 ms with unchanged errors (full-size and adversarial suites under it: profiles/r5_ns_far_policy.txt).
+// PSMF_NS_FAR / PSMF_NS_SKIP override both.
+void update_ns_policy(psmf_filter* h) {
+  const bool benign = h->q_iso && h->q_last > 0.0 && h->p_diag_max <= 1e3 * h->q_last;
+  if (!h->ns_far_env) { const double f = benign ? 0.9 : 0.3; h->sp.ns_far2 = f * f; }
+  if (!h->ns_skip_env) h->sp.ns_skip_n = benign ? 1 : 3;
+}
+
 int set_device(psmf_handle h) {
   HIP_TRY(h, hipSetDevice(h->cfg.device));
   return PSMF_OK;
@@ -1102,6 +1116,8 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
   const double ns_far = getenv("PSMF_NS_FAR") ? atof(getenv("PSMF_NS_FAR")) : 0.3;
   sp.ns_far2 = ns_far * ns_far;
   sp.ns_skip_n = getenv("PSMF_NS_SKIP") ? atoi(getenv("PSMF_NS_SKIP")) : 3;
+  h->ns_far_env = getenv("PSMF_NS_FAR") != nullptr;          // (otherwise psmf_set_state picks 0.9 / 1 where nothing cancels: update_ns_policy)
+  h->ns_skip_env = getenv("PSMF_NS_SKIP") != nullptr;
   sp.alpha = cfg->alpha; sp.beta = cfg->beta;
   sp.lr = cfg->adam_lr; sp.lr_end = cfg->adam_lr_end; sp.lr_steps = cfg->adam_lr_steps;
   sp.b1 = cfg->adam_b1; sp.b2 = cfg->adam_b2;
@@ -1199,7 +1215,12 @@ int psmf_set_state(psmf_handle h, const double* C, const double* V, const double
   }
   const size_t rr = (size_t)r * r * sizeof(double);
   if (V) HIP_TRY(h, hipMemcpy(h->st->V, V, rr, hipMemcpyHostToDevice));
-  if (P) HIP_TRY(h, hipMemcpy(h->st->P, P, rr, hipMemcpyHostToDevice));
+  if (P) {
+    HIP_TRY(h, hipMemcpy(h->st->P, P, rr, hipMemcpyHostToDevice));
+    double m = 0.0;
+    for (int i = 0; i < r; ++i) m = std::fmax(m, std::fabs(P[(size_t)i * r + i]));
+    h->p_diag_max = m;
+  }
   if (Q) {
     HIP_TRY(h, hipMemcpy(h->st->Q, Q, rr, hipMemcpyHostToDevice));
     bool iso = Q[0] > 0.0;
@@ -1207,6 +1228,7 @@ int psmf_set_state(psmf_handle h, const double* C, const double* V, const double
       for (int c = 0; c < r; ++c)
         if (Q[i * r + c] != (i == c ? Q[0] : 0.0)) { iso = false; break; }
     h->q_iso = iso;
+    h->q_last = Q[0];
     update_solve_dual(h);
   }
   if (mu) HIP_TRY(h, hipMemcpy(h->st->mu, mu, r * sizeof(double), hipMemcpyHostToDevice));
@@ -1216,6 +1238,7 @@ int psmf_set_state(psmf_handle h, const double* C, const double* V, const double
   if (!std::isnan(lambda0)) HIP_TRY(h, hipMemcpy(&h->st->lam, &lambda0, sizeof(double), hipMemcpyHostToDevice));
   { const int zero = 0; HIP_TRY(h, hipMemcpy(&h->st->ns_valid, &zero, sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY(h, hipMemcpy(&h->st->err, &zero, sizeof(int), hipMemcpyHostToDevice)); }   // a new state clears a sticky numeric error
+  if (P || Q) update_ns_policy(h);
   if (C && V && P && mu) h->have_state = true;
   h->need_prep = true;
   return PSMF_OK;
