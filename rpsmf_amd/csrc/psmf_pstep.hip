@@ -78,6 +78,13 @@ __device__ __forceinline__ double ps_wave_sum(double v) {
   return (readlane_f64(v, 0) + readlane_f64(v, 16)) + (readlane_f64(v, 32) + readlane_f64(v, 48));
 }
 
+// sin / cos / pow of the cos-phase dynamics and the in-loop optimiser, OUT of line: inlined, their range reduction and polynomial
+// temporaries (60-100 registers each) pushed the hub's loop over 256 registers and the spills landed on the common path -- 21 spilled
+// registers cost 1.4 us per timestep (9.4 -> 10.8) for filters that never call them (random walk: n_theta = 0)
+__device__ __attribute__((noinline)) double ps_sin(double x) { return sin(x); }
+__device__ __attribute__((noinline)) double ps_cos(double x) { return cos(x); }
+__device__ __attribute__((noinline)) double ps_pow(double a, double b) { return pow(a, b); }
+
 // workgroup barrier that orders LDS traffic only: __syncthreads() also drains vmcnt, and every wave here keeps global stores
 // (y_hat, the mean history, hand-off words) in flight that nothing inside the launch reads back through the cache
 __device__ __forceinline__ void ps_bar() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -142,6 +149,7 @@ __device__ __forceinline__ void pstep_rows(const PstepParams& q, char* smem) {
   const int row_begin = wg * q.rows_per_wg;
   const int row_end = min(row_begin + q.rows_per_wg, dl);
 
+  const u64* pkt_mine = q.pkt + (size_t)(wg % PSTEP_PKT_REP) * (PSTEP_REP_STRIDE / 8);      // this workgroup's replica of the packet
   unsigned* s_pkt32 = reinterpret_cast<unsigned*>(smem);                   // NG words (8-byte aligned doubles inside)
   double* s_red = reinterpret_cast<double*>(smem + 2048);                  // NW x (RPAD + 1)
   int* s_ctl = reinterpret_cast<int*>(smem + 2048 + NW * (RPAD + 1) * 8);  // [0] stop
@@ -220,7 +228,7 @@ __device__ __forceinline__ void pstep_rows(const PstepParams& q, char* smem) {
 #pragma unroll
         for (int m = 0; m < NGL; ++m) {
           const int k = lane + 64 * m;
-          const u64 x = gran_load(q.pkt + min(k, NG - 1));
+          const u64 x = gran_load(pkt_mine + min(k, NG - 1));
           val[m] = (unsigned)x;
           const unsigned tag = (unsigned)(x >> 32);
           ok &= (k >= NG) || tag == epoch;
@@ -366,7 +374,7 @@ __device__ __forceinline__ void pstep_rows(const PstepParams& q, char* smem) {
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // EVERY storing wave, then the barrier, then one flag
       ps_bar();
-      if (tid == 0) __hip_atomic_store(q.gflags + wg, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (tid < PSTEP_GF_REP) __hip_atomic_store(q.gflags + (size_t)tid * (PSTEP_REP_STRIDE / 4) + wg, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // every replica
       PS_PROFM(5);    // masked Gram of the next step: slabs, matrix cores, wave sums, partial out, drained, flag
       // ---------- reduce-scatter: this workgroup sums ITS elements of the Gram over all workgroups' partials (fixed order) ----------
       const int nwg = q.n_row_wg, SL = q.slice_len, e0 = wg * SL;
@@ -376,7 +384,7 @@ __device__ __forceinline__ void pstep_rows(const PstepParams& q, char* smem) {
         int stop = 0;
         for (;;) {
           bool ok = true;
-          for (int b = lane; b < nwg; b += 64) ok &= __hip_atomic_load(q.gflags + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= epoch;
+          for (int b = lane; b < nwg; b += 64) ok &= __hip_atomic_load(q.gflags + (size_t)(wg % PSTEP_GF_REP) * (PSTEP_REP_STRIDE / 4) + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= epoch;
           if (__all((int)ok)) break;
           __builtin_amdgcn_s_sleep(1);
           if ((long long)__builtin_amdgcn_s_memrealtime() - t0 > PSTEP_SPIN_TICKS) { stop = 2; break; }
@@ -644,7 +652,8 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
     const int e = gI >> 1;
     const double v = gI == NG - 1 ? 0.0 : (e < RPAD ? s_mub[e] : s_wn[e - RPAD]);
     const unsigned half = gI == NG - 1 ? 0u : ((gI & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v));
-    gran_store(q.pkt + gI, 1u, half);
+#pragma unroll
+    for (int rep = 0; rep < PSTEP_PKT_REP; ++rep) gran_store(q.pkt + (size_t)rep * (PSTEP_REP_STRIDE / 8) + gI, 1u, half);
   }
 
   // fan-in geometry: thread t of waves 0 .. NW-3 sums elements (2 pi, 2 pi + 1) of the partial rows seg, seg + S, ...
@@ -786,7 +795,7 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
     if (tl) {
       const double tk = (double)(k0 + 1);
       const double arg = 2.0 * M_PI * theta * tk + mu_old;
-      const double jt = -sin(arg) * (2.0 * M_PI * tk);
+      const double jt = -ps_sin(arg) * (2.0 * M_PI * tk);
       const double wi = w_t, hi = s_he[tid];
       double gf;
       if (p.robust) {
@@ -833,14 +842,14 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
     if (tl) {
       if (p.recursive && (knext % p.update_every) == 0) {
         const double kk = (double)knext;
-        const double lr = p.lr_steps > 0.0 ? p.lr * pow(p.lr_end / p.lr, kk / p.lr_steps) : p.lr;
+        const double lr = p.lr_steps > 0.0 ? p.lr * ps_pow(p.lr_end / p.lr, kk / p.lr_steps) : p.lr;
         if (p.recursive == 2) {           // plain SGD (psmf.py:244-248)
           theta = fmax(theta - lr * gsum, 0.0);
         } else {
           am = p.b1 * am + (1.0 - p.b1) * gsum;
           av = p.b2 * av + (1.0 - p.b2) * gsum * gsum;
-          const double mh = am / (1.0 - pow(p.b1, kk));
-          const double vh = av / (1.0 - pow(p.b2, kk));
+          const double mh = am / (1.0 - ps_pow(p.b1, kk));
+          const double vh = av / (1.0 - ps_pow(p.b2, kk));
           theta = fmax(theta - lr * mh / (sqrt(vh) + 1e-8), 0.0);
         }
         gsum = 0.0;
@@ -855,8 +864,8 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
       double mb = mu_new, f = 1.0;
       if (p.dyn_kind == 1) {   // cos(2 pi theta t + x)
         const double arg = 2.0 * M_PI * theta * (double)(knext + 1) + mu_new;
-        mb = cos(arg);
-        f = -sin(arg);
+        mb = ps_cos(arg);
+        f = -ps_sin(arg);
       }
       s_mub[tid] = mb;
       s_f[tid] = f;
@@ -955,7 +964,8 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
           const int e = gI >> 1;
           const double v = gI == NG - 1 ? 0.0 : (e < RPAD ? s_mub[e] : s_wn[e - RPAD]);
           const unsigned half = gI == NG - 1 ? 0u : ((gI & 1) ? (unsigned)__double2hiint(v) : (unsigned)__double2loint(v));
-          gran_store(q.pkt + gI, epoch + 1u, half);
+#pragma unroll
+          for (int rep = 0; rep < PSTEP_PKT_REP; ++rep) gran_store(q.pkt + (size_t)rep * (PSTEP_REP_STRIDE / 8) + gI, epoch + 1u, half);
         }
       }
     }
@@ -979,7 +989,7 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
   // ---------------- end of the launch: DevState as the two-launch engine leaves it ----------------
   const int stop = lds_word(s_ctl), badp = lds_word(s_ctl + 2);
   if ((stop != 0 || badp != 0) && tid == 0) {
-    gran_store(q.pkt + (NG - 1), PSTEP_ABORT_TAG, 1u);        // the row workgroups leave at their next poll
+    for (int rep = 0; rep < PSTEP_PKT_REP; ++rep) gran_store(q.pkt + (size_t)rep * (PSTEP_REP_STRIDE / 8) + (NG - 1), PSTEP_ABORT_TAG, 1u);        // the row workgroups leave at their next poll
     if (st->err == 0) st->err = badp ? (int)(k0 + 1) : -8;
   }
 #pragma unroll
@@ -1092,16 +1102,18 @@ bool pstep_plan(int d_local, int r, int n_cu, bool storage_f64, bool masked, Pst
   out->np = np;
   out->ncol2 = (r + 1 + 1) & ~1;
   const size_t fl = (((size_t)nwg * sizeof(unsigned)) + 15) & ~(size_t)15;
-  const size_t pk = (((size_t)PSTEP_PKT_MAX * sizeof(unsigned long long)) + 15) & ~(size_t)15;
-  // the zeroed block: | flags of the (h, ee) hand-off | flags of the Gram partials | (spare) | packet | granules of the reduced Gram |
+  // the zeroed block: | flags of the (h, ee) hand-off | packet x PSTEP_PKT_REP | flags of the Gram partials x PSTEP_GF_REP | granules of the reduced Gram |
+  static_assert(PSTEP_PKT_MAX * 8 <= PSTEP_REP_STRIDE, "a packet fits its replica slot");
   const int ntg = rpad > 16 ? 2 : 1;
   const int nge = masked ? ntg * (ntg + 1) / 2 * 256 + 1 : 0;
   const size_t gs = ((size_t)2 * nge * sizeof(unsigned long long) + 15) & ~(size_t)15;
-  out->off_gflags = fl;
-  out->off_sflags = 2 * fl;
-  out->off_pkt = 3 * fl;
-  out->off_gslice = 3 * fl + pk;
-  out->zero_bytes = 3 * fl + pk + gs;
+  const size_t fl4k = (fl + 4095) & ~(size_t)4095;
+  if ((size_t)nwg * sizeof(unsigned) > (size_t)PSTEP_REP_STRIDE) return false;
+  out->off_pkt = fl4k;
+  out->off_gflags = fl4k + (size_t)PSTEP_PKT_REP * PSTEP_REP_STRIDE;
+  out->off_sflags = 0;
+  out->off_gslice = out->off_gflags + (masked ? (size_t)PSTEP_GF_REP * PSTEP_REP_STRIDE : 0);
+  out->zero_bytes = out->off_gslice + gs;
   out->off_part = (out->zero_bytes + 255) & ~(size_t)255;
   size_t end = out->off_part + (size_t)nwg * out->ncol2 * sizeof(double);
   out->nge = nge; out->slice_len = 0; out->off_gpart = 0;
