@@ -820,6 +820,7 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
       if (!p.fixed_lambda) lam += dd;
     }
     const double iq_old = s_sc[1];
+    const double iom = p.robust ? fast_rcp(omega) : 1.0;      // (a float64 division per element is ~30 instructions: one reciprocal instead)
 #pragma unroll
     for (int m = 0; m < M; ++m) {
       if (val[m]) {
@@ -833,7 +834,7 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
         sG[ii[m] * LS + j] = Gv[m];
         if (dual) {
           const double wsym = 0.5 * (sW[ii[m] * LS + j] + sW[j * LS + ii[m]]);
-          sL[ii[m] * LS + j] = ((ii[m] == j ? iq_old : 0.0) - wsym * iq_old * iq_old) / omega;
+          sL[ii[m] * LS + j] = ((ii[m] == j ? iq_old : 0.0) - wsym * iq_old * iq_old) * iom;
         }
       }
     }
@@ -975,7 +976,7 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
     }
     if (tid == 0) {
       s_sc[0] = kap_n;
-      s_sc[1] = 1.0 / Qv[0];
+      s_sc[1] = fast_rcp(Qv[0]);
     }
     carried = dual;
     N0 = Nn; kappa0 = kap_n; s0 = sN; eta0 = eta; k0 = knext;
