@@ -51,8 +51,9 @@ typedef enum { PSMF_F32 = 0, PSMF_F64 = 1 } psmf_dtype;
  *                                                               per n; N = dyn_terms <= 4
  * PSMF_DYN_HOST         any callable: the host evaluates mu_bar = f(theta, mu, k) and P_bar = F P F^T + Q (r-sized) and
  *                       advances the device one timestep at a time with psmf_step_host (the d-sized work stays on the device)
- * Kinds 2-4 are evaluated inside the blocked engine (r <= 32), with analytic Jacobians df/dx, df/dtheta (the reference uses
- * autograd, psmf.py:41-44); the per-step engine evaluates kinds 0, 1 and is the engine of kind 5. */
+ * Kinds 0-4 are evaluated inside the device time loop of either engine, with analytic Jacobians df/dx, df/dtheta (the reference
+ * uses autograd, psmf.py:41-44): the blocked engine (r <= 32) or the serial stage of the per-step engine's launched form (r > 32,
+ * a non-uniform R, engine = 1; the persistent per-step kernel takes kinds 0, 1).  Kind 5 is the per-step engine's. */
 typedef enum { PSMF_DYN_RANDOM_WALK = 0, PSMF_DYN_COS_PHASE = 1, PSMF_DYN_SCALED_WALK = 2, PSMF_DYN_SINUSOID = 3,
                PSMF_DYN_FOURIER = 4, PSMF_DYN_HOST = 5 } psmf_dyn_kind;
 
@@ -135,6 +136,12 @@ int psmf_set_adam(psmf_handle h, const double* m, const double* v);
  * step k = 1 .. n - 1 (entry 0 unused; steps beyond n - 1 are refused by psmf_run).  NULL = constant (rho / Q of
  * psmf_set_state).  Not with robust = 1 (rPSMF runs on its own omega-scaled Q_{k-1}, R_{k-1}, rpsmf.py:123,128,141). */
 int psmf_set_schedules(psmf_handle h, const double* rho_k, const double* q_k, int64_t n);
+/* PSMFIter's Q[k] when it is NOT a scalar multiple of Q[1] (psmf.py:115 reads a matrix per step): n matrices of r x r doubles,
+ * row-major, matrix k for the 1-based step k (matrix 0 unused; steps beyond n - 1 are refused by psmf_run).  P_bar_k =
+ * F P F^T + Q_k is then formed from the uploaded matrix in the serial stage of the per-step engine (launched form; the handle
+ * must have been created with engine = 1).  NULL or n = 0 drops the schedule.  Not with robust = 1, masked handles or
+ * PSMF_DYN_HOST. */
+int psmf_set_q_matrix_schedule(psmf_handle h, const double* Q_k, int64_t n);
 
 /* Non-uniform diagonal R (cfg.nonuniform_R = 1): rho_rows[d_local] = diag(R) of this handle's rows, rho_mean = sum of diag(R)
  * over ALL rows / d (tr(R) / d of psmf.py:121-125; the same value on every shard).  The `rho` of psmf_set_state is then the

@@ -55,6 +55,7 @@ SIGNATURES = {
     "psmf_get_state": (C.c_int, [C.c_void_p, _dp, _dp, _dp, _dp, _dp, _dp, _dp, _dp]),
     "psmf_set_adam": (C.c_int, [C.c_void_p, _dp, _dp]),
     "psmf_set_schedules": (C.c_int, [C.c_void_p, _dp, _dp, C.c_int64]),
+    "psmf_set_q_matrix_schedule": (C.c_int, [C.c_void_p, _dp, C.c_int64]),
     "psmf_set_row_noise": (C.c_int, [C.c_void_p, _dp, C.c_double]),
     "psmf_set_noise_rotation": (C.c_int, [C.c_void_p, _dp, _dp]),
     "psmf_step_host": (C.c_int, [C.c_void_p, C.c_int64, _dp, _dp, _dp, _dp, _dp, _dp]),
@@ -295,6 +296,17 @@ class DeviceFilter:
             if a is not None and a.size != n:
                 raise ValueError("schedules must have the same length")
         self._check(self._lib.psmf_set_schedules(self._h, _ptr(rho_k), _ptr(q_k), n))
+
+    def set_q_matrix_schedule(self, Q_k=None):
+        """Q_k [n, r, r] as a matrix of its own per 1-based step k (matrix 0 unused): a Q[k] that is not a multiple of Q[1]
+        (psmf.py:115).  Per-step engine only (engine="step"); None drops the schedule."""
+        if Q_k is None:
+            self._check(self._lib.psmf_set_q_matrix_schedule(self._h, None, 0))
+            return
+        Q_k = _f64(Q_k)
+        if Q_k.ndim != 3 or Q_k.shape[1:] != (self.r, self.r):
+            raise ValueError(f"Q_k: expected [n, {self.r}, {self.r}], got {Q_k.shape}")
+        self._check(self._lib.psmf_set_q_matrix_schedule(self._h, _ptr(Q_k), Q_k.shape[0]))
 
     def step_host(self, k, mu_bar, P_bar, want_PQ=True):
         """One timestep k -> k + 1 with host-evaluated mu_bar [r], P_bar [r, r] (dyn_kind = DYN_HOST).

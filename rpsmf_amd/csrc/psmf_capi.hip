@@ -97,6 +97,8 @@ struct psmf_filter {
   bool have_mask = false;
   double* sched = nullptr;     // rho_k | q_k schedules, sched_n doubles each (psmf_set_schedules)
   int64_t sched_n = 0;
+  double* qmat = nullptr;      // Q_k matrices, (qmat_n + 1) x r x r (psmf_set_q_matrix_schedule)
+  int64_t qmat_n = 0;
   double* mu_hist = nullptr;   // (T_cap + 1) x r
   hipStream_t fstream = nullptr;   // blocked engine, pipelined: the filter chain's own stream, pinned to reserved CUs (or nullptr)
   bool streams_concurrent = false;           // the filter stream's kernels run concurrently with the bulk stream's (probed at creation)
@@ -378,7 +380,7 @@ enum FilterKernel { FK_STEP = 0, FK_GENERAL = 1, FK_FILTER2 = 2, FK_FILTER3 = 3,
 bool pstep_usable(const psmf_filter* h) {
   return h->engine == 1 && h->ps_ok && h->sw.step_persistent && !h->use_coll && !h->host_fn && !h->sp.rho_rows &&
          (h->cfg.masked == 0 || (h->cfg.masked == 1 && h->have_mask)) &&        // masked PSMF / rPSMF; MLE-SMF and TMF keep the two launches
-         !h->cfg.nonuniform_R && h->cfg.dyn_kind <= PSMF_DYN_COS_PHASE && !h->sp.solve_lds;
+         !h->cfg.nonuniform_R && h->cfg.dyn_kind <= PSMF_DYN_COS_PHASE && !h->sp.solve_lds && !h->sp.q_mat;
 }
 
 FilterKernel select_filter_kernel(const psmf_filter* h) {
@@ -742,7 +744,7 @@ void compute_geometry(const psmf_config& c, Geometry& g, const int sweep_nt = 51
 void update_solve_dual(psmf_filter* h) {
   const psmf_config& c = h->cfg;
   const int v = (h->sw.step_dual && h->engine == 1 && h->q_iso && c.masked < 2 && c.dyn_kind == PSMF_DYN_RANDOM_WALK && c.coef_update && c.pbar_predict && !c.nonuniform_R &&
-                 !h->sp.solve_lds && !h->sp.q_sched) ? 1 : 0;
+                 !h->sp.solve_lds && !h->sp.q_sched && !h->sp.q_mat) ? 1 : 0;
   if (v != h->sp.solve_dual) {
     h->sp.solve_dual = v;
     destroy_graph(h);        // the captured launches carry the old parameter block
@@ -952,10 +954,8 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
     // auto: blocked whenever it applies -- it is exact and removes the per-step launches and row sweeps
     h->engine = cfg->engine == 0 ? (can_block ? 2 : 1) : cfg->engine;
     if (const char* e = getenv("PSMF_ENGINE")) { const int v = atoi(e); if (v == 1 || (v == 2 && can_block)) h->engine = v; }
-    if (h->engine == 1 && cfg->dyn_kind >= PSMF_DYN_SCALED_WALK && cfg->dyn_kind <= PSMF_DYN_FOURIER) {
-      h->err = "psmf_create: scaled-walk / sinusoid / Fourier dynamics are evaluated by the blocked engine (r <= 32); use PSMF_DYN_HOST otherwise";
-      return bail(PSMF_ERR_ARG);
-    }
+    // (scaled-walk / sinusoid / Fourier dynamics on the per-step engine -- r > 32, a non-uniform R, engine = 1: the launched form's
+    //  serial stage evaluates them through psmf_dyn.hip like the blocked engine's general kernel)
   }
   h->th_cap = (size_t)(cfg->n_theta > psmf::RM ? cfg->n_theta : psmf::RM);
   CREATE_TRY(hipMalloc((void**)&h->thbuf, 4 * h->th_cap * sizeof(double)));
@@ -1092,7 +1092,7 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
   sp.dyn_kind = cfg->dyn_kind; sp.n_theta = cfg->n_theta; sp.store_yp = 0;
   sp.dyn_flags = cfg->dyn_flags; sp.dyn_terms = cfg->dyn_terms;
   sp.theta = h->thbuf; sp.gradsum = h->thbuf + h->th_cap; sp.adam_m = h->thbuf + 2 * h->th_cap; sp.adam_v = h->thbuf + 3 * h->th_cap;
-  sp.rho_sched = nullptr; sp.q_sched = nullptr;
+  sp.rho_sched = nullptr; sp.q_sched = nullptr; sp.q_mat = nullptr;
   sp.rho_rows = nullptr; sp.rho_mean = 1.0;
   sp.recursive = cfg->recursive; sp.update_every = cfg->update_every > 0 ? cfg->update_every : 1;
   sp.track_g = ((cfg->eta_full || cfg->coef_update) && !cfg->masked) ? 1 : 0;     // masked: G is this step's masked Gram, recomputed every step
@@ -1157,6 +1157,7 @@ void psmf_destroy(psmf_handle h) {
   if (h->mu_hist) hipFree(h->mu_hist);
   if (h->thbuf) hipFree(h->thbuf);
   if (h->sched) hipFree(h->sched);
+  if (h->qmat) hipFree(h->qmat);
   if (h->rho_rows) hipFree(h->rho_rows);
   if (h->rotU) hipFree(h->rotU);
   if (h->rot_tmp) hipFree(h->rot_tmp);
@@ -1392,6 +1393,7 @@ int psmf_run(psmf_handle h, int64_t k_begin, int64_t k_end) {
   if (k_begin < 0 || k_end < k_begin || k_end > h->T_cap) return fail(h, PSMF_ERR_ARG, "psmf_run: step range outside the uploaded series");
   if (h->cfg.dyn_kind == PSMF_DYN_HOST) return fail(h, PSMF_ERR_STATE, "psmf_run: host-stepped dynamics advance with psmf_step_host");
   if (h->sched && k_end >= h->sched_n) return fail(h, PSMF_ERR_ARG, "psmf_run: step range beyond the R / Q schedules");
+  if (h->qmat && k_end >= h->qmat_n) return fail(h, PSMF_ERR_ARG, "psmf_run: step range beyond the Q_k matrix schedule");
   if (h->cfg.nonuniform_R && !h->sp.rho_rows) return fail(h, PSMF_ERR_STATE, "psmf_run: psmf_set_row_noise first (nonuniform_R = 1)");
   if (h->cfg.masked && !h->have_mask) return fail(h, PSMF_ERR_STATE, "psmf_run: psmf_upload_mask first (masked = 1)");
   int rc = set_device(h);
@@ -1949,6 +1951,36 @@ int psmf_set_schedules(psmf_handle h, const double* rho_k, const double* q_k, in
   update_solve_dual(h);
   destroy_graph(h);      // the graph's kernel nodes carry StepParams by value
   { const int zero = 0; HIP_TRY(h, hipMemcpy(&h->st->ns_valid, &zero, sizeof(int), hipMemcpyHostToDevice)); }   // another filter kernel may run next: no carried register dump
+  h->need_prep = true;
+  return PSMF_OK;
+}
+
+int psmf_set_q_matrix_schedule(psmf_handle h, const double* Q_k, int64_t n) {
+  if (!h || n < 0) return PSMF_ERR_ARG;
+  if (Q_k && n > 0) {
+    if (h->cfg.robust) return fail(h, PSMF_ERR_ARG, "psmf_set_q_matrix_schedule: rPSMF runs on its own scaled Q (rpsmf.py:123,128)");
+    if (h->cfg.masked) return fail(h, PSMF_ERR_ARG, "psmf_set_q_matrix_schedule: masked handles take a constant Q (the ExperimentImpute filters)");
+    if (h->engine != 1) return fail(h, PSMF_ERR_ARG, "psmf_set_q_matrix_schedule: a Q_k that is not a multiple of Q_1 needs the per-step engine (engine = 1)");
+    if (h->cfg.dyn_kind == PSMF_DYN_HOST) return fail(h, PSMF_ERR_ARG, "psmf_set_q_matrix_schedule: host-stepped dynamics form P_bar (and add Q_k) on the host");
+  }
+  int rc = set_device(h);
+  if (rc) return rc;
+  HIP_TRY(h, hipStreamSynchronize(h->stream));
+  if (h->qmat) { HIP_TRY(h, hipFree(h->qmat)); h->qmat = nullptr; }
+  h->qmat_n = 0;
+  h->sp.q_mat = nullptr;
+  if (Q_k && n > 0) {
+    // n + 1 matrices, the last one repeated (as in psmf_set_schedules: the serial stage prepares one step ahead)
+    const size_t rr = (size_t)h->cfg.r * h->cfg.r;
+    HIP_TRY(h, hipMalloc((void**)&h->qmat, (size_t)(n + 1) * rr * sizeof(double)));
+    HIP_TRY(h, hipMemcpy(h->qmat, Q_k, (size_t)n * rr * sizeof(double), hipMemcpyHostToDevice));
+    HIP_TRY(h, hipMemcpy(h->qmat + (size_t)n * rr, Q_k + (size_t)(n - 1) * rr, rr * sizeof(double), hipMemcpyHostToDevice));
+    h->qmat_n = n;
+    h->sp.q_mat = h->qmat;
+  }
+  update_solve_dual(h);
+  destroy_graph(h);      // the graph's kernel nodes carry StepParams by value
+  { const int zero = 0; HIP_TRY(h, hipMemcpy(&h->st->ns_valid, &zero, sizeof(int), hipMemcpyHostToDevice)); }
   h->need_prep = true;
   return PSMF_OK;
 }

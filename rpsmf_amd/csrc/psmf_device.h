@@ -73,6 +73,9 @@ struct StepParams {
   // step; nullptr = constant
   const double* rho_sched;
   const double* q_sched;
+  // ... or Q_k as a matrix of its own per step (psmf_set_q_matrix_schedule: r x r doubles per step, same indexing; per-step engine,
+  // launched form); nullptr = Q of the state, times q_sched
+  const double* q_mat;
   // non-uniform diagonal R (per-step engine): R = st->rho * diag(rho_rows), st->rho starting at 1 (rPSMF scales it by omega);
   // rho_mean = sum(rho_rows over ALL shards) / d, so that tr(R) / d = st->rho * rho_mean.  nullptr / 1.0: uniform R = st->rho I
   const double* rho_rows;

@@ -88,6 +88,26 @@ __device__ __forceinline__ void dyn_sincospi(const double a, double& sn, double&
   cs = (qd == 1 || qd == 2) ? -c1 : c1;
 }
 
+// trig_t(arg_tj) and trig_t'(arg_tj) of every term at x = s_x, step index tk: the first phase of the forward pass, and all the
+// gradient pass needs of it (the per-step engine's serial stage evaluates them again at the step's end instead of keeping
+// them across two launches).  All NTH threads; ends with a barrier.  Nothing to do for the scaled walk (no trig terms).
+template <int NTH>
+__device__ __forceinline__ void dyn_trig(const StepParams& p, const double tk, const double* s_x, double* s_val, double* s_tp, const int tid) {
+  const int r = p.r, kind = p.dyn_kind, flags = p.dyn_flags, N = p.dyn_terms;
+  const double* th = p.theta;
+  const int nt = dyn_n_terms(kind, N);
+  for (int idx = tid; idx < nt * r; idx += NTH) {
+    const int t = idx / r, j = idx - t * r;
+    const DynTerm d = dyn_term(kind, flags, N, r, t);
+    const double c = d.c_off >= 0 ? th[d.c_off + j] : 1.0;
+    double sn, cs;
+    dyn_sincospi(2.0 * th[d.b_off + j] * tk + (c * s_x[j]) * 0.31830988618379067154, sn, cs);
+    s_val[t * RM + j] = d.is_cos ? cs : sn;
+    s_tp[t * RM + j] = d.is_cos ? -sn : cs;
+  }
+  __syncthreads();
+}
+
 // Forward pass, all NTH threads of the workgroup; ends with a barrier.
 //   s_x    mu_{k-1} (LDS, r)             s_mub  out: mu_bar (r)
 //   s_fd   out: diagonal of F when !dense (r)
@@ -117,16 +137,7 @@ __device__ __forceinline__ void dyn_forward(const StepParams& p, const double tk
     return;
   }
   const int nt = dyn_n_terms(kind, N);
-  for (int idx = tid; idx < nt * r; idx += NTH) {
-    const int t = idx / r, j = idx - t * r;
-    const DynTerm d = dyn_term(kind, flags, N, r, t);
-    const double c = d.c_off >= 0 ? th[d.c_off + j] : 1.0;
-    double sn, cs;
-    dyn_sincospi(2.0 * th[d.b_off + j] * tk + (c * s_x[j]) * 0.31830988618379067154, sn, cs);
-    s_val[t * RM + j] = d.is_cos ? cs : sn;
-    s_tp[t * RM + j] = d.is_cos ? -sn : cs;
-  }
-  __syncthreads();
+  dyn_trig<NTH>(p, tk, s_x, s_val, s_tp, tid);
   const bool dense = dyn_dense(kind, flags);
   if (!dense && kind != DYN_FOURIER) {
     // no matrix in any term (cos-phase, unscaled sinusoid -- the ExperimentSynthetic modes): mu_bar and the diagonal of F

@@ -25,6 +25,7 @@
 // is float64.
 #pragma once
 #include "psmf_device.h"
+#include "psmf_dyn.hip"
 
 namespace psmf {
 
@@ -505,6 +506,9 @@ __device__ __forceinline__ void serial_body(const StepParams& p, const int first
   __shared__ double s_w[RM], s_mub[RM], s_f[RM], s_vec[RM];
   __shared__ double s_part[NSEG][2 * (RM + 1)];
   __shared__ double s4[NWK / 64];
+  // dynamics with a matrix in them (scaled walk, sinusoid, Fourier basis: psmf_dyn.hip): mu_{k-1} / mu_k, g_f, the terms' trig values
+  __shared__ double s_dx[RM], s_gf[RM];
+  __shared__ double s_val[DYN_MAX_TERMS * RM], s_tp[DYN_MAX_TERMS * RM], s_dpart[DYN_MAX_TERMS * RM];
 
   PSMF_STAMP(0);
   // ---------------- every global load of the stage, issued up front ----------------
@@ -553,6 +557,7 @@ __device__ __forceinline__ void serial_body(const StepParams& p, const int first
   // the per-step engine evaluates the random walk and cos(2 pi theta t + x) itself (n_theta = r); every other f is
   // host-stepped here (dyn_kind 5: mu_bar, P_bar come from the host, g_f goes back) or runs in the blocked engine
   const bool host_dyn = p.dyn_kind == 5;
+  const bool gen_dyn = p.dyn_kind >= DYN_SCALED_WALK && p.dyn_kind <= DYN_FOURIER;      // evaluated through psmf_dyn.hip (uniform)
   const bool tl = tid < p.n_theta && p.dyn_kind == 1;
   const int tc = tid & (RM - 1);   // every r-sized array has RM entries: load unconditionally, mask afterwards
   const double l_mu = st->mu[tc], l_w = st->w[tc], l_mub = st->mu_bar[tc], l_th = p.theta[tc], l_gs = p.gradsum[tc],
@@ -668,6 +673,24 @@ __device__ __forceinline__ void serial_body(const StepParams& p, const int first
       }
       gsum += jt * gf;
     }
+    if (gen_dyn && p.n_theta > 0) {      // gradsum += J_theta^T g_f through the terms' trig values at x = mu_{k-1} (nonlinearities.py:59-150)
+      const double tk = (double)(k0 + 1);
+      if (vl) {
+        const double wi = w_t, hi = s_he[tid];
+        double gf;
+        if (p.robust) {
+          const double D = lam * N;
+          gf = dd * wi / N + 0.5 * (dd + lam) * (-2.0 * hi / D - 2.0 * lam * ee * wi / (D * D)) / (1.0 + ee / D);
+        } else {
+          gf = dd * wi / N - hi / N - ee * wi / (N * N);
+        }
+        s_gf[tid] = gf;
+        s_dx[tid] = mu_old;
+      }
+      __syncthreads();
+      dyn_trig<NWK>(p, tk, s_dx, s_val, s_tp, tid);
+      dyn_backward<NWK>(p, tk, s_dx, s_gf, s_val, s_tp, tid);
+    }
     if (host_dyn && vl) {     // g_f for the host, which holds J_theta (same closed forms)
       const double wi = w_t, hi = s_he[tid];
       if (p.robust) {
@@ -754,6 +777,8 @@ __device__ __forceinline__ void serial_body(const StepParams& p, const int first
       st->N_done = N;
     }
     if (host_dyn) return;        // the host evaluates f for the next step, then launches this stage with first = 1
+    // PSMFRecursive with these dynamics: the optimiser step on theta every update_every observations (psmf.py:299-304)
+    if (gen_dyn && p.recursive && p.n_theta > 0 && (knext % p.update_every) == 0) dyn_adam_step<NWK>(p, knext, tid);
   } else {
     if (!worker) return;
   }
@@ -763,24 +788,62 @@ __device__ __forceinline__ void serial_body(const StepParams& p, const int first
   // PSMFIter reads Q[k], R[k] of the step itself (psmf.py:115,123,141): scalar schedules (never with rPSMF's running Q, R)
   const double qs = p.q_sched ? p.q_sched[knext + 1 - p.series_t0] : 1.0;
   if (p.rho_sched) rho = p.rho_sched[knext + 1 - p.series_t0];
-  if (vl) {
-    double mb = mu_new, f = 1.0;
-    if (p.dyn_kind == 1) {   // cos(2 pi theta t + x)
-      const double arg = 2.0 * M_PI * theta * (double)(knext + 1) + mu_new;
-      mb = cos(arg);
-      f = -sin(arg);
+  const double* qm = p.q_mat ? p.q_mat + (size_t)(knext + 1 - p.series_t0) * r * r : nullptr;     // Q_k as a matrix of its own
+  double* sF = &s_part[0][0];          // dense F = df/dx, row stride RPAD + 1 (s_part is free since the reduction)
+  constexpr int FS = RPAD + 1;
+  if (gen_dyn) {
+    if (vl) s_dx[tid] = mu_new;
+    __syncthreads();
+    dyn_forward<NWK>(p, (double)(knext + 1), s_dx, s_mub, s_f, sF, FS, s_val, s_tp, s_dpart, tid);     // ends with a barrier
+    if (vl) st->mu_bar[tid] = s_mub[tid];
+  } else {
+    if (vl) {
+      double mb = mu_new, f = 1.0;
+      if (p.dyn_kind == 1) {   // cos(2 pi theta t + x)
+        const double arg = 2.0 * M_PI * theta * (double)(knext + 1) + mu_new;
+        mb = cos(arg);
+        f = -sin(arg);
+      }
+      if (host_dyn) mb = mub_t;     // mu_bar of the step as the host uploaded it
+      s_mub[tid] = mb;         // (the current step's mu_bar was consumed from registers above)
+      s_f[tid] = f;
+      st->mu_bar[tid] = mb;
     }
-    if (host_dyn) mb = mub_t;     // mu_bar of the step as the host uploaded it
-    s_mub[tid] = mb;         // (the current step's mu_bar was consumed from registers above)
-    s_f[tid] = f;
-    st->mu_bar[tid] = mb;
+    __syncthreads();
   }
-  __syncthreads();
+  double Fpf[M];            // (F P F^T)[i][j] of a dense F
+  if (gen_dyn && p.pbar_predict && dyn_dense(p.dyn_kind, p.dyn_flags)) {
+    // two r x r x r products, one output element per (i_m, j) as everywhere in this stage; P (symmetrised, scaled) and T = F P go
+    // through st->Lbar / st->XpY, which are scratch here: the side-by-side inversions that carry them are a random-walk form
+    double* Ps = st->Lbar;
+    double* Ts = st->XpY;
+#pragma unroll
+    for (int m = 0; m < M; ++m) if (val[m]) Ps[ii[m] * r + j] = Pv[m];
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      if (val[m]) {
+        double a = 0.0;
+        for (int l = 0; l < r; ++l) a += sF[ii[m] * FS + l] * Ps[l * r + j];
+        Ts[ii[m] * r + j] = a;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      double a = 0.0;
+      if (val[m]) for (int l = 0; l < r; ++l) a += Ts[ii[m] * r + l] * sF[j * FS + l];
+      Fpf[m] = a;
+    }
+  } else {
+#pragma unroll
+    for (int m = 0; m < M; ++m) Fpf[m] = val[m] ? s_f[ii[m]] * Pv[m] * s_f[j] : 0.0;
+  }
   double part = 0.0, gp = 0.0;
 #pragma unroll
   for (int m = 0; m < M; ++m) {
     if (val[m]) {
-      double pb = p.pbar_predict ? s_f[ii[m]] * Pv[m] * s_f[j] + qs * Qv[m] : Pv[m];
+      double pb = p.pbar_predict ? Fpf[m] + (qm ? qm[ii[m] * r + j] : qs * Qv[m]) : Pv[m];
       if (host_dyn) pb = 0.5 * (st->Pbar[ii[m] * r + j] + st->Pbar[j * r + ii[m]]);   // P_bar = F P F^T + Q as the host formed it
       else st->Pbar[ii[m] * r + j] = pb;
       part += Vv[m] * s_mub[ii[m]];

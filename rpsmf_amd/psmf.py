@@ -530,14 +530,11 @@ class PSMFIter:
         return rho1, Q1, rho_s, q_s
 
     def _host_stepped(self):
-        """True when f is evaluated on the host, one device step at a time (psmf_step_host): arbitrary callables, kinds the
-        chosen engine does not evaluate (scaled walk / sinusoid / Fourier need the blocked engine: r <= 32), or a Q[k]
-        schedule that is not a scalar multiple of Q[1]."""
-        kind = self._nl.device_kind
-        if kind is None or getattr(self, "_force_host_stepped", False):
-            return True
-        general = kind in (_capi.DYN_SCALED_WALK, _capi.DYN_SINUSOID, _capi.DYN_FOURIER)
-        return general and (self._r > 32 or self._dev_opts.get("engine") == "step" or self._row_noise() is not None)
+        """True when f is evaluated on the host, one device step at a time (psmf_step_host): arbitrary callables and what
+        psmf_dyn.hip does not hold (a Fourier basis of more than 4 + 4 terms), or a Q[k] schedule of matrices too large to
+        upload.  The recognised kinds run inside the device time loop on either engine (scaled walk / sinusoid / Fourier at
+        r > 32 or with a non-uniform R: the per-step engine's serial stage)."""
+        return self._nl.device_kind is None or getattr(self, "_force_host_stepped", False)
 
     def _device_kwargs(self):
         coef, eta_full, pbar = HIP_MODES[self.hip_mode]
@@ -546,9 +543,23 @@ class PSMFIter:
             kw.update(dyn_kind=_capi.DYN_HOST, engine="step")
         else:
             kw.update(dyn_kind=self._nl.device_kind, dyn_flags=self._nl.device_flags, dyn_terms=self._nl.device_terms)
+        if self._row_noise() is not None or getattr(self, "_q_matrix_sched", False):
+            kw.update(engine="step")
         if self._row_noise() is not None:
-            kw.update(nonuniform_R=True, engine="step")
+            kw.update(nonuniform_R=True)
         return kw
+
+    # a Q[k] schedule of matrices (not multiples of Q[1]) goes to the device as [T + 1, r, r] up to this size, else host-stepped
+    _Q_MATRIX_SCHEDULE_MAX_BYTES = 1 << 31
+
+    def _q_matrices(self, T):
+        Q = self._Q
+        k1 = 1 if 1 in Q else min(Q.keys())
+        out = np.empty((T + 1, self._r, self._r))
+        out[0] = self._q_matrix(Q[k1])
+        for k in range(1, T + 1):
+            out[k] = self._q_matrix(Q.get(k, Q[k1]))
+        return out
 
     def _ensure_device(self):
         if self._dev is None:
@@ -598,6 +609,12 @@ class PSMFIter:
         if sched != getattr(self, "_sched_key", (None, None)):
             dev.set_schedules(rho_s, None if isinstance(q_s, str) else q_s)
             self._sched_key = sched
+        if getattr(self, "_q_matrix_sched", False) and not self._host_stepped():
+            Qm = self._q_matrices(T)
+            key = (Qm.shape, _content_hash(Qm))
+            if key != getattr(self, "_qmat_key", None):
+                dev.set_q_matrix_schedule(Qm)
+                self._qmat_key = key
 
     def _device_lambda0(self):
         return 0.0
@@ -617,9 +634,15 @@ class PSMFIter:
 
     def _step_hip(self, y, i, T):
         self.step_reset()
-        if not self._host_stepped() and not self.robust and isinstance(self._device_rho_q(T)[3], str):
-            # Q[k] is not a scalar multiple of Q[1]: the host forms P_bar (any Q[k]); needs a handle of the host-stepped kind
-            self._force_host_stepped = True
+        if (not self._host_stepped() and not self.robust and not getattr(self, "_q_matrix_sched", False)
+                and isinstance(self._device_rho_q(T)[3], str)):
+            # Q[k] is not a scalar multiple of Q[1]: uploaded matrix by matrix, P_bar = F P F^T + Q_k formed in the per-step
+            # engine's serial stage (psmf_set_q_matrix_schedule) -- or, beyond _Q_MATRIX_SCHEDULE_MAX_BYTES, by the host, one
+            # device step at a time.  Either way another kind of handle.
+            if (T + 1) * self._r * self._r * 8 <= self._Q_MATRIX_SCHEDULE_MAX_BYTES:
+                self._q_matrix_sched = True
+            else:
+                self._force_host_stepped = True
             if self._dev is not None:
                 self._dev.close()
                 self._dev, self._series_key, self._sched_key = None, None, (None, None)

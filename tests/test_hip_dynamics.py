@@ -189,8 +189,9 @@ def test_host_stepped_arbitrary_callable(robust):
         assert relerr(f._theta[i].reshape(-1), st.theta) < 1e-7
 
 
-def test_general_kind_beyond_r32_runs_host_stepped():
-    """Sinusoid at r = 40: the blocked engine (which evaluates it) stops at r = 32 -> host-stepped automatically."""
+def test_general_kind_beyond_r32_runs_in_the_device_loop():
+    """Sinusoid at r = 40 through the drop-in class: the blocked engine (r <= 32) cannot take it, the per-step engine's serial stage
+    evaluates it (round 5; it was host-stepped before)."""
     d, r, T = 500, 40, 25
     rng = np.random.default_rng(5)
     Y, C0 = _problem(d, r, T, 9)
@@ -200,10 +201,92 @@ def test_general_kind_beyond_r32_runs_host_stepped():
     f = psmf.PSMFIter(theta0, C0, V0, np.zeros((r, 1)), P0, {k: Q for k in range(T + 1)}, {k: 1.0 for k in range(T + 1)}, nl, storage="f64")
     f.adam_init()
     f.step(ydict(Y), 1, T)
-    assert f._dev.dyn_kind == _capi().DYN_HOST
+    assert f._dev.dyn_kind == _capi().DYN_SINUSOID and f._dev.geometry()["filter_kernel"] == "psmf_sweep_solve"
     st = O.State(C=C0, V=V0, mu=np.zeros(r), P=P0, Q=Q, rho=1.0, lam=0.0, theta=theta0.reshape(-1).copy(), gradsum=np.zeros(nl.n_params))
     st, _, _ = O.run_epoch(st, Y, O.Mode(), O.CallableDyn(nl, nl.n_params))
     assert relerr(f._C[T], st.C) < 1e-8 and relerr(f._gradsum.reshape(-1), st.gradsum) < 1e-7
+
+
+# the kinds with a matrix in them on the PER-STEP engine (r > 32, engine = 1, a non-uniform R): psmf_dyn.hip inside psmf_serial /
+# psmf_serial_wide -- mu_bar, F, P_bar = F P F^T + Q as two r x r x r products, gradsum += J_theta^T g_f
+STEP_KINDS = [
+    ("scaled_walk_bias", lambda r: NL.ScaledWalk(r, bias=True), 6, False),
+    ("sinusoid", lambda r: NL.Sinusoid(r), 12, False),
+    ("sinusoid_unscaled", lambda r: NL.Sinusoid(r, scaled=False), 20, False),
+    ("sinusoid_unphased_r27", lambda r: NL.Sinusoid(r, phased=False), 27, False),
+    ("fourier3", lambda r: NL.FourierBasis(r, N=3), 4, False),
+    ("fourier1_r32", lambda r: NL.FourierBasis(r, N=1), 32, False),
+    ("fourier2_r40", lambda r: NL.FourierBasis(r, N=2), 40, False),
+    ("scaled_walk_r47", lambda r: NL.ScaledWalk(r, bias=False), 47, False),
+    ("sinusoid_r64", lambda r: NL.Sinusoid(r), 64, False),
+    ("sinusoid_nonuniform_R", lambda r: NL.Sinusoid(r), 9, True),
+    ("fourier1_r40_nonuniform_R", lambda r: NL.FourierBasis(r, N=1), 40, True),
+]
+
+
+@pytest.mark.parametrize("robust", [False, True], ids=["PSMF", "rPSMF"])
+@pytest.mark.parametrize("name,make,r,rows", STEP_KINDS, ids=[k[0] for k in STEP_KINDS])
+def test_device_dynamics_on_the_per_step_engine(name, make, r, rows, robust):
+    c = _capi()
+    d, T = 300, 60
+    nl = make(r)
+    rng = np.random.default_rng(311 + r)
+    Y, C0 = _problem(d, r, T, 150 + r)
+    theta = _theta_for(nl, rng, r)
+    V0, P0, Q = 0.1 * np.eye(r), np.eye(r), 0.1 * np.eye(r)
+    mu0 = 0.2 * rng.standard_normal(r)
+    rho = 0.3 + 2.0 * rng.random(d) if rows else 1.0
+    st = O.State(C=C0, V=V0, mu=mu0, P=P0, Q=Q, rho=rho, lam=1.8, theta=theta.copy(), gradsum=np.zeros(nl.n_params))
+    st, Yp, _ = O.run_epoch(st, Y, O.Mode(robust=robust), O.CallableDyn(nl, nl.n_params))
+    f = c.DeviceFilter(d, r, robust=robust, storage="f64", dyn_kind=nl.device_kind, dyn_flags=nl.device_flags,
+                       dyn_terms=nl.device_terms, engine="step", nonuniform_R=rows)
+    if rows:
+        f.set_row_noise(rho)
+    assert f.geometry()["engine"] == "step" and f.n_theta == nl.n_params
+    f.upload_series(Y)
+    f.set_state(C0, V0, P0, Q, mu0, rho=1.0, lambda0=1.8, theta=theta)
+    assert f.geometry()["filter_kernel"] == "psmf_sweep_solve"
+    f.zero_gradsum()
+    f.run(0, T // 2)                   # two runs: the serial stage's first = 1 preparation in the middle of a series too
+    f.run(T // 2, T)
+    s = f.get_state()
+    for k in ("C", "V", "mu", "P"):
+        assert relerr(s[k], getattr(st, k)) < 1e-8, (name, k, relerr(s[k], getattr(st, k)))
+    assert relerr(f.y_pred(0, T), Yp) < 1e-8
+    assert relerr(s["gradsum"], st.gradsum) < 1e-7, (name, relerr(s["gradsum"], st.gradsum))
+    assert relerr(f.predict(T, 5), O.predict_rollout(st.C, st.mu, theta, O.CallableDyn(nl, nl.n_params), T, 5)) < 1e-8
+    f.close()
+
+
+@pytest.mark.parametrize("optimiser", ["adam", "sgd"])
+def test_recursive_general_kind_per_step_engine_matches_the_blocked_engine(optimiser):
+    """The in-loop optimiser with a dense-Jacobian kind (psmf.py:287-304 with nonlinearities.py:81-114): the per-step engine's
+    serial stage against the blocked engine's general kernel (itself pinned to the reference's run by the cos-phase fixtures and
+    to the oracle's gradients above) -- theta after every update enters the next steps, so any difference grows."""
+    c = _capi()
+    d, r, T = 300, 12, 80
+    nl = NL.Sinusoid(r)
+    rng = np.random.default_rng(8)
+    Y, C0 = _problem(d, r, T, 61)
+    theta = _theta_for(nl, rng, r)
+    V0, P0, Q = 0.1 * np.eye(r), np.eye(r), 0.1 * np.eye(r)
+    out = {}
+    for engine in ("block", "step"):
+        f = c.DeviceFilter(d, r, storage="f64", dyn_kind=nl.device_kind, dyn_flags=nl.device_flags, dyn_terms=nl.device_terms,
+                           recursive=(2 if optimiser == "sgd" else 1), update_every=7, adam_lr=(1e-7 if optimiser == "sgd" else 1e-3),
+                           engine=engine)                 # (SGD steps by lr x the raw gradient sum, which grows with d)
+        f.upload_series(Y)
+        f.set_state(C0, V0, P0, Q, np.zeros(r), rho=1.0, lambda0=0.0, theta=theta)
+        f.zero_gradsum()
+        if optimiser == "adam":
+            f.set_adam(np.zeros(nl.n_params), np.zeros(nl.n_params))
+        f.run(0, T)
+        out[engine] = f.get_state()
+        out[engine]["yp"] = f.y_pred(0, T)
+        f.close()
+    assert np.max(np.abs(out["block"]["theta"] - theta)) > 1e-6          # the optimiser did move theta
+    for k in ("theta", "C", "V", "mu", "P", "yp"):
+        assert relerr(out["step"][k], out["block"][k]) < 1e-9, (k, relerr(out["step"][k], out["block"][k]))
 
 
 @pytest.mark.parametrize("engine", ["block", "step"])
@@ -291,8 +374,11 @@ def test_per_step_R_and_Q_schedules(engine, r, iso):
     assert relerr(yp, Yp) < 1e-9
 
 
-def test_arbitrary_Q_schedule_switches_to_host_stepped():
-    """A Q[k] that is not a scalar multiple of Q[1] cannot be a device schedule: the host forms P_bar (psmf_step_host)."""
+@pytest.mark.parametrize("where", ["device", "host"])
+def test_arbitrary_Q_schedule(where, monkeypatch):
+    """A Q[k] that is not a scalar multiple of Q[1] (psmf.py:115 reads a matrix per step): uploaded matrix by matrix, P_bar = P + Q_k
+    formed in the per-step engine's serial stage (psmf_set_q_matrix_schedule); beyond the upload limit the host forms P_bar
+    (psmf_step_host), as before round 5."""
     d, r, T = 400, 4, 30
     Y, C0 = _problem(d, r, T, 23)
     rng = np.random.default_rng(9)
@@ -301,10 +387,15 @@ def test_arbitrary_Q_schedule_switches_to_host_stepped():
         A = rng.standard_normal((r, r))
         Qs[k] = 0.05 * np.eye(r) + 0.01 * A @ A.T
     V0, P0 = 0.1 * np.eye(r), np.eye(r)
+    if where == "host":
+        monkeypatch.setattr(psmf.PSMFIter, "_Q_MATRIX_SCHEDULE_MAX_BYTES", 0)
     f = psmf.PSMFIter(np.zeros((0, 1)), C0, V0, np.zeros((r, 1)), P0, Qs, {k: 2.0 for k in range(T + 1)}, psmf.RandomWalk(), storage="f64")
     f.optim_init()
     f.step(ydict(Y), 1, T)
-    assert f._dev.dyn_kind == _capi().DYN_HOST
+    if where == "host":
+        assert f._dev.dyn_kind == _capi().DYN_HOST
+    else:
+        assert f._dev.dyn_kind == _capi().DYN_RANDOM_WALK and f._dev.geometry()["filter_kernel"] == "psmf_sweep_solve"
     st = O.State(C=C0, V=V0, mu=np.zeros(r), P=P0, Q=Qs[1], rho=2.0, lam=0.0)
     st, _, _ = O.run_epoch(st, Y, O.Mode(), O.RandomWalkDyn(), Qs=lambda k: Qs[k])
     assert relerr(f._C[T], st.C) < 1e-9 and relerr(f._P[T], st.P) < 1e-9

@@ -280,8 +280,9 @@ def test_engines_agree_and_auto_selects_blocked():
         c.DeviceFilter(100, 40, engine="block")      # r > 32
     with pytest.raises(ValueError):
         c.DeviceFilter(100, 8, engine="block", dyn_kind=c.DYN_HOST)      # host-stepped dynamics advance one step at a time
-    with pytest.raises(ValueError):
-        c.DeviceFilter(100, 8, engine="step", dyn_kind=c.DYN_SINUSOID, dyn_flags=3)   # evaluated by the blocked engine only
+    f = c.DeviceFilter(100, 8, engine="step", dyn_kind=c.DYN_SINUSOID, dyn_flags=3)   # (round 5: the per-step engine evaluates it too)
+    assert f.geometry()["engine"] == "step"
+    f.close()
 
 
 @pytest.mark.parametrize("robust", [False, True])
