@@ -52,7 +52,7 @@ struct Switches {
   bool bulk2 = true, filter3 = true, filter4 = true, filter6 = true, filter7 = true, filter6_dual = true, block_dual = true, block_flags = true, block_chain = true, block_pipe = true;
   bool force_collective = false;
   bool host_comm_flags = false;     // PSMF_HOST_COMM_FLAGS=1: device-flag hand-off (and chained filter launches) under a host-mediated communicator too
-  bool serial_wide = true, step_dual = true;
+  bool serial_wide = true, step_dual = true, tail_reduce = true, wgram_mfma = true;
   int sweep_threads = 512;
   double ns_far4 = 0.6;            // filter4 / filter4s: residual at which a Newton-Schulz start is given up (PSMF_NS_FAR4; PSMF_NS_FAR, when set, rules both)
   bool ns_far_set = false;
@@ -64,7 +64,7 @@ struct Switches {
     force_collective = getenv("PSMF_FORCE_COLLECTIVE") != nullptr;
     { const char* e = getenv("PSMF_HOST_COMM_FLAGS"); host_comm_flags = e && atoi(e) != 0; }
     step_persistent = !off("PSMF_STEP_PERSISTENT");
-    serial_wide = !off("PSMF_SERIAL_WIDE"); step_dual = !off("PSMF_STEP_DUAL");
+    serial_wide = !off("PSMF_SERIAL_WIDE"); step_dual = !off("PSMF_STEP_DUAL"); tail_reduce = !off("PSMF_TAIL_REDUCE"); wgram_mfma = !off("PSMF_WGRAM_MFMA");
     { const char* e = getenv("PSMF_SWEEP_THREADS"); sweep_threads = (e && atoi(e) == 256) ? 256 : 512; }
     if (const char* e = getenv("PSMF_NS_FAR4")) ns_far4 = atof(e);
     ns_far_set = getenv("PSMF_NS_FAR") != nullptr;
@@ -275,7 +275,7 @@ int enqueue_step(psmf_filter* h) {
   }
   launch_sweep(h);
   if (h->use_coll) {
-    hipLaunchKernelGGL(psmf::psmf_reduce_partials, dim3(1), dim3(psmf::WG), 0, h->stream, h->sp);
+    if (!h->sp.tail_reduce) hipLaunchKernelGGL(psmf::psmf_reduce_partials, dim3(1), dim3(psmf::WG), 0, h->stream, h->sp);
     const int rc = all_reduce_sum(h, h->st->red, h->geo.ps, h->stream);
     if (rc) return rc;
   }
@@ -647,7 +647,39 @@ int enqueue_serial_mgram(psmf_filter* h, int first) {
 }
 
 int enqueue_gram(psmf_filter* h) { return enqueue_gram_into(h, h->st->G, nullptr, nullptr); }
-int enqueue_weighted_gram(psmf_filter* h) { return enqueue_gram_into(h, h->st->GR, h->st, h->sp.rho_rows); }
+
+// the weighted Gram of the current step (non-uniform diagonal R) on the matrix cores: psmf_wgram_mfma + the masked Gram's reduction
+template <typename T>
+int launch_wgram_t(psmf_filter* h) {
+  const int r = h->cfg.r, rpad = h->geo.rpad;
+#define PSMF_WG_LAUNCH(NT_)                                                                                                 \
+  do {                                                                                                                      \
+    const size_t lds_ = (size_t)psmf::mgram_lds_doubles(NT_, 8) * sizeof(double);                                           \
+    static bool attr_[2] = {false, false};                                                                                  \
+    if (!attr_[sizeof(T) == 8]) {                                                                                           \
+      HIP_TRY(h, hipFuncSetAttribute((const void*)psmf::psmf_wgram_mfma<T, NT_, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_)); \
+      attr_[sizeof(T) == 8] = true;                                                                                         \
+    }                                                                                                                       \
+    hipLaunchKernelGGL((psmf::psmf_wgram_mfma<T, NT_, 8>), dim3(kMGramWG), dim3(8 * 64), lds_, h->stream, h->sp, h->gpart);  \
+  } while (0)
+  if (rpad <= 16) PSMF_WG_LAUNCH(1);
+  else if (rpad == 32) PSMF_WG_LAUNCH(2);
+  else if (r <= 48) PSMF_WG_LAUNCH(3);
+  else PSMF_WG_LAUNCH(4);
+#undef PSMF_WG_LAUNCH
+  return PSMF_OK;
+}
+
+int enqueue_weighted_gram(psmf_filter* h) {
+  if (!h->sw.wgram_mfma) return enqueue_gram_into(h, h->st->GR, h->st, h->sp.rho_rows);      // PSMF_WGRAM_MFMA=0: the vector-unit Gram
+  const int r = h->cfg.r;
+  const int rc = h->cfg.storage == PSMF_F64 ? launch_wgram_t<double>(h) : launch_wgram_t<float>(h);
+  if (rc) return rc;
+  hipLaunchKernelGGL(psmf::psmf_mgram_reduce, dim3((r * r + 63) / 64), dim3(512), 0, h->stream, (const double*)h->gpart, (int)kMGramWG, r * r,
+                     h->st->GR, (const double*)nullptr, r, (double*)nullptr);
+  if (h->use_coll) { const int rc2 = all_reduce_sum(h, h->st->GR, (size_t)r * r, h->stream); if (rc2) return rc2; }
+  return PSMF_OK;
+}
 
 void destroy_graph(psmf_filter* h) {
   if (h->gexec) { hipGraphExecDestroy(h->gexec); h->gexec = nullptr; }
@@ -945,7 +977,7 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
   CREATE_TRY(hipMemset(h->st, 0, sizeof(DevState)));
   CREATE_TRY(hipMalloc(&h->C, (size_t)cfg->d_local * h->geo.rp * h->elem()));
   CREATE_TRY(hipMalloc((void**)&h->partials, (size_t)h->geo.n_sweep_wg * h->geo.ps * sizeof(double)));
-  CREATE_TRY(hipMalloc((void**)&h->gpart, (size_t)(cfg->masked ? 256 : kGramWG) * (cfg->r * cfg->r + 1) * sizeof(double)));
+  CREATE_TRY(hipMalloc((void**)&h->gpart, (size_t)((cfg->masked || cfg->nonuniform_R) ? 256 : kGramWG) * (cfg->r * cfg->r + 1) * sizeof(double)));
   if (cfg->masked) CREATE_TRY(hipMalloc((void**)&h->mg, (size_t)(cfg->r * cfg->r + 2 + (cfg->r * cfg->r + 64) / 64 + 1) * sizeof(double)));     // Gram, count | trace shares
   {
     const bool can_block = cfg->r <= psmf::RM / 2 && cfg->dyn_kind != PSMF_DYN_HOST && !cfg->nonuniform_R && !cfg->masked;
@@ -1099,7 +1131,18 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
   sp.mask = nullptr; sp.mg = nullptr; sp.mg_tr = nullptr; sp.mg_ntr = 0; sp.sc_hist = nullptr; sp.mask_rows = 0;
   sp.masked_method = cfg->masked >= 2 ? cfg->masked : 0;
   sp.solve_lds = (Switches::off("PSMF_STEP_WAVE_SOLVE") || (cfg->r > 32 && Switches::off("PSMF_STEP_WAVE_BIG"))) ? 1 : 0;
-  sp.external_reduce = 0;
+  {
+    // The last row workgroup of a sweep sums the partial rows (tail_reduce_partials) where the solve block outlasts the row blocks
+    // by more than that tail -- r > 32 at moderate d_local, small shards: 31.6 -> 30.0 us per timestep at r = 40, d = 2e4, 50.3 ->
+    // 47.4 at r = 64 -- and the serial stage does where the rows are the longer part (d = 1e5, r = 32: 19.5 against 21.2 with the
+    // tail; tools/probe_tail.py).  PSMF_TAIL_REDUCE=1 / 0 forces it on / off.
+    const double rows_us = 2.0 * (double)cfg->d_local * h->geo.rp * (double)h->elem() / 3.0e6;
+    const double solve_us = cfg->r <= 32 ? 0.3 * cfg->r : (cfg->r <= 48 ? 13.0 : 24.0);
+    const char* e = getenv("PSMF_TAIL_REDUCE");
+    const bool forced = e && atoi(e) == 1;
+    sp.tail_reduce = (h->engine == 1 && h->sw.tail_reduce && (forced || (cfg->coef_update && rows_us + 3.0 < solve_us))) ? 1 : 0;
+  }
+  sp.external_reduce = sp.tail_reduce;
   sp.use_ns = (getenv("PSMF_NS") && atoi(getenv("PSMF_NS")) == 0) ? 0 : 1;
   sp.ns_predict = getenv("PSMF_NS_PREDICT") ? atoi(getenv("PSMF_NS_PREDICT")) : 7;      // bits: 1 a / b (phase F), 2 core (wave 7), 4 applied
   // Newton-Schulz acceptance: ||I - M X||_F below the tolerance BEFORE the last update (which squares it).  float64
@@ -1843,7 +1886,7 @@ int psmf_comm_init(psmf_handle h, int nranks, int rank, const void* unique_id) {
     hipFree(tmp);
   }
   h->use_coll = nranks > 1 || h->sw.force_collective;
-  h->sp.external_reduce = h->use_coll ? 1 : 0;
+  h->sp.external_reduce = (h->use_coll || h->sp.tail_reduce) ? 1 : 0;
   destroy_graph(h);
   h->need_prep = true;
   return PSMF_OK;
@@ -1862,7 +1905,7 @@ int psmf_comm_abort(psmf_handle h) {
   }
   h->nranks = 1; h->rank = 0;
   h->use_coll = false;
-  h->sp.external_reduce = 0;
+  h->sp.external_reduce = h->sp.tail_reduce;
   destroy_graph(h);
   h->need_prep = true;
   return PSMF_OK;

@@ -48,6 +48,8 @@ struct DevState {
   long long dbg[8];       // filter3 in-situ breakdown (10 ns ticks): [0] hand-off, [1] K load / assembly, [2] state init, [3] step loop, [4] block end
   long long cnt[8];       // diagnostics of the blocked filter: [0] steps inverted by Newton-Schulz, [1] by the sweep,
                           // [2] Newton-Schulz iterations in total, [3] failed Newton-Schulz attempts (psmf_counters)
+  unsigned ticket;        // row workgroups of the current sweep that have stored their partial row (StepParams.tail_reduce); the last one resets it
+  unsigned ticket_pad;
 };
 
 struct StepParams {
@@ -97,7 +99,8 @@ struct StepParams {
   // 3: TMF (TMF.py:47-66): x = x_p + (nu I + G_m)^-1 C^T e, i.e. the same solve with Pbar = I / nu, kappa = 1; C += gam (m o e) x_p^T.
   int masked_method;
   int solve_lds;        // 1: the LDS-and-barrier sweeps of round 1 for every r (PSMF_STEP_WAVE_SOLVE=0); default: wave-local sweeps for r <= 32
-  int external_reduce;  // 1: partial sums were reduced into st->red (multi-GPU)
+  int external_reduce;  // 1: partial sums were reduced into st->red (multi-GPU; tail_reduce)
+  int tail_reduce;      // 1: the last row workgroup of a sweep sums the partial rows into st->red (psmf_kernels.hip, tail_reduce_partials)
   int use_ns;           // 1: Newton-Schulz refinement of the r x r inverses (f64 MFMA), sweep as fallback
   int ns_predict;       // 1: filter3 starts the iteration from the rank-2 downdated, kappa-rescaled previous inverse
   int ns_skip_n;        // filter3: timesteps that go straight to the direct sweep after a failed Newton-Schulz start

@@ -42,7 +42,7 @@ template <> struct VecOf<double> { typedef double __attribute__((ext_vector_type
 
 // start of a run: step counter.  The numeric-error flag is NOT cleared here: runs may be queued back to back without a
 // sync in between, and a failure in an earlier one must still be reported by the next psmf_sync (cleared by psmf_set_state).
-__global__ void psmf_prepare_k(DevState* st, long long k) { st->k = k; st->kq = k; if (st->ns_valid == 7) st->ns_valid = 0; }   // (7: the per-step engine's carried Lbar -- a new run re-derives it)
+__global__ void psmf_prepare_k(DevState* st, long long k) { st->k = k; st->kq = k; st->ticket = 0u; if (st->ns_valid == 7) st->ns_valid = 0; }   // (7: the per-step engine's carried Lbar -- a new run re-derives it)
 // end of a run: the numeric-error flag to mapped host memory (system-scope store)
 __global__ void psmf_publish_err_k(const DevState* st, int* host_flag) { __hip_atomic_store(host_flag, st->err, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 
@@ -276,6 +276,60 @@ __device__ __forceinline__ void masked_prep_block(const StepParams& p, double* s
 }
 
 // ------------------------------------------------------------------------------------------
+// StepParams.tail_reduce: the fixed-order sum of the sweep's partial rows by the LAST row workgroup to finish, into st->red,
+// instead of by the serial stage (which then starts from r + 1 numbers, external_reduce = 1).  The rows leave their
+// workgroups as agent-scope stores, a ticket counts the workgroups that are done (the last one resets it), the last one reads all
+// rows with agent-scope loads -- whichever workgroup that is, the order of the sum is the same.  At r > 32 and small d the
+// row blocks finish long before the solve block: the reduction is off the step's path entirely; elsewhere it trades the serial
+// stage's single-CU fetch of n_sweep_wg rows (9.6 k of 28.8 k cycles at r = 40, tools/serial_prof.hip) for a tail on one
+// row workgroup.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void part_store(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ double part_load(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+template <int NT>
+__device__ __forceinline__ void tail_reduce_partials(const StepParams& p) {
+  __shared__ int s_last;
+  __shared__ double s_tail[8][2 * (RM + 1)];
+  DevState* st = p.st;
+  const int tid = threadIdx.x;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this workgroup's row is where every XCD sees it
+  __syncthreads();
+  if (tid == 0) {
+    const unsigned tk = __hip_atomic_fetch_add(&st->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = tk == (unsigned)p.n_sweep_wg - 1u;
+    if (last) __hip_atomic_store(&st->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = last;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  const int ne = p.rho_rows ? 2 * (p.r + 1) : p.r + 1, n = p.n_sweep_wg;
+  int nseg = NT / ne;
+  if (nseg > 8) nseg = 8;
+  if (tid < ne * nseg) {
+    const int e = tid % ne, sg = tid / ne;
+    const double* base = p.partials + e;
+    double acc = 0.0;
+    for (int w0 = sg; w0 < n; w0 += 16 * nseg) {       // as strided_sum: 16 clamped loads in flight, masked afterwards, fixed tree
+      double v[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v[q] = part_load(base + (size_t)min(w0 + q * nseg, n - 1) * p.ps);
+#pragma unroll
+      for (int q = 0; q < 16; ++q) v[q] = (w0 + q * nseg < n) ? v[q] : 0.0;
+      acc += (((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]))) +
+             (((v[8] + v[9]) + (v[10] + v[11])) + ((v[12] + v[13]) + (v[14] + v[15])));
+    }
+    s_tail[sg][e] = acc;
+  }
+  __syncthreads();
+  if (tid < ne) {
+    double a = 0.0;
+    for (int sg = 0; sg < nseg; ++sg) a += s_tail[sg][tid];
+    st->red[tid] = a;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Row sweep.  GS = lanes cooperating on one row (power of two >= nv = ceil(r / VEC)); each lane
 // owns one 16-byte vector of the row; a 256-thread workgroup covers 256/GS rows per pass and
 // keeps U passes of loads in flight.
@@ -412,8 +466,8 @@ __global__ __launch_bounds__(NT) void psmf_sweep_solve(StepParams p) {
     double s4 = 0.0;
 #pragma unroll
     for (int w = 0; w < NW; ++w) s4 += sm[w * (NE + 1) + tid];   // fixed order
-    if (tid < r) out[tid] = s4;
-    if (tid == NE) out[r] = s4;
+    if (tid < r) part_store(out + tid, s4);
+    if (tid == NE) part_store(out + r, s4);
   }
   if (rrow) {          // the weighted sums the same way (second half of the partial row)
     __syncthreads();
@@ -433,10 +487,11 @@ __global__ __launch_bounds__(NT) void psmf_sweep_solve(StepParams p) {
       double s4 = 0.0;
 #pragma unroll
       for (int w = 0; w < NW; ++w) s4 += sm[w * (NE + 1) + tid];
-      if (tid < r) out[r + 1 + tid] = s4;
-      if (tid == NE) out[2 * r + 1] = s4;
+      if (tid < r) part_store(out + r + 1 + tid, s4);
+      if (tid == NE) part_store(out + 2 * r + 1, s4);
     }
   }
+  if (p.tail_reduce) tail_reduce_partials<NT>(p);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -37,7 +37,10 @@ __host__ __device__ constexpr int mgram_lds_doubles(int nt, int nw) {
 }
 
 // sZ: mgram_lds_doubles(NT, NW) doubles of LDS (dynamic: the serial stage of the same kernel has its own static arrays)
-template <typename T, int NT, int NW>
+// MODE 1 (round 5): the WEIGHTED Gram of a non-uniform diagonal R, sum_i kappa_i c_i c_i^T with kappa_i = 1 / (rho rho_i + s) of the
+// current step (psmf.py:140-152 with a diagonal R) -- the same slabs, every row scaled by sqrt(kappa_i) as it is
+// stored, so that one image still serves both operands; partial rows of r * r doubles (no count).
+template <typename T, int NT, int NW, int MODE = 0>
 __device__ __forceinline__ void mgram_body(const StepParams& p, double* __restrict__ gpart, const int bid, const int nblk, double* sZ) {
   constexpr int S = mgram_stride(NT);
   constexpr int NTT = NT * (NT + 1) / 2;
@@ -49,7 +52,9 @@ __device__ __forceinline__ void mgram_body(const StepParams& p, double* __restri
   // st->k, not kq); clamped: the Gram "of the step after the last" is computed and never used
   long long trow = p.st->kq - p.series_t0;
   if (trow > (long long)p.mask_rows - 1) trow = (long long)p.mask_rows - 1;
-  const uint8_t* __restrict__ mk = p.mask + (size_t)trow * dl;
+  const uint8_t* __restrict__ mk = MODE == 0 ? p.mask + (size_t)trow * dl : nullptr;
+  const double* __restrict__ rrow = p.rho_rows;
+  const double rsc = p.st->rho, sk = p.st->s;
   double* slab = sZ + w * 16 * S;
   for (int idx = lane; idx < 16 * S; idx += 64) slab[idx] = 0.0;        // columns rp .. 16 NT stay zero
   f64x4 acc[NTT];
@@ -73,12 +78,14 @@ __device__ __forceinline__ void mgram_body(const StepParams& p, double* __restri
   int sl = bid * NW + w;
   VT v[NV];
   uint8_t m[NV];
+  double wr[NV];
   auto load_slab = [&](const int s_) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
       const int row = min(s_ * 16 + vrow[i], dl - 1);
       v[i] = *reinterpret_cast<const VT*>(C + (size_t)row * rp + vcol[i]);
-      m[i] = mk[row];
+      if (MODE == 0) m[i] = mk[row];
+      else wr[i] = rrow[row];
     }
   };
   if (sl < nslab) load_slab(sl);
@@ -86,10 +93,11 @@ __device__ __forceinline__ void mgram_body(const StepParams& p, double* __restri
     const int row0 = sl * 16;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-      const bool on = von[i] && (row0 + vrow[i] < dl) && m[i] != 0;
+      const bool on = von[i] && (row0 + vrow[i] < dl) && (MODE == 1 || m[i] != 0);
+      const double sw = MODE == 1 ? rsqrt(rsc * wr[i] + sk) : 1.0;
       if (von[i]) {
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) slab[vrow[i] * S + vcol[i] + j] = on ? (double)v[i][j] : 0.0;
+        for (int j = 0; j < VEC; ++j) slab[vrow[i] * S + vcol[i] + j] = on ? (MODE == 1 ? (double)v[i][j] * sw : (double)v[i][j]) : 0.0;
       }
       cnt += (on && vcol[i] == 0) ? 1.0 : 0.0;          // the lane that holds a row's first vector counts the row
     }
@@ -143,7 +151,7 @@ __device__ __forceinline__ void mgram_body(const StepParams& p, double* __restri
   cnt = wave_sum(cnt);
   if (lane == 0) sCnt[w] = cnt;
   __syncthreads();
-  const size_t gs = (size_t)r * r + 1;
+  const size_t gs = (size_t)r * r + (MODE == 0 ? 1 : 0);
   double* out = gpart + (size_t)bid * gs;
   for (int idx = tid; idx < r * r; idx += NW * 64) {
     int i = idx / r, j = idx - i * r;
@@ -151,11 +159,19 @@ __device__ __forceinline__ void mgram_body(const StepParams& p, double* __restri
     const int ii = i & 15, jj = j & 15;
     out[idx] = buf[(((i >> 4) * NT + (j >> 4)) * 4 + (ii >> 2)) * 64 + (ii & 3) * 16 + jj];
   }
-  if (tid == 0) {
+  if (MODE == 0 && tid == 0) {
     double c = 0.0;
     for (int ww = 0; ww < NW; ++ww) c += sCnt[ww];
     out[(size_t)r * r] = c;
   }
+}
+
+// the weighted Gram of the current step on its own (non-uniform diagonal R, per-step engine): gpart[blockIdx.x][r * r], reduced by
+// psmf_mgram_reduce into st->GR.  (psmf_gram_partial, the vector-unit Gram of psmf_set_state, took 170 us per timestep at d = 1e5, r = 32.)
+template <typename T, int NT, int NW>
+__global__ __launch_bounds__(NW * 64) void psmf_wgram_mfma(StepParams p, double* __restrict__ gpart) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  mgram_body<T, NT, NW, 1>(p, gpart, (int)blockIdx.x, (int)gridDim.x, reinterpret_cast<double*>(smem_raw));
 }
 
 // One launch for the serial stage of step k (block 0: psmf_serial's body, psmf_kernels.hip) AND the masked Gram of step k + 1 (blocks

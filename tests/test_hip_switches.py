@@ -70,6 +70,9 @@ CASES = [
     ("persistent_step_dual_off", {"PSMF_STEP_DUAL": "0"}, "step", "f64", 2500, 20, 40, True, False, "psmf_pstep_k"),
     ("wave_solve_off", {"PSMF_STEP_WAVE_SOLVE": "0"}, "step", "f64", 2500, 20, 40, False, False, "psmf_sweep_solve"),
     ("sweep_threads_256", {"PSMF_STEP_PERSISTENT": "0", "PSMF_SWEEP_THREADS": "256"}, "step", "f64", 2500, 20, 40, True, False, "psmf_sweep_solve"),
+    ("tail_reduce_off", {"PSMF_STEP_PERSISTENT": "0", "PSMF_TAIL_REDUCE": "0"}, "step", "f64", 2500, 20, 40, True, False, "psmf_sweep_solve"),
+    ("tail_reduce_off_r40", {"PSMF_TAIL_REDUCE": "0"}, "step", "f64", 1500, 40, 30, False, False, "psmf_sweep_solve"),
+    ("tail_reduce_forced", {"PSMF_STEP_PERSISTENT": "0", "PSMF_TAIL_REDUCE": "1"}, "step", "f32", 60000, 32, 30, False, False, "psmf_sweep_solve"),
     ("wave_big_off", {"PSMF_STEP_WAVE_BIG": "0"}, "step", "f64", 1500, 40, 30, False, False, "psmf_sweep_solve"),
     ("serial_wide_off", {"PSMF_SERIAL_WIDE": "0"}, "step", "f64", 1500, 40, 30, True, False, "psmf_sweep_solve"),
 ]
@@ -152,3 +155,32 @@ def test_persistent_kernel_is_deterministic_and_splits_like_one_run():
     cut32 = run((0, 17, 64, T), "f32")
     for n in ("C", "V", "mu", "P", "yp"):
         assert relerr(cut32[n], a[n]) < 2e-6, (n, relerr(cut32[n], a[n]))
+
+
+@pytest.mark.parametrize("r", [9, 24, 40, 64])
+@pytest.mark.parametrize("wgram", ["1", "0"], ids=["wgram_mfma", "wgram_vector"])
+def test_weighted_gram_of_a_nonuniform_R_both_kernels(wgram, r):
+    """Non-uniform diagonal R (psmf.py:140-152 with a diagonal R): the step's weighted Gram sum_i c_i c_i^T / (rho_i + s) on the
+    matrix cores (psmf_wgram_mfma, the default) and on the vector units (PSMF_WGRAM_MFMA=0), float32 and float64 storage."""
+    from rpsmf_amd import _capi as c
+
+    d, T = 3001, 40
+    rng = np.random.default_rng(90 + r)
+    rho = 0.3 + 2.0 * rng.random(d)
+    for storage in ("f64", "f32"):
+        Y, C0 = _problem(d, r, T, True, 500 + r, storage == "f32")
+        V0, P0, Q = 0.1 * np.eye(r), np.eye(r), 0.1 * np.eye(r)
+        st = O.State(C=C0, V=V0, mu=np.zeros(r), P=P0, Q=Q, rho=rho, lam=1.8)
+        st, Yp, _ = O.run_epoch(st, Y, O.Mode(robust=True), O.RandomWalkDyn(), want_grad=False)
+        with _env({"PSMF_WGRAM_MFMA": wgram}):
+            f = c.DeviceFilter(d, r, storage=storage, robust=True, engine="step", nonuniform_R=True)
+            f.set_row_noise(rho)
+            f.upload_series(Y)
+            f.set_state(C0, V0, P0, Q, np.zeros(r), rho=1.0, lambda0=1.8)
+            f.run(0, T)
+            s = f.get_state()
+            tol = 1e-9 if storage == "f64" else 1e-5
+            for n in ("C", "V", "mu", "P"):
+                assert relerr(s[n], getattr(st, n)) < tol, (wgram, storage, n, relerr(s[n], getattr(st, n)))
+            assert relerr(f.y_pred(0, T), Yp) < tol
+            f.close()
