@@ -52,7 +52,7 @@ struct Switches {
   bool bulk2 = true, filter3 = true, filter4 = true, filter6 = true, filter7 = true, filter6_dual = true, block_dual = true, block_flags = true, block_chain = true, block_pipe = true;
   bool force_collective = false;
   bool host_comm_flags = false;     // PSMF_HOST_COMM_FLAGS=1: device-flag hand-off (and chained filter launches) under a host-mediated communicator too
-  bool serial_wide = true, step_dual = true, tail_reduce = true, wgram_mfma = true;
+  bool serial_wide = true, step_dual = true, tail_reduce = true, wgram_mfma = true, pstep_big = true;
   int sweep_threads = 512;
   double ns_far4 = 0.6;            // filter4 / filter4s: residual at which a Newton-Schulz start is given up (PSMF_NS_FAR4; PSMF_NS_FAR, when set, rules both)
   bool ns_far_set = false;
@@ -64,7 +64,7 @@ struct Switches {
     force_collective = getenv("PSMF_FORCE_COLLECTIVE") != nullptr;
     { const char* e = getenv("PSMF_HOST_COMM_FLAGS"); host_comm_flags = e && atoi(e) != 0; }
     step_persistent = !off("PSMF_STEP_PERSISTENT");
-    serial_wide = !off("PSMF_SERIAL_WIDE"); step_dual = !off("PSMF_STEP_DUAL"); tail_reduce = !off("PSMF_TAIL_REDUCE"); wgram_mfma = !off("PSMF_WGRAM_MFMA");
+    serial_wide = !off("PSMF_SERIAL_WIDE"); step_dual = !off("PSMF_STEP_DUAL"); tail_reduce = !off("PSMF_TAIL_REDUCE"); wgram_mfma = !off("PSMF_WGRAM_MFMA"); pstep_big = !off("PSMF_PSTEP_BIG");
     { const char* e = getenv("PSMF_SWEEP_THREADS"); sweep_threads = (e && atoi(e) == 256) ? 256 : 512; }
     if (const char* e = getenv("PSMF_NS_FAR4")) ns_far4 = atof(e);
     ns_far_set = getenv("PSMF_NS_FAR") != nullptr;
@@ -1099,7 +1099,8 @@ int psmf_create(psmf_handle* out, const psmf_config* cfg) {
   }
   if (h->geo.sweep_lds > 48 * 1024)
     CREATE_TRY(hipFuncSetAttribute((const void*)sweep_kernel(h), hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->geo.sweep_lds));
-  if (h->engine == 1 && h->sw.step_persistent && cfg->r <= 32 && cfg->masked <= 1 && !cfg->nonuniform_R && cfg->dyn_kind <= PSMF_DYN_COS_PHASE) {
+  if (h->engine == 1 && h->sw.step_persistent && (cfg->r <= 32 || (h->sw.pstep_big && cfg->r <= 48 && cfg->masked == 0)) && cfg->masked <= 1 && !cfg->nonuniform_R &&
+      cfg->dyn_kind <= PSMF_DYN_COS_PHASE) {
     hipDeviceProp_t prop;
     CREATE_TRY(hipGetDeviceProperties(&prop, cfg->device));
     if (psmf::pstep_plan(cfg->d_local, cfg->r, prop.multiProcessorCount, cfg->storage == PSMF_F64, cfg->masked == 1, &h->ps_plan)) {

@@ -535,17 +535,24 @@ __device__ __forceinline__ void hub_col_reduce(const bool worker, const double p
 template <int RPAD, int NT, bool MASKED>
 __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
   constexpr bool SHARED = NT == 256;         // r > 32: 256-thread workgroups (a wave may hold 512 registers); all four waves are workers, the last two ALSO run the inversions
-  constexpr int NWK = 256;                   // worker threads: waves 0-3
+  constexpr int NWK = RPAD == 64 ? 384 : 256;     // worker threads: waves 0-3 (RPAD = 64: waves 0-5 -- six row groups of 8 rows each, all of the worker loop's threads)
   constexpr int NW = NT / 64;
   constexpr int RG = NWK / RPAD;
   constexpr int M = (RPAD * RPAD) / NWK > 0 ? (RPAD * RPAD) / NWK : 1;
-  constexpr int LS = RPAD + 1;               // row stride of the r x r LDS images
+  // BIG (RPAD = 64, 33 <= r <= 48): 16 elements of five matrices per worker do not fit beside the tile sweeps (2.7 KB of scratch per lane
+  // when it was tried) -- V, Q and Pbar live in LDS images like G, P+, W and Lbar already do, 48 x 49 each; a worker walks its (row
+  // group, column) elements through them, nothing r x r stays in registers across a timestep
+  constexpr bool BIG = RPAD == 64;
+  constexpr int MB = BIG ? 8 : 1;            // rows ig + 6 m < 48 of a worker's column
+  constexpr int LS = BIG ? 49 : RPAD + 1;    // row stride of the r x r LDS images
+  constexpr int IMG = BIG ? 48 * 49 : RPAD * (RPAD + 1);
+  constexpr int MR = BIG ? 1 : M;            // (the register copies of the small layouts)
   constexpr int NG = 4 * RPAD + 1;
   // threads of the fan-in.  512-thread hub: waves 0, 1, 4, 5 -- the SIMDs (wave id mod 4) of the two solve waves, 6 and 7, are shared
   // with waves 2 and 3, which therefore spend phase A asleep in the workgroup barrier instead of polling LDS beside the tile sweeps
   constexpr int NFT = SHARED ? (NW - 2) * 64 : 256;
   constexpr int NLT = SHARED ? NT : NT - 128; // threads that run the worker loop (the two solve waves have a loop of their own)
-  constexpr int LPC = NT >= 512 ? 8 : 1;     // lanes per column of the fan-in's second level (LPC x (r + 1) <= NFT)
+  constexpr int LPC = RPAD == 64 ? 4 : (NT >= 512 ? 8 : 1);     // lanes per column of the fan-in's second level (LPC x (r + 1) <= the worker loop's NLT threads: 4 x 49 at r = 48)
   const StepParams& p = q.sp;
   DevState* st = p.st;
   const int r = p.r, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -555,10 +562,13 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
   const int nwg = q.n_row_wg, ncol2 = q.ncol2, ncol = r + 1;
 
   double* sPp = reinterpret_cast<double*>(smem);
-  double* sW = sPp + RPAD * LS;
-  double* sL = sW + RPAD * LS;               // Lbar (inversions side by side, carried) or Pbar
-  double* sG = sL + RPAD * LS;
-  double* s_seg = sG + RPAD * LS;            // fan-in: [segment][ncol2]
+  double* sW = sPp + IMG;
+  double* sL = sW + IMG;                     // Lbar (inversions side by side, carried) or Pbar
+  double* sG = sL + IMG;
+  double* sV = sG + IMG;                     // BIG only: V, Q, Pbar
+  double* sQ = sV + (BIG ? IMG : 0);
+  double* sPb = sQ + (BIG ? IMG : 0);
+  double* s_seg = sPb + (BIG ? IMG : 0);     // fan-in: [segment][ncol2]
   double* s_red = s_seg + 2 * NT;
   double* s_he = s_red + NWK;                // h[0..r), ee at [r]
   double* s_w = s_he + 2 * (RM + 1);
@@ -584,11 +594,32 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
   const bool dual = p.solve_dual != 0;
   const int nsv = st->ns_valid;
   bool carried = dual && nsv == 7;
-  double Vv[M], Pv[M], Gv[M], Qv[M], Pbv[M];
-  bool val[M];
-  int ii[M];
+#define PS_BIG_FOR(...)                                                                                    \
+  _Pragma("unroll") for (int m = 0; m < MB; ++m) {                                                         \
+    const int i_ = ig + m * RG;                                                                            \
+    const bool v_ = worker && j < r && i_ < r;                                                             \
+    const int a_ = v_ ? i_ * LS + j : 0, at_ = v_ ? j * LS + i_ : 0;                                       \
+    (void)a_; (void)at_;                                                                                   \
+    __VA_ARGS__                                                                                            \
+  }
+  double Vv[MR], Pv[MR], Gv[MR], Qv[MR], Pbv[MR];
+  bool val[MR];
+  int ii[MR];
+  double pscale_last = 1.0;
+  if constexpr (BIG) {
+    PS_BIG_FOR({
+      const int idx = v_ ? i_ * r + j : 0;
+      const double lv = st->V[idx], lg = st->G[idx], lq = st->Q[idx], lp = st->Pbar[idx], lpt = st->Pbar[v_ ? j * r + i_ : 0], ll = st->Lbar[idx];
+      if (v_) {
+        const double pb = 0.5 * (lp + lpt);
+        sV[a_] = lv; sG[a_] = lg; sQ[a_] = lq; sPb[a_] = pb;
+        sL[a_] = carried ? ll : pb;
+      }
+    })
+  }
 #pragma unroll
-  for (int m = 0; m < M; ++m) {
+  for (int m = 0; m < MR; ++m) {
+    if constexpr (BIG) { ii[m] = 0; val[m] = false; Vv[m] = Gv[m] = Qv[m] = Pbv[m] = Pv[m] = 0.0; continue; }
     ii[m] = ig + m * RG;
     val[m] = worker && (j < r) && (ii[m] < r);
     const int idx = val[m] ? ii[m] * r + j : 0;
@@ -674,8 +705,7 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
         const int role = wv - (NW - 2);
         if constexpr (RPAD <= 16) hub_solve<1>(role, dual, carried, r, s_sc[0], s_sc[1], s_sc[2], sL, sG, sPp, sW, LS, s_ctl + 2);
         else if constexpr (RPAD == 32) hub_solve<2>(role, dual, carried, r, s_sc[0], s_sc[1], s_sc[2], sL, sG, sPp, sW, LS, s_ctl + 2);
-        else if (r <= 48) hub_solve<3>(role, dual, carried, r, s_sc[0], s_sc[1], s_sc[2], sL, sG, sPp, sW, LS, s_ctl + 2);
-        else hub_solve<4>(role, dual, carried, r, s_sc[0], s_sc[1], s_sc[2], sL, sG, sPp, sW, LS, s_ctl + 2);
+        else hub_solve<3>(role, dual, carried, r, s_sc[0], s_sc[1], s_sc[2], sL, sG, sPp, sW, LS, s_ctl + 2);      // (RPAD = 64: r <= 48, pstep_plan)
       }
       PS_PROF(0);                                                 // the inversion
       ps_bar();                                                   // end of phase A
@@ -709,8 +739,7 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
         const int role = wv - (NW - 2);
         if constexpr (RPAD <= 16) hub_solve<1>(role, dual, carried, r, s_sc[0], s_sc[1], s_sc[2], sL, sG, sPp, sW, LS, s_ctl + 2);
         else if constexpr (RPAD == 32) hub_solve<2>(role, dual, carried, r, s_sc[0], s_sc[1], s_sc[2], sL, sG, sPp, sW, LS, s_ctl + 2);
-        else if (r <= 48) hub_solve<3>(role, dual, carried, r, s_sc[0], s_sc[1], s_sc[2], sL, sG, sPp, sW, LS, s_ctl + 2);
-        else hub_solve<4>(role, dual, carried, r, s_sc[0], s_sc[1], s_sc[2], sL, sG, sPp, sW, LS, s_ctl + 2);
+        else hub_solve<3>(role, dual, carried, r, s_sc[0], s_sc[1], s_sc[2], sL, sG, sPp, sW, LS, s_ctl + 2);
       }
     } else {
       if (wv == 0) {
@@ -767,10 +796,12 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
       if (u == 0) s_he[col] = a;
     }
     // P+ and W of the solve waves, symmetrised
+    if constexpr (!BIG) {
 #pragma unroll
-    for (int m = 0; m < M; ++m) {
-      if (p.coef_update) Pv[m] = val[m] ? 0.5 * (sPp[ii[m] * LS + j] + sPp[j * LS + ii[m]]) : 0.0;
-      else Pv[m] = Pbv[m];
+      for (int m = 0; m < M; ++m) {
+        if (p.coef_update) Pv[m] = val[m] ? 0.5 * (sPp[ii[m] * LS + j] + sPp[j * LS + ii[m]]) : 0.0;
+        else Pv[m] = Pbv[m];
+      }
     }
     ps_bar();
     PS_PROF(3);        // h, ee summed; P+, W read
@@ -781,8 +812,12 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
     const double mu_old = mu_new;
     if (p.coef_update) {
       double part = 0.0;
+      if constexpr (BIG) {
+        PS_BIG_FOR({ part += v_ ? 0.5 * (sPp[a_] + sPp[at_]) * s_he[i_] : 0.0; })
+      } else {
 #pragma unroll
-      for (int m = 0; m < M; ++m) part += val[m] ? Pv[m] * s_he[min(ii[m], r - 1)] : 0.0;
+        for (int m = 0; m < M; ++m) part += val[m] ? Pv[m] * s_he[min(ii[m], r - 1)] : 0.0;
+      }
       hub_col_reduce<RPAD, NWK>(worker, part, s_red, s_vec);      // s_vec = P+ h
       const double bPb = ps_wave_sum(lane < r ? s_he[lane] * s_vec[lane] : 0.0);
       quad -= kappa * kappa * bPb;
@@ -821,8 +856,23 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
     }
     const double iq_old = s_sc[1];
     const double iom = p.robust ? fast_rcp(omega) : 1.0;      // (a float64 division per element is ~30 instructions: one reciprocal instead)
+    pscale_last = pscale;
+    if constexpr (BIG) {
+      PS_BIG_FOR({
+        if (v_) {
+          const double wi = s_w[i_], hi = s_he[i_], hj = s_he[j];
+          sV[a_] = vscale * (sV[a_] - wi * wj * invN);
+          if (p.track_g) sG[a_] += (hi * wj + wi * hj) * invN + ee * (wi * wj) * (invN * invN);
+          if (qscale != 1.0) sQ[a_] *= qscale;
+          if (dual) {
+            const double wsym = 0.5 * (sW[a_] + sW[at_]);
+            sL[a_] = ((i_ == j ? iq_old : 0.0) - wsym * iq_old * iq_old) * iom;
+          }
+        }
+      })
+    }
 #pragma unroll
-    for (int m = 0; m < M; ++m) {
+    for (int m = 0; m < (BIG ? 0 : M); ++m) {
       if (val[m]) {
         const double wi = s_w[ii[m]], hi = s_he[ii[m]], hj = s_he[j];
         Vv[m] = vscale * (Vv[m] - wi * wj * invN);
@@ -875,8 +925,19 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
     ps_bar();
     PS_PROF(5);        // gradient, scalars, r x r updates, Adam, mu_bar
     double part = 0.0, gp = 0.0;
+    if constexpr (BIG) {
+      PS_BIG_FOR({
+        if (v_) {
+          const double pv = p.coef_update ? pscale * (0.5 * (sPp[a_] + sPp[at_])) : sPb[a_];      // (sL is being rewritten: Pbar of the step from its own image)
+          const double pb = p.pbar_predict ? s_f[i_] * pv * s_f[j] + qs * sQ[a_] : pv;
+          sPb[a_] = pb;
+          part += sV[a_] * s_mub[i_];
+          gp += sG[a_] * pb;
+        }
+      })
+    }
 #pragma unroll
-    for (int m = 0; m < M; ++m) {
+    for (int m = 0; m < (BIG ? 0 : M); ++m) {
       if (val[m]) {
         const double pb = p.pbar_predict ? s_f[ii[m]] * Pv[m] * s_f[j] + qs * Qv[m] : Pv[m];
         Pbv[m] = pb;
@@ -943,7 +1004,7 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
         if (knext - p.series_t0 <= (long long)p.mask_rows - 1) { p.sc_hist[2 * tr_] = sN; p.sc_hist[2 * tr_ + 1] = eta; }
       }
     } else if (p.eta_full) {
-      eta += ((s4[0] + s4[1]) + (s4[2] + s4[3])) / dd;
+      eta += (((s4[0] + s4[1]) + (s4[2] + s4[3])) + (BIG ? s4[4] + s4[5] : 0.0)) / dd;
     }
     PS_PROF(6);        // V mu_bar, s, eta
     const double Nn = sN + eta;
@@ -971,12 +1032,16 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
       }
     }
     if (!dual) {      // inversions one after the other: the solve wave starts from Pbar
+      if constexpr (BIG) {
+        PS_BIG_FOR({ if (v_) sL[a_] = sPb[a_]; })
+      } else {
 #pragma unroll
-      for (int m = 0; m < M; ++m) if (val[m]) sL[ii[m] * LS + j] = Pbv[m];
+        for (int m = 0; m < M; ++m) if (val[m]) sL[ii[m] * LS + j] = Pbv[m];
+      }
     }
     if (tid == 0) {
       s_sc[0] = kap_n;
-      s_sc[1] = fast_rcp(Qv[0]);
+      s_sc[1] = fast_rcp(BIG ? sQ[0] : Qv[0]);
     }
     carried = dual;
     N0 = Nn; kappa0 = kap_n; s0 = sN; eta0 = eta; k0 = knext;
@@ -993,8 +1058,22 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
     for (int rep = 0; rep < PSTEP_PKT_REP; ++rep) gran_store(q.pkt + (size_t)rep * (PSTEP_REP_STRIDE / 8) + (NG - 1), PSTEP_ABORT_TAG, 1u);        // the row workgroups leave at their next poll
     if (st->err == 0) st->err = badp ? (int)(k0 + 1) : -8;
   }
+  if constexpr (BIG) {
+    PS_BIG_FOR({
+      if (v_) {
+        const int idx = i_ * r + j;
+        st->V[idx] = sV[a_];
+        if (n_done > 0) st->P[idx] = p.coef_update ? pscale_last * (0.5 * (sPp[a_] + sPp[at_])) : sPb[a_];
+        st->G[idx] = sG[a_];
+        st->Q[idx] = sQ[a_];
+        st->Pbar[idx] = sPb[a_];
+        if (n_done > 0 && dual) { st->Lbar[idx] = sL[a_]; st->XpY[idx] = 0.5 * (sW[a_] + sW[at_]); }
+        if (n_done > 0 && p.coef_update) st->Pplus[idx] = sPp[a_];
+      }
+    })
+  }
 #pragma unroll
-  for (int m = 0; m < M; ++m) {
+  for (int m = 0; m < (BIG ? 0 : M); ++m) {
     if (val[m]) {
       const int idx = ii[m] * r + j;
       st->V[idx] = Vv[m];
@@ -1050,8 +1129,8 @@ __global__ __launch_bounds__(NT) void psmf_pstep_k(PstepParams q) {
 }
 
 typedef void (*pstep_fn_t)(PstepParams);
-constexpr int pstep_nt(int rpad) { return rpad > 32 ? 256 : 512; }
-int pstep_np_variant(int rpad, int np) { return rpad > 32 ? (np <= 8 ? 8 : PSTEP_NPMAX_BIG) : (np <= 4 ? 4 : (np <= 8 ? 8 : PSTEP_NPMAX)); }
+constexpr int pstep_nt(int rpad) { return 512; }
+int pstep_np_variant(int rpad, int np) { (void)rpad; return np <= 4 ? 4 : (np <= 8 ? 8 : PSTEP_NPMAX); }
 
 template <int RPAD, bool MASKED>
 pstep_fn_t pstep_kernel_r(bool f64, int np) {
@@ -1064,6 +1143,7 @@ pstep_fn_t pstep_kernel(int rpad, bool f64, int np, bool masked) {
     case 8: return masked ? pstep_kernel_r<8, true>(f64, np) : pstep_kernel_r<8, false>(f64, np);
     case 16: return masked ? pstep_kernel_r<16, true>(f64, np) : pstep_kernel_r<16, false>(f64, np);
     case 32: return masked ? pstep_kernel_r<32, true>(f64, np) : pstep_kernel_r<32, false>(f64, np);
+    case 64: return masked ? nullptr : pstep_kernel_r<64, false>(f64, np);      // 33 <= r <= 48, unmasked (the hub's LDS-resident layout)
   }
   return nullptr;
 }
@@ -1074,20 +1154,20 @@ int pstep_rpad(int r) { return r <= 8 ? 8 : (r <= 16 ? 16 : (r <= 32 ? 32 : 64))
 
 }  // namespace
 
-// r > 32 is NOT instantiated: with 16 elements of five 64 x 64 matrices per worker thread beside the 3 x 3 / 4 x 4 tile sweeps the hub needs
-// more than the 512 registers a wave of a 256-thread workgroup may hold (hipcc: 2.7 KB of scratch per lane, measured before it was
-// dropped) -- those ranks keep the two launches per timestep (psmf_kernels.hip), whose serial stage spreads the state over 512 workers.
-static pstep_fn_t pstep_kernel_any(int rpad, bool f64, int np, bool masked) { return rpad > 32 ? nullptr : pstep_kernel(rpad, f64, np, masked); }
+// 33 <= r <= 48: the hub keeps every r x r matrix in LDS (pstep_hub, BIG) -- with 16 elements of five 64 x 64 matrices per worker thread in
+// registers beside the 3 x 3 tile sweeps it needed more than a wave can hold (hipcc: 2.7 KB of scratch per lane, measured).  r > 48 (4 x 4
+// tiles, seven 64 x 65 images = 233 KB of LDS) and masked handles at r > 32 keep the launches per timestep (psmf_kernels.hip).
+static pstep_fn_t pstep_kernel_any(int rpad, bool f64, int np, bool masked) { return pstep_kernel(rpad, f64, np, masked); }
 
 bool pstep_plan(int d_local, int r, int n_cu, bool storage_f64, bool masked, PstepPlan* out) {
-  if (r < 1 || r > 32 || d_local < 1 || n_cu < 2) return false;
+  if (r < 1 || r > 48 || (r > 32 && masked) || d_local < 1 || n_cu < 2) return false;
   const int rpad = pstep_rpad(r);
   const int rpw = pstep_nt(rpad) / (rpad / 4);
   int nwg = (d_local + rpw - 1) / rpw;
   if (nwg > n_cu - 1) nwg = n_cu - 1;
   int rows = (d_local + nwg - 1) / nwg;
   int np = (rows + rpw - 1) / rpw;
-  if (np > (rpad > 32 ? PSTEP_NPMAX_BIG : PSTEP_NPMAX)) return false;
+  if (np > PSTEP_NPMAX) return false;
   (void)storage_f64;
   np = pstep_np_variant(rpad, np);       // the kernel instance runs exactly this many passes: fewer, fuller workgroups
   rows = np * rpw;
@@ -1095,7 +1175,8 @@ bool pstep_plan(int d_local, int r, int n_cu, bool storage_f64, bool masked, Pst
   {      // the hub's fan-in: (threads of its four fan-in waves / pairs of columns, at most 24) segments x PSTEP_FANIN_ROWS rows each
     const int npair = ((r + 1 + 1) & ~1) / 2;
     int S = (4 * 64) / npair;
-    if (S > 24) S = 24;
+    const int cap = rpad > 32 ? 12 : 24;      // 3 x the lanes per column of the second level (pstep_hub: LPC)
+    if (S > cap) S = cap;
     if (nwg > S * PSTEP_FANIN_ROWS) return false;
   }
   out->n_row_wg = nwg;
@@ -1128,9 +1209,10 @@ bool pstep_plan(int d_local, int r, int n_cu, bool storage_f64, bool masked, Pst
 }
 
 hipError_t pstep_init() {
-  for (int rpad = 8; rpad <= 32; rpad *= 2)
+  for (int rpad = 8; rpad <= 64; rpad *= 2)
     for (int f = 0; f < 4; ++f)
       for (int np = 4; np <= 16; np *= 2) {      // (every instance is reached by one of these)
+        if (rpad == 64 && (f & 2)) continue;
         const hipError_t e = hipFuncSetAttribute((const void*)pstep_kernel_any(rpad, (f & 1) != 0, np, (f & 2) != 0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pstep_lds_bytes(rpad));
         if (e != hipSuccess) return e;
       }

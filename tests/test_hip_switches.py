@@ -71,10 +71,12 @@ CASES = [
     ("wave_solve_off", {"PSMF_STEP_WAVE_SOLVE": "0"}, "step", "f64", 2500, 20, 40, False, False, "psmf_sweep_solve"),
     ("sweep_threads_256", {"PSMF_STEP_PERSISTENT": "0", "PSMF_SWEEP_THREADS": "256"}, "step", "f64", 2500, 20, 40, True, False, "psmf_sweep_solve"),
     ("tail_reduce_off", {"PSMF_STEP_PERSISTENT": "0", "PSMF_TAIL_REDUCE": "0"}, "step", "f64", 2500, 20, 40, True, False, "psmf_sweep_solve"),
-    ("tail_reduce_off_r40", {"PSMF_TAIL_REDUCE": "0"}, "step", "f64", 1500, 40, 30, False, False, "psmf_sweep_solve"),
+    ("tail_reduce_off_r40", {"PSMF_TAIL_REDUCE": "0", "PSMF_PSTEP_BIG": "0"}, "step", "f64", 1500, 40, 30, False, False, "psmf_sweep_solve"),
+    ("pstep_big_default", {}, "step", "f64", 1500, 40, 30, True, False, "psmf_pstep_k"),
+    ("pstep_big_off", {"PSMF_PSTEP_BIG": "0"}, "step", "f64", 1500, 40, 30, True, False, "psmf_sweep_solve"),
     ("tail_reduce_forced", {"PSMF_STEP_PERSISTENT": "0", "PSMF_TAIL_REDUCE": "1"}, "step", "f32", 60000, 32, 30, False, False, "psmf_sweep_solve"),
     ("wave_big_off", {"PSMF_STEP_WAVE_BIG": "0"}, "step", "f64", 1500, 40, 30, False, False, "psmf_sweep_solve"),
-    ("serial_wide_off", {"PSMF_SERIAL_WIDE": "0"}, "step", "f64", 1500, 40, 30, True, False, "psmf_sweep_solve"),
+    ("serial_wide_off", {"PSMF_SERIAL_WIDE": "0", "PSMF_PSTEP_BIG": "0"}, "step", "f64", 1500, 40, 30, True, False, "psmf_sweep_solve"),
 ]
 
 
