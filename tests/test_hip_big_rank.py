@@ -104,3 +104,57 @@ def test_big_rank_masked_filter(robust):
     errs = dict(Epred=relerr(res["Epred"][0], ep[0, 1:]), Efull=relerr(res["Efull"][0], ef[0, 1:]), inside=abs(res["inside"][0] - ib),
                 C=relerr(res["C"][0], st["C"]), X=relerr(res["X"][0], st["X"]), Yrec=relerr(res["Yrec"][0], st["Yrec"]))
     assert max(errs.values()) < 5e-9, errs
+
+
+PERSISTENT_BIG = [
+    ("cos_phase_r36", 36, dict(dyn="cos"), False),
+    ("cos_phase_recursive_r41_rPSMF", 41, dict(dyn="cos", recursive=True, update_every=5), True),
+    ("simplified_hooks_r45", 45, dict(coef_update=False, eta_full=False, pbar_predict=False), False),
+    ("general_Q_r37", 37, dict(general_Q=True), True),
+    ("schedules_r48", 48, dict(sched=True), False),
+]
+
+
+@pytest.mark.parametrize("name,r,opts,robust", PERSISTENT_BIG, ids=[c[0] for c in PERSISTENT_BIG])
+def test_persistent_kernel_at_33_to_48_matches_the_launched_form(name, r, opts, robust):
+    """33 <= r <= 48 on the persistent per-step kernel (round 5: the hub with LDS-resident matrices, psmf_pstep.hip) against the two
+    launches per timestep, which the tests above and test_hip_step_engine_random.py pin to the oracle: every mode the kernel takes,
+    a run cut in three."""
+    import os
+
+    c = _capi()
+    d, T = 1100 + r, 36
+    Y, C0 = _problem(d, r, T, 900 + r, robust)
+    rng = np.random.default_rng(r)
+    A = rng.standard_normal((r, r)) / np.sqrt(r)
+    Q = 0.1 * np.eye(r) + (0.05 * (A @ A.T) if opts.get("general_Q") else 0.0)
+    kw = {k: v for k, v in opts.items() if k in ("coef_update", "eta_full", "pbar_predict", "recursive", "update_every")}
+    if opts.get("dyn") == "cos":
+        kw["dyn_kind"] = c.DYN_COS_PHASE
+    theta = 0.01 * (1 + np.arange(r)) / r if opts.get("dyn") == "cos" else None
+    out = {}
+    old = os.environ.get("PSMF_STEP_PERSISTENT")
+    try:
+        for persistent in (True, False):
+            os.environ["PSMF_STEP_PERSISTENT"] = "1" if persistent else "0"
+            f = c.DeviceFilter(d, r, storage="f64", robust=robust, engine="step", **kw)
+            if opts.get("sched"):
+                f.set_schedules(1.0 + 0.1 * np.sin(np.arange(T + 1)), 1.0 + 0.2 * np.cos(np.arange(T + 1)))
+            f.upload_series(Y)
+            f.set_state(C0, 0.1 * np.eye(r), np.eye(r), Q, np.zeros(r), rho=1.0, lambda0=1.8, theta=theta)
+            if kw.get("recursive"):
+                f.set_adam(np.zeros(r), np.zeros(r))
+            assert f.geometry()["filter_kernel"] == ("psmf_pstep_k" if persistent else "psmf_sweep_solve")
+            for a, b in ((0, 7), (7, 8), (8, T)):
+                f.run(a, b)
+            s = f.get_state()
+            s["yp"] = f.y_pred(0, T)
+            out[persistent] = s
+            f.close()
+    finally:
+        if old is None:
+            os.environ.pop("PSMF_STEP_PERSISTENT", None)
+        else:
+            os.environ["PSMF_STEP_PERSISTENT"] = old
+    for n in ("C", "V", "mu", "P", "Q", "yp") + (("theta", "gradsum") if theta is not None else ()):
+        assert relerr(out[True][n], out[False][n]) < 1e-10, (name, n, relerr(out[True][n], out[False][n]))

@@ -112,6 +112,16 @@ if __name__ == "__main__":
         check(1500, 12, 40, False, "f64", dyn=c.DYN_COS_PHASE)
         check(1500, 24, 40, True, "f64", dyn=c.DYN_COS_PHASE, recursive=True, update_every=5)
         check(900, 8, 30, False, "f64", coef_update=False, eta_full=False, pbar_predict=False)
+        # 33 <= r <= 48: the hub with LDS-resident matrices
+        check(3000, 40, 30, False, "f64")
+        check(2500, 48, 30, True, "f64")
+        check(2000, 33, 30, True, "f32")
+        check(1500, 37, 30, False, "f64", general_Q=True)
+        check(1500, 44, 30, True, "f64", general_Q=True)
+        check(1200, 36, 40, False, "f64", dyn=c.DYN_COS_PHASE)
+        check(1200, 41, 40, True, "f64", dyn=c.DYN_COS_PHASE, recursive=True, update_every=5)
+        check(900, 45, 30, False, "f64", coef_update=False, eta_full=False, pbar_predict=False)
+        check(40000, 40, 40, False, "f32")
     timing(100000, 32, 2000, "f32")
     if not quick:
         timing(100000, 32, 2000, "f64")
@@ -119,3 +129,7 @@ if __name__ == "__main__":
         timing(20000, 32, 2000, "f64")
         timing(10000, 20, 2000, "f32")
         timing(20000, 10, 2000, "f64")
+        timing(20000, 40, 2000, "f64")
+        timing(20000, 48, 2000, "f64")
+        timing(50000, 40, 2000, "f32")
+        timing(5000, 36, 2000, "f64", robust=True)
