@@ -5,7 +5,6 @@
 namespace psmf {
 
 constexpr int PSTEP_NPMAX = 12;      // row passes a row workgroup can keep in registers (4 float64 per lane and pass; y_k beside them)
-constexpr int PSTEP_NPMAX_BIG = 32;  // ... of the 256-thread instances (r > 32: 16 rows per pass, 512 registers per wave)
 constexpr int PSTEP_PKT_MAX = 4 * RM + 1;      // granules of the hub -> rows packet
 // Replicas of words that MANY workgroups poll at once, 4 KB apart; workgroup i polls replica i % R, the writers store all replicas.
 // Measured (d = 1e5, r = 32): eight replicas of the hub's packet COST 0.9 us per timestep (24 granule stores per lane of the publishing

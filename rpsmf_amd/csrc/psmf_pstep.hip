@@ -1118,9 +1118,9 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
 }
 
 // NP: row passes of a row workgroup, all of them unrolled and executed (rows beyond the workgroup's share are masked): no branch
-// between the passes, so their dot products, lane sums and updates interleave.  NT: threads per workgroup -- 512 for r <= 32; 256 for
-// r > 32, where the solve waves keep 3 x 3 / 4 x 4 tiles of 16 x 16 in registers and the workers 32 elements of five 64 x 64 matrices
-// each (a wave of a 256-thread workgroup may hold 512 registers).
+// between the passes, so their dot products, lane sums and updates interleave.  NT: threads per workgroup -- 512 in every instance
+// (RPAD = 64, 33 <= r <= 48: the hub's r x r matrices live in LDS, pstep_hub BIG; its 256-thread form with everything in registers, the
+// SHARED branches of pstep_hub, spilled 2.7 KB per lane and is not instantiated).
 template <typename T, int RPAD, int NP, int NT, bool MASKED>
 __global__ __launch_bounds__(NT) void psmf_pstep_k(PstepParams q) {
   extern __shared__ __attribute__((aligned(16))) char ps_smem[];
