@@ -892,6 +892,10 @@ def main():
                     other["small_rank_r12"] = run_filter_config(_capi, "r12", 10_000, 12, 5_000, False)
                 except Exception as e:
                     other["small_rank_r12"] = {"error": repr(e)}
+                try:     # beyond the blocked engine's r <= 32: the persistent per-step kernel with the hub's matrices in LDS (33 <= r <= 48)
+                    other["rank_40_per_step_engine"] = run_filter_config(_capi, "r40", 20_000, 40, 3_000, False, passes=2, storage="f64")
+                except Exception as e:
+                    other["rank_40_per_step_engine"] = {"error": repr(e)}
                 try:
                     other["ExperimentSynthetic_hooks"] = run_synthetic_simplified(_capi)
                 except Exception as e:
