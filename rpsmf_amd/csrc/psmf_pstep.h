@@ -14,6 +14,7 @@ constexpr int PSTEP_PKT_REP = 1;
 constexpr int PSTEP_GF_REP = 8;
 constexpr int PSTEP_REP_STRIDE = 4096;         // bytes between replicas
 constexpr int PSTEP_FANIN_ROWS = 17;           // partial rows one thread of the hub's fan-in sums (all its loads in flight at once)
+constexpr int PSTEP_FANIN_ROWS_BIG = 20;       // ... at 33 <= r <= 48 (the workers of that hub hold nothing in registers): d_local = 1e5 at r = 48 is 196 rows of 10 segments
 
 struct PstepParams {
   StepParams sp;               // the handle's parameter block

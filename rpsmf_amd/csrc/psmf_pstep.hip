@@ -765,12 +765,13 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
         double a0 = 0.0, a1 = 0.0;
         // every load of the thread in flight at once: ONE memory round trip (rows f_seg, f_seg + S, ...: at most PSTEP_FANIN_ROWS of them,
         // which pstep_plan guarantees), summed in fixed order
-        ps_f64pair x[PSTEP_FANIN_ROWS];
+        constexpr int FR = BIG ? PSTEP_FANIN_ROWS_BIG : PSTEP_FANIN_ROWS;
+        ps_f64pair x[FR];
         const __amdgpu_buffer_rsrc_t rs = wt_rsrc(q.part, (unsigned)nwg * (unsigned)ncol2 * 8u);
 #pragma unroll
-        for (int u = 0; u < PSTEP_FANIN_ROWS; ++u) x[u] = wt_load2(rs, (min(f_seg + u * S, nwg - 1) * ncol2 + 2 * f_pi) * 8);
+        for (int u = 0; u < FR; ++u) x[u] = wt_load2(rs, (min(f_seg + u * S, nwg - 1) * ncol2 + 2 * f_pi) * 8);
 #pragma unroll
-        for (int u = 0; u < PSTEP_FANIN_ROWS; ++u) {
+        for (int u = 0; u < FR; ++u) {
           const bool in = f_seg + u * S < nwg;
           a0 += in ? x[u].x : 0.0;
           a1 += in ? x[u].y : 0.0;
@@ -1130,7 +1131,10 @@ __global__ __launch_bounds__(NT) void psmf_pstep_k(PstepParams q) {
 
 typedef void (*pstep_fn_t)(PstepParams);
 constexpr int pstep_nt(int rpad) { return 512; }
-int pstep_np_variant(int rpad, int np) { (void)rpad; return np <= 4 ? 4 : (np <= 8 ? 8 : PSTEP_NPMAX); }
+// RPAD = 64 (16 lanes per row, 32 rows per pass): a fourth variant of 16 passes = 512 rows per workgroup, so that d_local = 1e5 fits the
+// 204 partial rows the hub's fan-in takes at r >= 40
+constexpr int PSTEP_NPMAX_BIG = 16;
+int pstep_np_variant(int rpad, int np) { return np <= 4 ? 4 : (np <= 8 ? 8 : (np <= PSTEP_NPMAX || rpad <= 32 ? PSTEP_NPMAX : PSTEP_NPMAX_BIG)); }
 
 template <int RPAD, bool MASKED>
 pstep_fn_t pstep_kernel_r(bool f64, int np) {
@@ -1143,7 +1147,10 @@ pstep_fn_t pstep_kernel(int rpad, bool f64, int np, bool masked) {
     case 8: return masked ? pstep_kernel_r<8, true>(f64, np) : pstep_kernel_r<8, false>(f64, np);
     case 16: return masked ? pstep_kernel_r<16, true>(f64, np) : pstep_kernel_r<16, false>(f64, np);
     case 32: return masked ? pstep_kernel_r<32, true>(f64, np) : pstep_kernel_r<32, false>(f64, np);
-    case 64: return masked ? nullptr : pstep_kernel_r<64, false>(f64, np);      // 33 <= r <= 48, unmasked (the hub's LDS-resident layout)
+    case 64:      // 33 <= r <= 48, unmasked (the hub's LDS-resident layout)
+      if (masked) return nullptr;
+      if (np > PSTEP_NPMAX) return f64 ? psmf_pstep_k<double, 64, PSTEP_NPMAX_BIG, 512, false> : psmf_pstep_k<float, 64, PSTEP_NPMAX_BIG, 512, false>;
+      return pstep_kernel_r<64, false>(f64, np);
   }
   return nullptr;
 }
@@ -1167,7 +1174,7 @@ bool pstep_plan(int d_local, int r, int n_cu, bool storage_f64, bool masked, Pst
   if (nwg > n_cu - 1) nwg = n_cu - 1;
   int rows = (d_local + nwg - 1) / nwg;
   int np = (rows + rpw - 1) / rpw;
-  if (np > PSTEP_NPMAX) return false;
+  if (np > (rpad > 32 ? PSTEP_NPMAX_BIG : PSTEP_NPMAX)) return false;
   (void)storage_f64;
   np = pstep_np_variant(rpad, np);       // the kernel instance runs exactly this many passes: fewer, fuller workgroups
   rows = np * rpw;
@@ -1177,7 +1184,7 @@ bool pstep_plan(int d_local, int r, int n_cu, bool storage_f64, bool masked, Pst
     int S = (4 * 64) / npair;
     const int cap = rpad > 32 ? 12 : 24;      // 3 x the lanes per column of the second level (pstep_hub: LPC)
     if (S > cap) S = cap;
-    if (nwg > S * PSTEP_FANIN_ROWS) return false;
+    if (nwg > S * (rpad > 32 ? PSTEP_FANIN_ROWS_BIG : PSTEP_FANIN_ROWS)) return false;
   }
   out->n_row_wg = nwg;
   out->rows_per_wg = rows;
@@ -1211,7 +1218,7 @@ bool pstep_plan(int d_local, int r, int n_cu, bool storage_f64, bool masked, Pst
 hipError_t pstep_init() {
   for (int rpad = 8; rpad <= 64; rpad *= 2)
     for (int f = 0; f < 4; ++f)
-      for (int np = 4; np <= 16; np *= 2) {      // (every instance is reached by one of these)
+      for (int np = 4; np <= 16; np += 4) {      // (every instance is reached by one of these)
         if (rpad == 64 && (f & 2)) continue;
         const hipError_t e = hipFuncSetAttribute((const void*)pstep_kernel_any(rpad, (f & 1) != 0, np, (f & 2) != 0), hipFuncAttributeMaxDynamicSharedMemorySize, (int)pstep_lds_bytes(rpad));
         if (e != hipSuccess) return e;

@@ -27,7 +27,8 @@ def run(d, r, T, storage, robust, persistent, Y, C0, cuts=None):
 rel = lambda a, b: float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
 rng = np.random.default_rng(0)
 for (d, r, T, storage, robust) in [(948, 48, 12, "f64", False), (947, 47, 12, "f64", False), (944, 44, 12, "f64", True), (933, 33, 12, "f64", False),
-                                   (20000, 40, 400, "f64", False), (20000, 48, 400, "f64", False), (20000, 40, 400, "f32", True), (5000, 36, 400, "f64", False)]:
+                                   (20000, 40, 400, "f64", False), (20000, 48, 400, "f64", False), (20000, 40, 400, "f32", True), (5000, 36, 400, "f64", False),
+                                   (100000, 40, 300, "f32", False), (100000, 48, 300, "f64", True), (70000, 33, 300, "f32", False)]:
     Y = rng.standard_normal((T, d)).astype(np.float32).astype(np.float64)
     C0 = (0.1 * rng.standard_normal((d, r))).astype(np.float32).astype(np.float64)
     a, ea, ka, ta = run(d, r, T, storage, robust, True, Y, C0, cuts=(0, T // 3, T))
