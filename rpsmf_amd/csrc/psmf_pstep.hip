@@ -5,6 +5,8 @@
 //   block 0            the HUB: everything r-sized.  Waves 0-3 ("workers") keep V, P, G, Q, Lbar in registers across the
 //                      steps and do the serial stage of a step; waves 6-7 run the step's r x r inversions as wave-local tile
 //                      sweeps on the f64 matrix cores (psmf_ns.hip) while waves 0-5 collect the row workgroups' partial sums.
+//                      33 <= r <= 48 ("BIG"): no wave can hold its share of five 64 x 64 matrices beside the 3 x 3 tile sweeps, so
+//                      every r x r matrix lives in an LDS image (seven of 48 x 49) and waves 0-5 walk their elements through them.
 //   blocks 1 .. n      ROW workgroups: each keeps its rows of C ON CHIP, as float64 in registers, for the whole launch (12.8 MB
 //                      of float32 storage at d = 1e5, r = 32 = 100 KB of float64 per CU).  Per timestep a row workgroup reads
 //                      y_k (prefetched one step ahead), forms y_hat = C mu_bar, e = y - y_hat, h += c e, C += e w^T / N, stores
@@ -534,7 +536,6 @@ __device__ __forceinline__ void hub_col_reduce(const bool worker, const double p
 
 template <int RPAD, int NT, bool MASKED>
 __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
-  constexpr bool SHARED = NT == 256;         // r > 32: 256-thread workgroups (a wave may hold 512 registers); all four waves are workers, the last two ALSO run the inversions
   constexpr int NWK = RPAD == 64 ? 384 : 256;     // worker threads: waves 0-3 (RPAD = 64: waves 0-5 -- six row groups of 8 rows each, all of the worker loop's threads)
   constexpr int NW = NT / 64;
   constexpr int RG = NWK / RPAD;
@@ -550,8 +551,8 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
   constexpr int NG = 4 * RPAD + 1;
   // threads of the fan-in.  512-thread hub: waves 0, 1, 4, 5 -- the SIMDs (wave id mod 4) of the two solve waves, 6 and 7, are shared
   // with waves 2 and 3, which therefore spend phase A asleep in the workgroup barrier instead of polling LDS beside the tile sweeps
-  constexpr int NFT = SHARED ? (NW - 2) * 64 : 256;
-  constexpr int NLT = SHARED ? NT : NT - 128; // threads that run the worker loop (the two solve waves have a loop of their own)
+  constexpr int NFT = 256;
+  constexpr int NLT = NT - 128;              // threads that run the worker loop (the two solve waves have a loop of their own)
   constexpr int LPC = RPAD == 64 ? 4 : (NT >= 512 ? 8 : 1);     // lanes per column of the fan-in's second level (LPC x (r + 1) <= the worker loop's NLT threads: 4 x 49 at r = 48)
   const StepParams& p = q.sp;
   DevState* st = p.st;
@@ -690,14 +691,14 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
   // fan-in geometry: thread t of waves 0 .. NW-3 sums elements (2 pi, 2 pi + 1) of the partial rows seg, seg + S, ...
   const int npair = ncol2 >> 1;
   const int S = min(NFT / npair, 3 * LPC);   // segments: the second level below sums three of them per lane, LPC lanes per column
-  const int f_tid = SHARED ? tid : (wv < 2 ? tid : (wv >= 4 && wv < 6 ? tid - 128 : NFT));      // index among the fan-in threads
+  const int f_tid = wv < 2 ? tid : (wv >= 4 && wv < 6 ? tid - 128 : NFT);      // index among the fan-in threads
   const bool f_wave = f_tid < NFT;
   const int f_pi = f_tid % npair, f_seg = f_tid / npair;
   const bool f_on = f_wave && f_seg < S;
 
   // ---- the solve waves run a loop of their own (same barriers, none of the workers' registers): the kernel's register allocation
   //      is the larger of the two roles, not their sum ----
-  if (!SHARED && wv >= NW - 2) {
+  if (wv >= NW - 2) {
     PS_PROF_DECL(8);
     PS_PROF_START();
     for (int s = 0; s < q.n_steps; ++s) {
@@ -734,14 +735,7 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
   for (int s = 0; s < q.n_steps; ++s) {
     const unsigned epoch = (unsigned)s + 1u;
     // =========================== phase A: the fan-in (beside the solve waves' inversions) ===========================
-    if (SHARED && wv >= NW - 2) {
-      if (p.coef_update) {      // (r > 32: these waves are workers too and run the inversions of the step here)
-        const int role = wv - (NW - 2);
-        if constexpr (RPAD <= 16) hub_solve<1>(role, dual, carried, r, s_sc[0], s_sc[1], s_sc[2], sL, sG, sPp, sW, LS, s_ctl + 2);
-        else if constexpr (RPAD == 32) hub_solve<2>(role, dual, carried, r, s_sc[0], s_sc[1], s_sc[2], sL, sG, sPp, sW, LS, s_ctl + 2);
-        else hub_solve<3>(role, dual, carried, r, s_sc[0], s_sc[1], s_sc[2], sL, sG, sPp, sW, LS, s_ctl + 2);
-      }
-    } else {
+    {
       if (wv == 0) {
         const long long t0 = (long long)__builtin_amdgcn_s_memrealtime();
         int stop = 0;
@@ -1120,8 +1114,8 @@ __device__ __forceinline__ void pstep_hub(const PstepParams& q, char* smem) {
 
 // NP: row passes of a row workgroup, all of them unrolled and executed (rows beyond the workgroup's share are masked): no branch
 // between the passes, so their dot products, lane sums and updates interleave.  NT: threads per workgroup -- 512 in every instance
-// (RPAD = 64, 33 <= r <= 48: the hub's r x r matrices live in LDS, pstep_hub BIG; its 256-thread form with everything in registers, the
-// SHARED branches of pstep_hub, spilled 2.7 KB per lane and is not instantiated).
+// (RPAD = 64, 33 <= r <= 48: the hub's r x r matrices live in LDS, pstep_hub BIG; a 256-thread form with everything in registers
+// spilled 2.7 KB per lane and was removed).
 template <typename T, int RPAD, int NP, int NT, bool MASKED>
 __global__ __launch_bounds__(NT) void psmf_pstep_k(PstepParams q) {
   extern __shared__ __attribute__((aligned(16))) char ps_smem[];
