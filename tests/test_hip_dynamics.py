@@ -567,3 +567,45 @@ def test_simplified_hooks_kernel_vs_oracle(kind, robust, recursive):
     if robust:
         assert relerr(s["rho"], st.rho) < 1e-9 and relerr(s["lam"], st.lam) < 1e-12
     f.close()
+
+
+def test_q_matrix_schedule_refusals_and_dense_dynamics_with_it():
+    """psmf_set_q_matrix_schedule: refused where it cannot hold (blocked engine, rPSMF's own running Q), range-checked by psmf_run,
+    dropped again by None; and together with a dense-Jacobian kind (P_bar = F P F^T + Q_k, both in the serial stage) against the oracle."""
+    c = _capi()
+    d, r, T = 350, 5, 24
+    Y, C0 = _problem(d, r, T, 31)
+    rng = np.random.default_rng(4)
+    Qm = np.empty((T + 1, r, r))
+    for k in range(T + 1):
+        A = rng.standard_normal((r, r))
+        Qm[k] = 0.05 * np.eye(r) + 0.01 * A @ A.T
+    f = c.DeviceFilter(d, r, storage="f64", engine="block")
+    with pytest.raises(ValueError):
+        f.set_q_matrix_schedule(Qm)
+    f.close()
+    f = c.DeviceFilter(d, r, storage="f64", engine="step", robust=True)
+    with pytest.raises(ValueError):
+        f.set_q_matrix_schedule(Qm)
+    f.close()
+    nl = NL.Sinusoid(r)
+    theta = _theta_for(nl, rng, r)
+    V0, P0 = 0.1 * np.eye(r), np.eye(r)
+    st = O.State(C=C0, V=V0, mu=np.zeros(r), P=P0, Q=Qm[1], rho=1.0, lam=0.0, theta=theta.copy(), gradsum=np.zeros(nl.n_params))
+    st, Yp, _ = O.run_epoch(st, Y, O.Mode(), O.CallableDyn(nl, nl.n_params), Qs=lambda k: Qm[k])
+    f = c.DeviceFilter(d, r, storage="f64", engine="step", dyn_kind=nl.device_kind, dyn_flags=nl.device_flags, dyn_terms=nl.device_terms)
+    f.upload_series(Y)
+    f.set_state(C0, V0, P0, Qm[1], np.zeros(r), rho=1.0, lambda0=0.0, theta=theta)
+    f.set_q_matrix_schedule(Qm[:T])                      # one matrix short: the last step is beyond the schedule
+    with pytest.raises(ValueError):
+        f.run(0, T)
+    f.set_q_matrix_schedule(Qm)
+    f.set_state(C0, V0, P0, Qm[1], np.zeros(r), rho=1.0, lambda0=0.0, theta=theta)
+    f.zero_gradsum()
+    f.run(0, T)
+    s = f.get_state()
+    for n in ("C", "V", "mu", "P"):
+        assert relerr(s[n], getattr(st, n)) < 1e-8, n
+    assert relerr(f.y_pred(0, T), Yp) < 1e-8 and relerr(s["gradsum"], st.gradsum) < 1e-7
+    f.set_q_matrix_schedule(None)                        # back to the constant Q of the state
+    f.close()
