@@ -30,7 +30,9 @@ Extra objects on the JSON line (rank 0; the N = 1 run carries all of them):
   cpu_baseline_literal    the reference-shaped O(d^2 r) algebra (dense R, d x d inverse innovation: what the
                 reference itself costs) at d = 2000, where it still fits
   other_configs BASELINE configs B, C (d = 10 000, r = 20, T = 5 000, PSMF / rPSMF) and D (masked filter, 19 x 295 719,
-                50 seeds in one launch): throughput + parity against the oracle, each
+                50 seeds in one launch): throughput + parity against the oracle, each; config E again with float64 storage, on the
+                per-step engine (one persistent launch per pass) and masked; a small rank (r = 12) and r = 40 (beyond the blocked
+                engine: the persistent per-step kernel with the hub's matrices in LDS); ExperimentSynthetic's hooks, Beijing's dynamics
 """
 
 import argparse
