@@ -252,4 +252,100 @@ __device__ __forceinline__ void wave_sweep_tiles_m(double (&A)[NT][NT][4], const
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// A <- -A^-1 for 33 <= r2 <= 48 (3 x 3 tiles) by BLOCKS instead of 24 rounds over all nine tiles (round 5): with A = [[A11, B], [B^T, D]],
+// A11 the leading 32 x 32,
+//     A11^-1 (sweep on 2 x 2 tiles: 16 rounds of 4 MFMAs),  E = A11^-1 B,  S = D - B^T E,  S^-1 (sweep on one tile: (r2 - 32) / 2 rounds),
+//     A^-1 = [[A11^-1 + F E^T, -F], [-F^T, S^-1]],  F = E S^-1.
+// Every product is  C = X^T Y  over tiles in the MFMA output layout ("T-layout"), which is the B-operand layout of Y and the
+// A-operand layout of X^T (psmf_blk3.hip) -- no operand is shuffled:  E = A11^-1^T B (A11^-1 symmetric),  E^T = B^T A11^-1,
+// S = D - B^T E,  F^T = S^-1^T E^T,  F = (E^T)^T S^-1,  F E^T = (F^T)^T E^T.  72 MFMAs of products beside the two short sweeps: a
+// round of the 3 x 3 sweep costs ~1 700 cycles of one wave's instruction stream, of the 2 x 2 one ~850, of the single tile ~500.
+// Identity padding beyond r2 (as wave_sweep_tiles_m expects it) stays padding: the padded rows / columns of B are zero.
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void tile_xty(const double (&X)[4], const double (&Y)[4], f64x4& acc) {      // acc += X^T Y  (16 x 16 tiles, K = 16)
+#pragma unroll
+  for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[q], Y[q], acc, 0, 0, 0);
+}
+
+__device__ __forceinline__ void wave_inverse_blocked3(double (&A)[3][3][4], const int r2, const Sw16K& c, bool& bad) {
+  double T[2][2][4];
+#pragma unroll
+  for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) T[ti][tj][q] = A[ti][tj][q];
+  wave_sweep_tiles_m<2>(T, 32, c, bad);                       // T = -A11^-1
+  // (every group of products below runs its independent accumulators interleaved, k-step by k-step: an MFMA that accumulates into the
+  //  result of the one before it waits for it)
+#define MF(acc_, x_, y_) acc_ = __builtin_amdgcn_mfma_f64_16x16x4f64(x_, y_, acc_, 0, 0, 0)
+  // E = A11^-1 B = -(T^T B)  (two row tiles);  E^T = -(B^T T)  (two column tiles)
+  double E[2][4], Et[2][4];
+  {
+    f64x4 e0 = {0.0, 0.0, 0.0, 0.0}, e1 = e0, t0 = e0, t1 = e0;
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        MF(e0, T[m][0][q], A[m][2][q]); MF(e1, T[m][1][q], A[m][2][q]);
+        MF(t0, A[m][2][q], T[m][0][q]); MF(t1, A[m][2][q], T[m][1][q]);
+      }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { E[0][q] = -e0[q]; E[1][q] = -e1[q]; Et[0][q] = -t0[q]; Et[1][q] = -t1[q]; }
+  }
+  // S = D - B^T E
+  double S1[1][1][4];
+  {
+    f64x4 s0 = {0.0, 0.0, 0.0, 0.0}, s1 = s0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { MF(s0, A[0][2][q], E[0][q]); MF(s1, A[1][2][q], E[1][q]); }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) S1[0][0][q] = A[2][2][q] - (s0[q] + s1[q]);
+  }
+  wave_sweep_tiles_m<1>(S1, r2 - 32, c, bad);                 // S1 = -S^-1 on its leading (r2 - 32) block; the padding keeps its ones
+  // F^T = S^-1 E^T = -(S1^T E^T),  F = E S^-1 = -((E^T)^T S1)
+  double Ft[2][4], F[2][4];
+  {
+    f64x4 a0 = {0.0, 0.0, 0.0, 0.0}, a1 = a0, b0 = a0, b1 = a0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      MF(a0, S1[0][0][q], Et[0][q]); MF(a1, S1[0][0][q], Et[1][q]);
+      MF(b0, Et[0][q], S1[0][0][q]); MF(b1, Et[1][q], S1[0][0][q]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { Ft[0][q] = -a0[q]; Ft[1][q] = -a1[q]; F[0][q] = -b0[q]; F[1][q] = -b1[q]; }
+  }
+  // -A^-1: top left -(A11^-1 + F E^T) = T - (F^T)^T E^T, top right +F, bottom left +F^T, bottom right -S^-1 = S1
+  {
+    f64x4 c00 = {0.0, 0.0, 0.0, 0.0}, c01 = c00, c10 = c00, c11 = c00;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      MF(c00, Ft[0][q], Et[0][q]); MF(c01, Ft[0][q], Et[1][q]);
+      MF(c10, Ft[1][q], Et[0][q]); MF(c11, Ft[1][q], Et[1][q]);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      A[0][0][q] = T[0][0][q] - c00[q]; A[0][1][q] = T[0][1][q] - c01[q];
+      A[1][0][q] = T[1][0][q] - c10[q]; A[1][1][q] = T[1][1][q] - c11[q];
+    }
+  }
+#undef MF
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { A[t][2][q] = F[t][q]; A[2][t][q] = Ft[t][q]; }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) A[2][2][q] = S1[0][0][q];
+}
+
+// the sweep a solve uses for NTL x NTL tiles: by blocks where that is the shorter instruction stream (NTL = 3)
+template <int NTL>
+__device__ __forceinline__ void wave_invert_tiles(double (&A)[NTL][NTL][4], const int r2, const Sw16K& c, bool& bad) {
+  if constexpr (NTL == 3) {
+    if (r2 > 32) { wave_inverse_blocked3(A, r2, c, bad); return; }
+  }
+  wave_sweep_tiles_m<NTL>(A, r2, c, bad);
+}
+
 }  // namespace psmf

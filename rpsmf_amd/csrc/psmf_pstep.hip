@@ -498,19 +498,19 @@ __device__ __forceinline__ void hub_solve(const int role, const bool dual, const
       const double mv = sL[ic * LS + cc] + kappa * sG[ic * LS + cc];
       A[ti][tj][qq] = in ? (role == 0 ? mv : mv * ib + (i == cI ? iq : 0.0)) : (pad ? 1.0 : 0.0);
     })
-    wave_sweep_tiles_m<NTL>(A, r2, swk, bad);
+    wave_invert_tiles<NTL>(A, r2, swk, bad);
     double* dst = role == 0 ? sPp : sW;
     HS_FOR({ if (in) dst[i * LS + cI] = -A[ti][tj][qq]; })
   } else {
     HS_FOR({ A[ti][tj][qq] = in ? 0.5 * (sL[ic * LS + cc] + sL[cc * LS + ic]) : (pad ? 1.0 : 0.0); })      // sL holds Pbar here
-    wave_sweep_tiles_m<NTL>(A, r2, swk, bad);                       // -Pbar^-1
+    wave_invert_tiles<NTL>(A, r2, swk, bad);                       // -Pbar^-1
     double Mx[NTL][NTL][4];
     HS_FOR({ Mx[ti][tj][qq] = in ? kappa * sG[ic * LS + cc] - A[ti][tj][qq] : (pad ? 1.0 : 0.0); A[ti][tj][qq] = Mx[ti][tj][qq]; })
-    wave_sweep_tiles_m<NTL>(A, r2, swk, bad);                       // -P+
+    wave_invert_tiles<NTL>(A, r2, swk, bad);                       // -P+
     HS_FOR({ if (in) sPp[i * LS + cI] = -A[ti][tj][qq]; })
     if (dual) {
       HS_FOR({ A[ti][tj][qq] = in ? Mx[ti][tj][qq] * ib + (i == cI ? iq : 0.0) : (pad ? 1.0 : 0.0); })
-      wave_sweep_tiles_m<NTL>(A, r2, swk, bad);                     // -W
+      wave_invert_tiles<NTL>(A, r2, swk, bad);                     // -W
       HS_FOR({ if (in) sW[i * LS + cI] = -A[ti][tj][qq]; })
     }
   }

@@ -133,19 +133,19 @@ __device__ __forceinline__ void solve_block_wave_t(const StepParams& p) {
       const double mv = Ll[ti][tj][q] + Gk[ti][tj][q];
       A[ti][tj][q] = in ? (w == 0 ? mv : mv * ib + (i == c ? iq : 0.0)) : (pad ? 1.0 : 0.0);
     })
-    wave_sweep_tiles_m<NT>(A, r2, swk, bad);
+    wave_invert_tiles<NT>(A, r2, swk, bad);
     double* dst = w == 0 ? st->Pplus : st->XpY;
     WS_FOR({ if (in) dst[i * r + c] = -A[ti][tj][q]; })
   } else {
     WS_FOR({ A[ti][tj][q] = in ? at(st->Pbar, ic, cc) : (pad ? 1.0 : 0.0); })
-    wave_sweep_tiles_m<NT>(A, r2, swk, bad);                       // -Pbar^-1
+    wave_invert_tiles<NT>(A, r2, swk, bad);                       // -Pbar^-1
     WS_FOR({ Gk[ti][tj][q] = in ? Gk[ti][tj][q] - A[ti][tj][q] : (pad ? 1.0 : 0.0); A[ti][tj][q] = Gk[ti][tj][q]; })     // Gk now holds M
-    wave_sweep_tiles_m<NT>(A, r2, swk, bad);                       // -P+
+    wave_invert_tiles<NT>(A, r2, swk, bad);                       // -P+
     WS_FOR({ if (in) st->Pplus[i * r + c] = -A[ti][tj][q]; })
     if (dual) {
       const double iq = 1.0 / q0, ib = p.robust ? 1.0 / p.beta : 1.0;
       WS_FOR({ A[ti][tj][q] = in ? Gk[ti][tj][q] * ib + (i == c ? iq : 0.0) : (pad ? 1.0 : 0.0); })
-      wave_sweep_tiles_m<NT>(A, r2, swk, bad);                     // -W
+      wave_invert_tiles<NT>(A, r2, swk, bad);                     // -W
       WS_FOR({ if (in) st->XpY[i * r + c] = -A[ti][tj][q]; })
     }
   }
@@ -198,23 +198,23 @@ __device__ __forceinline__ void solve_block_wave_big_t(const StepParams& p) {
       const double mv = st->Lbar[ic * r + cc] + WB_GK();
       A[ti][tj][q] = in ? (w == 0 ? mv : mv * ib + (i == c ? iq : 0.0)) : (pad ? 1.0 : 0.0);
     })
-    wave_sweep_tiles_m<NT>(A, r2, swk, bad);
+    wave_invert_tiles<NT>(A, r2, swk, bad);
     double* dst = w == 0 ? st->Pplus : st->XpY;
     WB_FOR({ if (in) dst[i * r + c] = -A[ti][tj][q]; })
   } else {
     WB_FOR({ A[ti][tj][q] = in ? 0.5 * (st->Pbar[ic * r + cc] + st->Pbar[cc * r + ic]) : (pad ? 1.0 : 0.0); })
-    wave_sweep_tiles_m<NT>(A, r2, swk, bad);                       // -Pbar^-1
+    wave_invert_tiles<NT>(A, r2, swk, bad);                       // -Pbar^-1
     if (dual) {
       double Mx[NT][NT][4];
       WB_FOR({ Mx[ti][tj][q] = in ? WB_GK() - A[ti][tj][q] : (pad ? 1.0 : 0.0); A[ti][tj][q] = Mx[ti][tj][q]; })
-      wave_sweep_tiles_m<NT>(A, r2, swk, bad);                     // -P+
+      wave_invert_tiles<NT>(A, r2, swk, bad);                     // -P+
       WB_FOR({ if (in) st->Pplus[i * r + c] = -A[ti][tj][q]; })
       WB_FOR({ A[ti][tj][q] = in ? Mx[ti][tj][q] * ib + (i == c ? iq : 0.0) : (pad ? 1.0 : 0.0); })
-      wave_sweep_tiles_m<NT>(A, r2, swk, bad);                     // -W
+      wave_invert_tiles<NT>(A, r2, swk, bad);                     // -W
       WB_FOR({ if (in) st->XpY[i * r + c] = -A[ti][tj][q]; })
     } else {
       WB_FOR({ A[ti][tj][q] = in ? WB_GK() - A[ti][tj][q] : (pad ? 1.0 : 0.0); })
-      wave_sweep_tiles_m<NT>(A, r2, swk, bad);                     // -P+
+      wave_invert_tiles<NT>(A, r2, swk, bad);                     // -P+
       WB_FOR({ if (in) st->Pplus[i * r + c] = -A[ti][tj][q]; })
     }
   }
