@@ -366,7 +366,7 @@ __device__ __forceinline__ void f7_program(const BlockParams& b) {
           for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
             for (int q = 0; q < 4; ++q) A[ti][tj][q] = Pb[ti][tj][q] + (ti == tj ? dgq[q] * (1.0 - frow[ti][q]) : 0.0);
-        wave_sweep_tiles_m<2>(A, r2, swk, bad);              // -Pbar^-1
+        wave_invert_tiles<2>(A, r2, swk, bad);               // -Pbar^-1 (by blocks: psmf_ns.hip)
       }
     } else if (wv == 2) {
       // ================= phase A, V wave: w = V mu_bar, s; N, kappa when wave 0's eta is there =================

@@ -85,7 +85,7 @@ __device__ __forceinline__ void f4_sweep_image(const F3Lds& L, double* im, const
           }
       Sw16K swk;
       sw16k_init(swk, lk, lr);
-      wave_sweep_tiles_m<2>(A, r2, swk, bad);
+      wave_invert_tiles<2>(A, r2, swk, bad);
 #pragma unroll
       for (int ti = 0; ti < 2; ++ti)
 #pragma unroll

@@ -268,6 +268,7 @@ __device__ __forceinline__ void tile_xty(const double (&X)[4], const double (&Y)
   for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(X[q], Y[q], acc, 0, 0, 0);
 }
 
+__device__ __forceinline__ void wave_inverse_blocked2(double (&A)[2][2][4], const int r2, const Sw16K& c, bool& bad);
 __device__ __forceinline__ void wave_inverse_blocked3(double (&A)[3][3][4], const int r2, const Sw16K& c, bool& bad) {
   double T[2][2][4];
 #pragma unroll
@@ -276,7 +277,7 @@ __device__ __forceinline__ void wave_inverse_blocked3(double (&A)[3][3][4], cons
     for (int tj = 0; tj < 2; ++tj)
 #pragma unroll
       for (int q = 0; q < 4; ++q) T[ti][tj][q] = A[ti][tj][q];
-  wave_sweep_tiles_m<2>(T, 32, c, bad);                       // T = -A11^-1
+  wave_inverse_blocked2(T, 32, c, bad);                       // T = -A11^-1
   // (every group of products below runs its independent accumulators interleaved, k-step by k-step: an MFMA that accumulates into the
   //  result of the one before it waits for it)
 #define MF(acc_, x_, y_) acc_ = __builtin_amdgcn_mfma_f64_16x16x4f64(x_, y_, acc_, 0, 0, 0)
@@ -339,11 +340,60 @@ __device__ __forceinline__ void wave_inverse_blocked3(double (&A)[3][3][4], cons
   for (int q = 0; q < 4; ++q) A[2][2][q] = S1[0][0][q];
 }
 
-// the sweep a solve uses for NTL x NTL tiles: by blocks where that is the shorter instruction stream (NTL = 3)
+// The same by blocks for 17 <= r2 <= 32 (2 x 2 tiles): two single-tile sweeps (8 + (r2 - 16) / 2 rounds of ~500 cycles) and 24 MFMAs of
+// products against 16 rounds of ~850 on four tiles.  Each 16 x 16 x 16 product is split over two accumulators (k-steps 0, 1 | 2, 3): half
+// the chain of dependent MFMAs.
+__device__ __forceinline__ void wave_inverse_blocked2(double (&A)[2][2][4], const int r2, const Sw16K& c, bool& bad) {
+#define MF(acc_, x_, y_) acc_ = __builtin_amdgcn_mfma_f64_16x16x4f64(x_, y_, acc_, 0, 0, 0)
+  double T[1][1][4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) T[0][0][q] = A[0][0][q];
+  wave_sweep_tiles_m<1>(T, 16, c, bad);                       // T = -A11^-1
+  double E[4], Et[4];
+  {
+    f64x4 e0 = {0.0, 0.0, 0.0, 0.0}, e1 = e0, t0 = e0, t1 = e0;
+    MF(e0, T[0][0][0], A[0][1][0]); MF(e1, T[0][0][2], A[0][1][2]); MF(t0, A[0][1][0], T[0][0][0]); MF(t1, A[0][1][2], T[0][0][2]);
+    MF(e0, T[0][0][1], A[0][1][1]); MF(e1, T[0][0][3], A[0][1][3]); MF(t0, A[0][1][1], T[0][0][1]); MF(t1, A[0][1][3], T[0][0][3]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { E[q] = -(e0[q] + e1[q]); Et[q] = -(t0[q] + t1[q]); }
+  }
+  double S1[1][1][4];
+  {
+    f64x4 s0 = {0.0, 0.0, 0.0, 0.0}, s1 = s0;
+    MF(s0, A[0][1][0], E[0]); MF(s1, A[0][1][2], E[2]);
+    MF(s0, A[0][1][1], E[1]); MF(s1, A[0][1][3], E[3]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) S1[0][0][q] = A[1][1][q] - (s0[q] + s1[q]);
+  }
+  wave_sweep_tiles_m<1>(S1, r2 - 16, c, bad);                 // S1 = -S^-1 (padding keeps its ones)
+  double Ft[4], F[4];
+  {
+    f64x4 a0 = {0.0, 0.0, 0.0, 0.0}, a1 = a0, b0 = a0, b1 = a0;
+    MF(a0, S1[0][0][0], Et[0]); MF(a1, S1[0][0][2], Et[2]); MF(b0, Et[0], S1[0][0][0]); MF(b1, Et[2], S1[0][0][2]);
+    MF(a0, S1[0][0][1], Et[1]); MF(a1, S1[0][0][3], Et[3]); MF(b0, Et[1], S1[0][0][1]); MF(b1, Et[3], S1[0][0][3]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) { Ft[q] = -(a0[q] + a1[q]); F[q] = -(b0[q] + b1[q]); }
+  }
+  {
+    f64x4 c0 = {0.0, 0.0, 0.0, 0.0}, c1 = c0;
+    MF(c0, Ft[0], Et[0]); MF(c1, Ft[2], Et[2]);
+    MF(c0, Ft[1], Et[1]); MF(c1, Ft[3], Et[3]);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) A[0][0][q] = T[0][0][q] - (c0[q] + c1[q]);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) { A[0][1][q] = F[q]; A[1][0][q] = Ft[q]; A[1][1][q] = S1[0][0][q]; }
+#undef MF
+}
+
+// the sweep a solve uses for NTL x NTL tiles: by blocks where that is the shorter instruction stream (NTL = 2, 3)
 template <int NTL>
 __device__ __forceinline__ void wave_invert_tiles(double (&A)[NTL][NTL][4], const int r2, const Sw16K& c, bool& bad) {
   if constexpr (NTL == 3) {
     if (r2 > 32) { wave_inverse_blocked3(A, r2, c, bad); return; }
+  }
+  if constexpr (NTL == 2) {
+    if (r2 > 16) { wave_inverse_blocked2(A, r2, c, bad); return; }
   }
   wave_sweep_tiles_m<NTL>(A, r2, c, bad);
 }
