@@ -195,12 +195,13 @@ __device__ __forceinline__ void f7_program(const BlockParams& b) {
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
     fcol[t] = (16 * t + lr < r) ? 1.0 : 0.0;
-    caug[t] = (16 * t + lr == r2) ? 1.0 : 0.0;                      // column r2 (the augmentation; none when r2 = 32)
+    caug[t] = 0.0;                  // (round 5: no augmentation -- the inversion by blocks, psmf_ns.hip, is a plain inverse and saves more than
+                                    //  kappa P+ h as a product costs; the augmented sweep was  (16 * t + lr == r2) ? 1.0 : 0.0  here)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int i = 16 * t + lk + 4 * q;
       frow[t][q] = i < r ? 1.0 : 0.0;
-      raug[t][q] = i == r2 ? 1.0 : 0.0;
+      raug[t][q] = 0.0;
     }
   }
 #pragma unroll
@@ -227,7 +228,7 @@ __device__ __forceinline__ void f7_program(const BlockParams& b) {
           Vm[ti][tj][q] = in ? lv : 0.0;
         }
       }
-  const bool aug_fits = r2 < 32;
+  const bool aug_fits = false;              // (r2 < 32 with the augmented sweep)
   Sw16K swk;
   if (wv == 0) sw16k_init(swk, lk, lr);
   double rho = st->rho, lam = st->lam;
@@ -478,7 +479,7 @@ __device__ __forceinline__ void f7_program(const BlockParams& b) {
               A[ti][tj][q] = fma(kappa, Gm[ti][tj][q], pad - fin * A[ti][tj][q]) +
                              (caug[tj] * frow[ti][q] * (kappa * hrow[ti][q]) + raug[ti][q] * fcol[tj] * (kappa * hcol[tj]));
             }
-        wave_sweep_tiles_m<2>(A, r2, swk, bad);              // [[-P+, kappa P+ h], [., 1 - kappa^2 h'P+h]]
+        wave_invert_tiles<2>(A, r2, swk, bad);               // -P+ (kappa P+ h as a product below)
         BLK_T(4);
 #pragma unroll
         for (int ti = 0; ti < 2; ++ti)
