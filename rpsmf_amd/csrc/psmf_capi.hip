@@ -775,8 +775,12 @@ void compute_geometry(const psmf_config& c, Geometry& g, const int sweep_nt = 51
 // full filter, uniform R, wave-local solve, no Q_k schedule: q of the next step is q -- or omega q -- of this one)
 void update_solve_dual(psmf_filter* h) {
   const psmf_config& c = h->cfg;
+  // Lbar' = (I / q - W / q^2) / omega loses log10((p + q) / q) digits to cancellation (p: the scale of P): with float64 storage, whose
+  // results are otherwise good to 1e-11, the side-by-side form is left where that is more than five (q = 1e-8 against P0 = I: 3e-8
+  // measured, 3e-11 with the inversions one after the other -- tools/probe_step_tinyq.py); float32 storage has its 1e-7 anyway
+  const bool cancels = c.storage == PSMF_F64 && h->q_last > 0.0 && h->p_diag_max > 1e5 * h->q_last;
   const int v = (h->sw.step_dual && h->engine == 1 && h->q_iso && c.masked < 2 && c.dyn_kind == PSMF_DYN_RANDOM_WALK && c.coef_update && c.pbar_predict && !c.nonuniform_R &&
-                 !h->sp.solve_lds && !h->sp.q_sched && !h->sp.q_mat) ? 1 : 0;
+                 !h->sp.solve_lds && !h->sp.q_sched && !h->sp.q_mat && !cancels) ? 1 : 0;
   if (v != h->sp.solve_dual) {
     h->sp.solve_dual = v;
     destroy_graph(h);        // the captured launches carry the old parameter block
@@ -1265,6 +1269,7 @@ int psmf_set_state(psmf_handle h, const double* C, const double* V, const double
     double m = 0.0;
     for (int i = 0; i < r; ++i) m = std::fmax(m, std::fabs(P[(size_t)i * r + i]));
     h->p_diag_max = m;
+    if (!Q) update_solve_dual(h);
   }
   if (Q) {
     HIP_TRY(h, hipMemcpy(h->st->Q, Q, rr, hipMemcpyHostToDevice));

@@ -112,3 +112,38 @@ def test_adversarial_series_on_filter4(name, r, robust):
     assert e < TOL, (name, "y_pred", e)
     assert tot["ns_steps"] + tot["sweep_steps"] == T, tot
     print("filter4", name, f"r={r} worst rel-err {worst:.1e}, y_pred {e:.1e}", tot)
+
+
+STEP_COMBOS = [(n, 32, False, "f64") for n in CASES] + [("tiny_Q", 20, True, "f64"), ("tiny_P0", 40, False, "f64"), ("tiny_Q", 44, True, "f64"),
+                                                     ("outlier_block", 32, False, "f32")]
+
+
+@pytest.mark.parametrize("name,r,robust,storage", STEP_COMBOS, ids=[f"step-{n}-{'rPSMF' if rb else 'PSMF'}_r{r}_{s}" for n, r, rb, s in STEP_COMBOS])
+def test_adversarial_series_on_the_per_step_engine(name, r, robust, storage):
+    """The same series on the persistent per-step kernel, whose r x r inversions are direct -- by blocks since round 5 (psmf_ns.hip:
+    leading block, Schur complement on one tile; r = 20, 32: 2 x 2 tiles, r = 40, 44: 3 x 3): q = 1e-8, a nearly singular P0 and
+    1000-sigma innovations against the float64 oracle at float64 tolerance.  (q = 1e-8 with P0 = I: psmf_set_state takes the
+    inversions one after the other there -- the side-by-side form's Lbar' = (I / q - W / q^2) / omega cancels eight digits.)"""
+    from rpsmf_amd import _capi
+
+    cs = make_case(name, D, r, T, robust)
+    st = O.State(C=cs["C0"].copy(), V=cs["V0"], mu=np.zeros(r), P=cs["P0"], Q=cs["Q"], rho=1.0, lam=1.8)
+    st, Yp, trace = O.run_epoch(st, cs["Y"].astype(np.float64), O.Mode(robust=robust), O.RandomWalkDyn(), keep=cs["checkpoints"],
+                                want_grad=False)
+    f = _capi.DeviceFilter(D, r, robust=robust, storage=storage, engine="step")
+    f.upload_series(cs["Y"])
+    f.set_state(cs["C0"], cs["V0"], cs["P0"], cs["Q"], np.zeros(r), rho=1.0, lambda0=1.8)
+    assert f.geometry()["filter_kernel"] == "psmf_pstep_k"
+    tol = 1e-8 if storage == "f64" else TOL
+    k_prev = 0
+    for k in cs["checkpoints"]:
+        f.run(k_prev, k)
+        s = f.get_state()
+        ref = trace[k][0]
+        for n in ("C", "V", "mu", "P"):
+            e = relerr(s[n], getattr(ref, n))
+            assert e < tol, (name, n, k, e)
+        k_prev = k
+    e = relerr(f.y_pred(0, T), Yp)
+    f.close()
+    assert e < tol, (name, "y_pred", e)
